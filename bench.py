@@ -1,0 +1,118 @@
+#!/usr/bin/env python3
+"""Headline benchmark: training throughput (images/s, whole job) of the deep-MNIST
+CNN on N MI355X GPUs, synchronous data parallel over RCCL.
+
+  python bench.py --gpus 1 --steps 200 --warmup 20
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+      --master-port P bench.py --gpus N --steps K --warmup W
+
+Metric / config follow BASELINE.json ("train images/sec (whole node) at 1/2/4/8
+MI355X", sync DP, global batch 8192 at 8 GPUs): weak scaling with a fixed
+per-GPU batch of 1024, bf16 compute with fp32 master weights, the reference's
+optimizer (plain SGD, lr 1e-3, dropout keep_prob 1.0; reference
+.idea/MNISTDist.py:30,149,179), HBM-resident synthetic 28x28x1 data, random
+TF-style init.  Every step runs sampler + forward + loss + backward +
+gradient all-reduce + update + global_step increment; nothing is skipped.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--per_gpu_batch", type=int, default=1024)
+    ap.add_argument("--model", default="deep_mnist")
+    ap.add_argument("--optimizer", default="sgd")
+    ap.add_argument("--keep_prob", type=float, default=1.0)
+    ap.add_argument("--dataset_size", type=int, default=60000)
+    ap.add_argument("--no_graph", action="store_true", help="eager launches instead of HIP-graph replay (1 GPU)")
+    args = ap.parse_args()
+
+    from distributed_tensorflow_amd.engine import DeviceDataset, HipEngine
+    from distributed_tensorflow_amd.models.spec import ModelSpec
+    from distributed_tensorflow_amd.parallel.sync_dp import SyncDataParallel
+    from distributed_tensorflow_amd.parallel import comm
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run for N>1")
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        comm.init_process_group(backend="nccl", rank=rank, world_size=world, device=torch.device("cuda", local_rank))
+
+    spec = ModelSpec.from_name(args.model)
+    B = args.per_gpu_batch
+    ds = DeviceDataset.synthetic(args.dataset_size, seed=1234)
+    eng = HipEngine(spec, B, ds, optimizer=args.optimizer, learning_rate=1e-3, keep_prob=args.keep_prob,
+                    seed=1000 + rank)
+    eng.init_params(seed=7)
+
+    if world > 1:
+        dp = SyncDataParallel(eng)
+        dp.broadcast_parameters()
+        step = dp.train_step
+    else:
+        if not args.no_graph:
+            eng.capture()
+        step = eng.train_step
+
+    def barrier():
+        if world > 1:
+            torch.distributed.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    barrier()
+    dt = time.perf_counter() - t0
+
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+        dt = float(t.item())
+    loss, acc = eng.last_metrics()
+    if rank == 0:
+        global_batch = B * world
+        value = global_batch * args.steps / dt
+        _, fb = spec.flops_per_image()
+        print(json.dumps({
+            "metric": "train images/sec (whole node)",
+            "value": round(value, 1),
+            "unit": "images/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": round(1e3 * dt / args.steps, 4),
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "bf16",
+            "data": "synthetic (HBM-resident 28x28x1, random TF-style init)",
+            "config": {"model": spec.name, "global_batch": global_batch, "per_gpu_batch": B, "seq_len": None,
+                       "parallelism": f"dp{world}", "optimizer": args.optimizer, "keep_prob": args.keep_prob,
+                       "graph": (world == 1 and not args.no_graph)},
+            "model_tflops": round(value * fb / 1e12, 2),
+            "final_loss": round(loss, 4),
+        }))
+    if world > 1:
+        torch.distributed.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,105 @@
+// Shared device helpers for the gfx950 (MI355X / CDNA4) kernels.
+//
+// Everything here assumes wave64, the unified VGPR/AGPR file and the
+// 16x16x32 bf16 MFMA fragment maps of CDNA4:
+//   A frag: lane l holds A[row = l&15][k = 8*(l>>4) + j], j = 0..7
+//   B frag: lane l holds B[k = 8*(l>>4) + j][col = l&15]
+//   C/D   : lane l holds D[row = 4*(l>>4) + r][col = l&15], r = 0..3
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace dtf {
+
+typedef __bf16 bf16;
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
+typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef __attribute__((ext_vector_type(4))) short s16x4;
+typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
+typedef __attribute__((ext_vector_type(2))) unsigned int u32x2;
+
+constexpr int kWave = 64;
+
+__device__ __forceinline__ f32x4 mfma16(bf16x8 a, bf16x8 b, f32x4 c) {
+  return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
+}
+
+// ---------------------------------------------------------------------------
+// Counter-based RNG: Philox4x32-10 (Salmon et al.), used for dropout masks and
+// the truncated-normal initialiser.  Stateless: (key, counter) -> 4 x u32.
+// ---------------------------------------------------------------------------
+struct Philox {
+  static __host__ __device__ __forceinline__ void mulhilo(uint32_t a, uint32_t b,
+                                                         uint32_t& hi, uint32_t& lo) {
+    uint64_t p = (uint64_t)a * (uint64_t)b;
+    hi = (uint32_t)(p >> 32);
+    lo = (uint32_t)p;
+  }
+  static __host__ __device__ __forceinline__ void run(uint64_t key, uint64_t ctr_lo,
+                                                     uint64_t ctr_hi, uint32_t out[4]) {
+    uint32_t c0 = (uint32_t)ctr_lo, c1 = (uint32_t)(ctr_lo >> 32);
+    uint32_t c2 = (uint32_t)ctr_hi, c3 = (uint32_t)(ctr_hi >> 32);
+    uint32_t k0 = (uint32_t)key, k1 = (uint32_t)(key >> 32);
+#pragma unroll
+    for (int r = 0; r < 10; ++r) {
+      uint32_t hi0, lo0, hi1, lo1;
+      mulhilo(0xD2511F53u, c0, hi0, lo0);
+      mulhilo(0xCD9E8D57u, c2, hi1, lo1);
+      uint32_t n0 = hi1 ^ c1 ^ k0, n1 = lo1, n2 = hi0 ^ c3 ^ k1, n3 = lo0;
+      c0 = n0; c1 = n1; c2 = n2; c3 = n3;
+      k0 += 0x9E3779B9u;
+      k1 += 0xBB67AE85u;
+    }
+    out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
+  }
+};
+
+__host__ __device__ __forceinline__ float u32_to_unit_float(uint32_t x) {
+  // [0,1) with 24 bits of mantissa.
+  return (float)(x >> 8) * (1.0f / 16777216.0f);
+}
+
+// ---------------------------------------------------------------------------
+// Stateless epoch shuffle: a 4-round Feistel network over 2^(2*hb) >= n with
+// cycle walking gives a bijection on [0, n).  Mirrors
+// distributed_tensorflow_amd/data/sampler.py::feistel_permute bit for bit.
+// ---------------------------------------------------------------------------
+__host__ __device__ __forceinline__ uint32_t mix32(uint32_t x) {
+  x ^= x >> 16; x *= 0x7feb352du;
+  x ^= x >> 15; x *= 0x846ca68bu;
+  x ^= x >> 16;
+  return x;
+}
+
+__host__ __device__ __forceinline__ uint32_t feistel_permute(uint32_t i, uint32_t n,
+                                                            uint32_t hb, uint32_t key) {
+  const uint32_t mask = (1u << hb) - 1u;
+  do {
+    uint32_t L = i >> hb, R = i & mask;
+#pragma unroll
+    for (uint32_t r = 0; r < 4; ++r) {
+      uint32_t t = L ^ (mix32(R ^ key ^ (r * 0x9E3779B9u)) & mask);
+      L = R;
+      R = t;
+    }
+    i = (L << hb) | R;
+  } while (i >= n);
+  return i;
+}
+
+// Wave-level sum across all 64 lanes.
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+  return v;
+}
+
+}  // namespace dtf

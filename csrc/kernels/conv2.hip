@@ -1,0 +1,401 @@
+// 5x5 SAME stride-1 convolution over 14x14 feature maps as an implicit GEMM on
+// the CDNA4 bf16 matrix cores (v_mfma_f32_16x16x32_bf16), NHWC activations.
+//
+// Replaces the TF ops the reference graph instantiates for its second conv
+// block (reference .idea/MNISTDist.py:52-62,76-78): Conv2D + BiasAdd + Relu +
+// MaxPool forward, and Conv2DBackpropInput / Conv2DBackpropFilter + ReluGrad +
+// MaxPoolGrad + BiasAddGrad backward.
+//
+// Forward / dgrad share one kernel (conv5x5_igemm):
+//   M = positions of IMGS images, N = NC output channels, K = 25 taps x KC.
+//   The (18x18 halo-padded) input tile of each image lives in LDS; the A
+//   fragment of tap (ky,kx) is the same LDS image read at a shifted address,
+//   so no im2col is ever materialised.  The 16 rows of an MFMA tile are
+//   ordered m = 4*window + q (q = 2*dy+dx inside a 2x2 pooling window), which
+//   puts every pooling window in the 4 accumulator registers of ONE lane:
+//   bias + ReLU + 2x2 max-pool (+argmax) is a pure in-register epilogue.
+//   MODE_DGRAD stages the tile through the max-pool/ReLU gradient instead
+//   (scatter of the pooled gradient to the saved argmax position) and reads
+//   the taps flipped.
+//
+// wgrad (conv5x5_wgrad): dW[tap][ci][co] = sum_pos X[pos+tap][ci] * dY[pos][co]
+//   M = 32 input channels, N = 64 output channels, K = positions.  The X tile
+//   is [pos][ci] in LDS (K-slow), so A fragments come from the gfx950
+//   transposing LDS read (ds_read_b64_tr_b16); the dY fragment is built in
+//   registers straight from the pooled gradient + argmax (never expanded in
+//   memory).  Split-K over images across workgroups; partial slabs are summed
+//   by reduce_partials (optim.hip).
+#include "common.hpp"
+
+namespace dtf {
+
+constexpr int kTileW = 18;          // 14 + 2*2 halo
+constexpr int kTilePos = 328;       // 18*18 = 324 (+4 slack for the dummy window's reads)
+
+enum { MODE_FWD = 0, MODE_DGRAD = 1 };
+
+// ----------------------------------------------------------------------------
+// Forward / dgrad
+//   in   MODE_FWD  : x    [B,14,14,KC] bf16
+//        MODE_DGRAD: gpool[B,7,7,KC] bf16 (gradient wrt the pooled output),
+//                    arg  [B,7,7,KC] u8, pooled [B,7,7,KC] bf16 (fwd output)
+//   wk   [25][NC][KC] bf16  (K contiguous; fwd: transposed shadow of HWIO,
+//                            dgrad: the HWIO tensor itself, taps read flipped)
+//   out  MODE_FWD  : pooled [B,7,7,NC] bf16 + argmax [B,7,7,NC] u8
+//        MODE_DGRAD: dx [B,14,14,NC] bf16
+// ----------------------------------------------------------------------------
+template <int KC, int NC, int IMGS, int NW, int MODE>
+__global__ __launch_bounds__(IMGS * 2 * NW * 64) void conv5x5_igemm(
+    const bf16* __restrict__ in, const uint8_t* __restrict__ in_arg,
+    const bf16* __restrict__ in_pooled, const bf16* __restrict__ wk,
+    const float* __restrict__ bias, bf16* __restrict__ out, uint8_t* __restrict__ out_arg,
+    int B) {
+  constexpr int NTHREADS = IMGS * 2 * NW * 64;
+  constexpr int NT = NC / (16 * NW);   // n-tiles per wave
+  constexpr int KSTEPS = KC / 32;      // k-steps per tap
+  constexpr int CH8 = KC / 8;          // 16-byte chunks per position
+  static_assert(NC % (16 * NW) == 0, "NC must split evenly over NW waves");
+  static_assert(KC % 32 == 0, "KC must be a multiple of 32");
+
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  bf16* tile = reinterpret_cast<bf16*>(smem);  // [IMGS][kTilePos][KC]
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = tid >> 6;
+  const int w_img = wave / (2 * NW);
+  const int w_h = (wave / NW) & 1;
+  const int w_n = wave % NW;
+  const int img0 = blockIdx.x * IMGS;
+
+  // ---- zero the whole tile (halo + slack), then fill the interior ----
+  {
+    u32x4 z = {0u, 0u, 0u, 0u};
+    u32x4* t4 = reinterpret_cast<u32x4*>(smem);
+    constexpr int N16 = IMGS * kTilePos * KC * 2 / 16;
+    for (int i = tid; i < N16; i += NTHREADS) t4[i] = z;
+  }
+  __syncthreads();
+  if (MODE == MODE_FWD) {
+    constexpr int NCHUNK = IMGS * 196 * CH8;
+    for (int c = tid; c < NCHUNK; c += NTHREADS) {
+      int ch = c % CH8;
+      int pos = (c / CH8) % 196;
+      int im = c / (CH8 * 196);
+      int b = img0 + im;
+      if (b < B) {
+        u32x4 v = *reinterpret_cast<const u32x4*>(in + ((size_t)b * 196 + pos) * KC + ch * 8);
+        int y = pos / 14, x = pos % 14;
+        int tp = (y + 2) * kTileW + (x + 2);
+        *reinterpret_cast<u32x4*>(tile + ((size_t)im * kTilePos + tp) * KC + ch * 8) = v;
+      }
+    }
+  } else {
+    // max-pool / ReLU gradient: route g to the saved argmax position.
+    constexpr int NCHUNK = IMGS * 49 * CH8;
+    for (int c = tid; c < NCHUNK; c += NTHREADS) {
+      int ch = c % CH8;
+      int pp = (c / CH8) % 49;
+      int im = c / (CH8 * 49);
+      int b = img0 + im;
+      if (b < B) {
+        size_t off = ((size_t)b * 49 + pp) * KC + ch * 8;
+        bf16x8 g = *reinterpret_cast<const bf16x8*>(in + off);
+        bf16x8 p = *reinterpret_cast<const bf16x8*>(in_pooled + off);
+        u32x2 a2 = *reinterpret_cast<const u32x2*>(in_arg + off);
+        int py = pp / 7, px = pp % 7;
+        bf16x8 o[4];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          unsigned a = ((e < 4 ? a2[0] : a2[1]) >> ((e & 3) * 8)) & 0xffu;
+          bool live = (float)p[e] > 0.f;
+#pragma unroll
+          for (int q = 0; q < 4; ++q) o[q][e] = (live && a == (unsigned)q) ? g[e] : (bf16)0.f;
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          int tp = (2 * py + (q >> 1) + 2) * kTileW + (2 * px + (q & 1) + 2);
+          *reinterpret_cast<bf16x8*>(tile + ((size_t)im * kTilePos + tp) * KC + ch * 8) = o[q];
+        }
+      }
+    }
+  }
+  __syncthreads();
+
+  // ---- main loop ----
+  // lane -> (row m of the 16-row tile, k-group g)
+  const int m = lane & 15, g = lane >> 4;
+  const int wl = m >> 2, q = m & 3;
+  // position of this lane's A row for m-tile 0 (row pair 0), tap (0,0), in tile coordinates
+  const int a_pos = (q >> 1) * kTileW + 2 * (4 * w_h + wl) + (q & 1);
+  const bf16* a_base = tile + ((size_t)w_img * kTilePos + a_pos) * KC + g * 8;
+  // B fragment: column n = lane&15 of n-tile nt, k = 8g..8g+7
+  const bf16* b_base = wk + ((size_t)(w_n * NT * 16 + m)) * KC + g * 8;
+
+  f32x4 acc[7][NT];
+#pragma unroll
+  for (int i = 0; i < 7; ++i)
+#pragma unroll
+    for (int j = 0; j < NT; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  bf16x8 bcur[NT], bnxt[NT];
+  auto load_b = [&](bf16x8 (&dst)[NT], int step) {
+    int tap = step / KSTEPS, ks = step % KSTEPS;
+    int wtap = (MODE == MODE_DGRAD) ? (24 - tap) : tap;
+#pragma unroll
+    for (int j = 0; j < NT; ++j)
+      dst[j] = *reinterpret_cast<const bf16x8*>(b_base + ((size_t)wtap * NC + j * 16) * KC + ks * 32);
+  };
+  load_b(bcur, 0);
+  constexpr int NSTEPS = 25 * KSTEPS;
+#pragma unroll 1
+  for (int step = 0; step < NSTEPS; ++step) {
+    if (step + 1 < NSTEPS) load_b(bnxt, step + 1);
+    const int tap = step / KSTEPS, ks = step % KSTEPS;
+    const int ky = tap / 5, kx = tap % 5;
+    const bf16* ap = a_base + (ky * kTileW + kx) * KC + ks * 32;
+    bf16x8 a[7];
+#pragma unroll
+    for (int i = 0; i < 7; ++i)
+      a[i] = *reinterpret_cast<const bf16x8*>(ap + i * (2 * kTileW * KC));
+#pragma unroll
+    for (int i = 0; i < 7; ++i)
+#pragma unroll
+      for (int j = 0; j < NT; ++j) acc[i][j] = mfma16(a[i], bcur[j], acc[i][j]);
+#pragma unroll
+    for (int j = 0; j < NT; ++j) bcur[j] = bnxt[j];
+  }
+
+  // ---- epilogue ----
+  const int b = img0 + w_img;
+  if (b >= B) return;
+  // C/D map: lane holds rows 4*(lane>>4)+r -> window (lane>>4), q = r; col = lane&15
+  const int ewin = 4 * w_h + g;  // window index along x (0..7; 7 is the dummy window)
+  if (ewin >= 7) return;
+  if (MODE == MODE_FWD) {
+#pragma unroll
+    for (int j = 0; j < NT; ++j) {
+      const int n = w_n * NT * 16 + j * 16 + m;
+      const float bv = bias[n];
+#pragma unroll
+      for (int i = 0; i < 7; ++i) {
+        f32x4 v = acc[i][j];
+        float best = v[0];
+        int bi = 0;
+        if (v[1] > best) { best = v[1]; bi = 1; }
+        if (v[2] > best) { best = v[2]; bi = 2; }
+        if (v[3] > best) { best = v[3]; bi = 3; }
+        float o = fmaxf(best + bv, 0.f);
+        size_t off = (((size_t)b * 7 + i) * 7 + ewin) * NC + n;
+        out[off] = (bf16)o;
+        out_arg[off] = (uint8_t)bi;
+      }
+    }
+  } else {
+#pragma unroll
+    for (int j = 0; j < NT; ++j) {
+      const int n = w_n * NT * 16 + j * 16 + m;
+#pragma unroll
+      for (int i = 0; i < 7; ++i) {
+        f32x4 v = acc[i][j];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          int y = 2 * i + (r >> 1), x = 2 * ewin + (r & 1);
+          out[(((size_t)b * 14 + y) * 14 + x) * NC + n] = (bf16)v[r];
+        }
+      }
+    }
+  }
+}
+
+// ----------------------------------------------------------------------------
+// wgrad.  grid = (G image chunks, 5 tap rows ky, (C_IN/32)*(C_OUT/64) tiles)
+//   x      [B,14,14,C_IN] bf16   layer input
+//   gpool  [B,7,7,C_OUT]  bf16   gradient wrt pooled output
+//   arg    [B,7,7,C_OUT]  u8     saved argmax
+//   pooled [B,7,7,C_OUT]  bf16   forward pooled output (ReLU mask = pooled > 0)
+//   part   [G][25*C_IN*C_OUT + C_OUT] fp32 partial slabs (HWIO order, then bias)
+// Each block: 4 waves = (mi in {0,1}: 16 input channels) x (nh in {0,1}: 32
+// output channels); every wave walks all images of its chunk, 7 row pairs each.
+// K (=32 positions of a row pair) is ordered for the transposing LDS read:
+//   element j of lane group g  <->  dy = g>>1, x = 4*(g&1) + (j&3) + 8*(j>>2)
+// ----------------------------------------------------------------------------
+template <int C_IN, int C_OUT>
+__global__ __launch_bounds__(256) void conv5x5_wgrad(
+    const bf16* __restrict__ x, const bf16* __restrict__ gpool,
+    const uint8_t* __restrict__ arg, const bf16* __restrict__ pooled,
+    float* __restrict__ part, int B, int imgs_per_block) {
+  constexpr int CI_T = C_IN / 32, CO_T = C_OUT / 64;
+  __shared__ __attribute__((aligned(16))) bf16 tile[kTilePos * 32];  // [pos][32 ci], halves swizzled
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int mi = wave & 1, nh = wave >> 1;
+  const int ky = blockIdx.y;
+  const int ci_t = blockIdx.z % CI_T, co_t = blockIdx.z / CI_T;
+  const int g = lane >> 4, i16 = lane & 15;
+  const int qr = i16 >> 2, pc = i16 & 3;  // tr-read: row in 4-row block, 4-channel column chunk
+
+  const int b_begin = blockIdx.x * imgs_per_block;
+  const int b_end = min(B, b_begin + imgs_per_block);
+
+  f32x4 acc[5][2];
+#pragma unroll
+  for (int t = 0; t < 5; ++t)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) acc[t][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  float bsum[2] = {0.f, 0.f};
+
+  // zero once: halo and slack stay zero, the interior is overwritten per image
+  for (int i = tid; i < kTilePos * 32 * 2 / 16; i += 256)
+    reinterpret_cast<u32x4*>(tile)[i] = (u32x4){0u, 0u, 0u, 0u};
+
+  // tr-read lane address (in elements) for row pair 0, kx = 0, first read
+  const int tr_pos = (ky + (g >> 1)) * kTileW + 4 * (g & 1) + qr;
+  const int co_base = co_t * 64 + nh * 32;
+
+  for (int b = b_begin; b < b_end; ++b) {
+    __syncthreads();  // previous image fully consumed (and the zero fill done)
+    for (int c = tid; c < 196 * 4; c += 256) {
+      int ch = c & 3, pos = c >> 2;
+      u32x4 v = *reinterpret_cast<const u32x4*>(x + ((size_t)b * 196 + pos) * C_IN + ci_t * 32 + ch * 8);
+      int y = pos / 14, xx = pos % 14;
+      int tp = (y + 2) * kTileW + (xx + 2);
+      int chs = ch ^ (((tp >> 2) & 1) << 1);  // swap 32-byte halves on odd 4-position groups
+      *reinterpret_cast<u32x4*>(tile + tp * 32 + chs * 8) = v;
+    }
+    __syncthreads();
+#pragma unroll 1
+    for (int r = 0; r < 7; ++r) {
+      // ---- dY fragments (2 n-tiles) built from the pooled gradient ----
+      bf16x8 bfrag[2];
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        const int n = co_base + j * 16 + i16;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          // elements 2e, 2e+1 (same window, dx = 0,1)
+          const int w = 2 * (g & 1) + (e & 1) + 4 * (e >> 1);
+          float gv = 0.f;
+          int a = -1;
+          if (w < 7) {
+            size_t off = (((size_t)b * 7 + r) * 7 + w) * C_OUT + n;
+            float pv = (float)pooled[off];
+            if (pv > 0.f) { gv = (float)gpool[off]; a = arg[off]; }
+          }
+          const int q0 = (g >> 1) * 2;
+          float v0 = (a == q0) ? gv : 0.f, v1 = (a == q0 + 1) ? gv : 0.f;
+          bfrag[j][2 * e] = (bf16)v0;
+          bfrag[j][2 * e + 1] = (bf16)v1;
+          bsum[j] += v0 + v1;
+        }
+      }
+      // ---- 5 taps of this tap row ----
+#pragma unroll
+      for (int kx = 0; kx < 5; ++kx) {
+        const int p0 = tr_pos + 2 * r * kTileW + kx;
+        const int p1 = p0 + 8;
+        const int h0 = mi ^ ((p0 >> 2) & 1), h1 = mi ^ ((p1 >> 2) & 1);
+        s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+            (__attribute__((address_space(3))) s16x4*)(tile + p0 * 32 + h0 * 16 + pc * 4));
+        s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+            (__attribute__((address_space(3))) s16x4*)(tile + p1 * 32 + h1 * 16 + pc * 4));
+        typedef __attribute__((ext_vector_type(8))) short s16x8;
+        s16x8 av = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+        bf16x8 afrag = __builtin_bit_cast(bf16x8, av);
+        acc[kx][0] = mfma16(afrag, bfrag[0], acc[kx][0]);
+        acc[kx][1] = mfma16(afrag, bfrag[1], acc[kx][1]);
+      }
+    }
+  }
+
+  // ---- write the partial slab: rows ci = 4g + r, cols co ----
+  float* slab = part + (size_t)blockIdx.x * (25 * C_IN * C_OUT + C_OUT);
+#pragma unroll
+  for (int kx = 0; kx < 5; ++kx)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        int ci = ci_t * 32 + mi * 16 + 4 * g + r;
+        int co = co_base + j * 16 + i16;
+        slab[((size_t)(ky * 5 + kx) * C_IN + ci) * C_OUT + co] = acc[kx][j][r];
+      }
+  if (ky == 0 && ci_t == 0 && mi == 0) {
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      float s = bsum[j];
+      s += __shfl_xor(s, 16, 64);
+      s += __shfl_xor(s, 32, 64);
+      if (g == 0) slab[25 * C_IN * C_OUT + co_base + j * 16 + i16] = s;
+    }
+  }
+}
+
+}  // namespace dtf
+
+// ---------------------------------------------------------------------------
+// C ABI launchers
+// ---------------------------------------------------------------------------
+using namespace dtf;
+
+#define DTF_LAUNCH_CHECK() (int)hipGetLastError()
+
+template <int KC, int NC, int IMGS, int NW, int MODE>
+static int launch_igemm(const void* in, const void* in_arg, const void* in_pooled, const void* wk,
+                        const void* bias, void* out, void* out_arg, int B, hipStream_t s) {
+  constexpr int threads = IMGS * 2 * NW * 64;
+  constexpr size_t lds = (size_t)IMGS * kTilePos * KC * 2;
+  auto kern = conv5x5_igemm<KC, NC, IMGS, NW, MODE>;
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    attr_set = true;
+  }
+  int grid = (B + IMGS - 1) / IMGS;
+  hipLaunchKernelGGL(kern, dim3(grid), dim3(threads), lds, s, (const bf16*)in, (const uint8_t*)in_arg,
+                     (const bf16*)in_pooled, (const bf16*)wk, (const float*)bias, (bf16*)out,
+                     (uint8_t*)out_arg, B);
+  return DTF_LAUNCH_CHECK();
+}
+
+extern "C" {
+
+// Forward: x[B,14,14,cin] -> pooled[B,7,7,cout], arg[B,7,7,cout]; wT [25][cout][cin]
+int dtf_conv2_fwd(const void* x, const void* wT, const void* bias, void* pooled, void* arg, int B,
+                  int cin, int cout, hipStream_t s) {
+  if (cin == 32 && cout == 64)
+    return launch_igemm<32, 64, 2, 1, MODE_FWD>(x, nullptr, nullptr, wT, bias, pooled, arg, B, s);
+  if (cin == 128 && cout == 256)
+    return launch_igemm<128, 256, 1, 4, MODE_FWD>(x, nullptr, nullptr, wT, bias, pooled, arg, B, s);
+  return -1;
+}
+
+// dgrad: gpool[B,7,7,cout] (+arg, pooled) -> dx[B,14,14,cin]; w is HWIO [25][cin][cout]
+int dtf_conv2_dgrad(const void* gpool, const void* arg, const void* pooled, const void* w, void* dx,
+                    int B, int cin, int cout, hipStream_t s) {
+  if (cin == 32 && cout == 64)
+    return launch_igemm<64, 32, 2, 1, MODE_DGRAD>(gpool, arg, pooled, w, nullptr, dx, nullptr, B, s);
+  if (cin == 128 && cout == 256)
+    return launch_igemm<256, 128, 1, 2, MODE_DGRAD>(gpool, arg, pooled, w, nullptr, dx, nullptr, B, s);
+  return -1;
+}
+
+// wgrad partial slabs: part [G][25*cin*cout + cout]
+int dtf_conv2_wgrad(const void* x, const void* gpool, const void* arg, const void* pooled, void* part,
+                    int B, int cin, int cout, int G, hipStream_t s) {
+  if (G <= 0) return -2;
+  int ipb = (B + G - 1) / G;
+  if (cin == 32 && cout == 64) {
+    hipLaunchKernelGGL((conv5x5_wgrad<32, 64>), dim3(G, 5, 1), dim3(256), 0, s, (const bf16*)x,
+                       (const bf16*)gpool, (const uint8_t*)arg, (const bf16*)pooled, (float*)part, B, ipb);
+    return DTF_LAUNCH_CHECK();
+  }
+  if (cin == 128 && cout == 256) {
+    hipLaunchKernelGGL((conv5x5_wgrad<128, 256>), dim3(G, 5, 16), dim3(256), 0, s, (const bf16*)x,
+                       (const bf16*)gpool, (const uint8_t*)arg, (const bf16*)pooled, (float*)part, B, ipb);
+    return DTF_LAUNCH_CHECK();
+  }
+  return -1;
+}
+
+}  // extern "C"

@@ -1,0 +1,308 @@
+// bf16 MFMA GEMMs for the dense layers (reference .idea/MNISTDist.py:82-89:
+// matmul(fc1, wd1)+bd1 -> relu -> dropout -> matmul(., out)+out_b, and the
+// MatMul gradient ops autodiff generates from them).
+//
+//   gemm_nt : C[M,N] = A[M,K] . B[N,K]^T      (both operands K-contiguous)
+//             forward  h1 = relu(flat . wd1 + bd1) [+ dropout]   (B = wd1^T shadow)
+//             dgrad    dflat = dh1 . wd1^T                       (B = wd1 itself)
+//   gemm_tn : C[M,N] = A[K,M]^T . B[K,N]      (both operands K-slow), fp32 out
+//             wgrad    dwd1 = flat^T . dh1   -- K is the batch
+//
+// Tiling: 256 threads = 4 waves as 2x2, wave tile (BM/2)x(BN/2) of 16x16x32
+// MFMAs, BK = 64, one LDS buffer + register prefetch of the next K tile.
+//   NT: LDS rows are 128 B (64 bf16 of K); the 16-byte chunk index is XORed
+//       with (row & 7) so that ds_read_b128 fragment reads are conflict-free.
+//   TN: LDS keeps the global [K][M] orientation (coalesced staging) with a
+//       +32 B row pad; fragments come from ds_read_b64_tr_b16, and element j of
+//       lane group g is k = 16*(j>>2) + 4*g + (j&3) for BOTH operands (any
+//       bijection of k is a valid GEMM), which makes the transposed reads
+//       bank-conflict free.
+#include "common.hpp"
+
+namespace dtf {
+
+enum { EPI_STORE = 0, EPI_BIAS_RELU_DROPOUT = 1 };
+
+struct DropoutArgs {
+  float keep_prob;        // 1.0 -> disabled
+  uint64_t seed;
+  const int64_t* state;   // device step state; state[2] = dropout offset (graph-replay safe)
+};
+
+__device__ __forceinline__ float dropout_scale(const DropoutArgs& d, uint64_t offset, uint64_t elem) {
+  uint32_t r[4];
+  Philox::run(d.seed, elem, offset, r);
+  return u32_to_unit_float(r[0]) < d.keep_prob ? 1.0f / d.keep_prob : 0.f;
+}
+
+template <int BM, int BN, int EPI>
+__global__ __launch_bounds__(256) void gemm_nt_bf16(const bf16* __restrict__ A, const bf16* __restrict__ Bm,
+                                                    bf16* __restrict__ C, const float* __restrict__ bias,
+                                                    int M, int N, int K, int lda, int ldb, int ldc,
+                                                    DropoutArgs drop) {
+  constexpr int BK = 64;
+  constexpr int WM = BM / 2, WN = BN / 2;
+  constexpr int MT = WM / 16, NTL = WN / 16;
+  constexpr int A_CH = BM * 8 / 256, B_CH = BN * 8 / 256;  // 16-byte chunks per thread
+  __shared__ __attribute__((aligned(16))) bf16 sA[BM * BK];
+  __shared__ __attribute__((aligned(16))) bf16 sB[BN * BK];
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
+  const int i16 = lane & 15, g = lane >> 4;
+
+  f32x4 acc[MT][NTL];
+#pragma unroll
+  for (int i = 0; i < MT; ++i)
+#pragma unroll
+    for (int j = 0; j < NTL; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  u32x4 ra[A_CH], rb[B_CH];
+  auto gload = [&](int k0) {
+#pragma unroll
+    for (int i = 0; i < A_CH; ++i) {
+      int c = tid + i * 256, row = c >> 3, slot = c & 7;
+      int gm = m0 + row, gk = k0 + slot * 8;
+      ra[i] = (gm < M && gk < K) ? *reinterpret_cast<const u32x4*>(A + (size_t)gm * lda + gk)
+                                 : (u32x4){0u, 0u, 0u, 0u};
+    }
+#pragma unroll
+    for (int i = 0; i < B_CH; ++i) {
+      int c = tid + i * 256, row = c >> 3, slot = c & 7;
+      int gn = n0 + row, gk = k0 + slot * 8;
+      rb[i] = (gn < N && gk < K) ? *reinterpret_cast<const u32x4*>(Bm + (size_t)gn * ldb + gk)
+                                 : (u32x4){0u, 0u, 0u, 0u};
+    }
+  };
+  auto swrite = [&]() {
+#pragma unroll
+    for (int i = 0; i < A_CH; ++i) {
+      int c = tid + i * 256, row = c >> 3, slot = c & 7;
+      *reinterpret_cast<u32x4*>(sA + row * BK + ((slot ^ (row & 7)) << 3)) = ra[i];
+    }
+#pragma unroll
+    for (int i = 0; i < B_CH; ++i) {
+      int c = tid + i * 256, row = c >> 3, slot = c & 7;
+      *reinterpret_cast<u32x4*>(sB + row * BK + ((slot ^ (row & 7)) << 3)) = rb[i];
+    }
+  };
+
+  gload(0);
+  for (int k0 = 0; k0 < K; k0 += BK) {
+    swrite();
+    __syncthreads();
+    if (k0 + BK < K) gload(k0 + BK);
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk) {
+      bf16x8 af[MT], bfv[NTL];
+#pragma unroll
+      for (int i = 0; i < MT; ++i) {
+        int row = wm * WM + i * 16 + i16;
+        af[i] = *reinterpret_cast<const bf16x8*>(sA + row * BK + (((kk * 4 + g) ^ (row & 7)) << 3));
+      }
+#pragma unroll
+      for (int j = 0; j < NTL; ++j) {
+        int row = wn * WN + j * 16 + i16;
+        bfv[j] = *reinterpret_cast<const bf16x8*>(sB + row * BK + (((kk * 4 + g) ^ (row & 7)) << 3));
+      }
+#pragma unroll
+      for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int j = 0; j < NTL; ++j) acc[i][j] = mfma16(af[i], bfv[j], acc[i][j]);
+    }
+    __syncthreads();
+  }
+
+  uint64_t drop_off = 0;
+  const bool do_drop = (EPI == EPI_BIAS_RELU_DROPOUT) && drop.keep_prob < 1.0f;
+  if (do_drop) drop_off = drop.state ? (uint64_t)drop.state[2] : 0;
+#pragma unroll
+  for (int j = 0; j < NTL; ++j) {
+    const int n = n0 + wn * WN + j * 16 + i16;
+    if (n >= N) continue;
+    float bv = 0.f;
+    if (EPI == EPI_BIAS_RELU_DROPOUT) bv = bias[n];
+#pragma unroll
+    for (int i = 0; i < MT; ++i)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int mrow = m0 + wm * WM + i * 16 + 4 * g + r;
+        if (mrow >= M) continue;
+        float v = acc[i][j][r];
+        if (EPI == EPI_BIAS_RELU_DROPOUT) {
+          v = fmaxf(v + bv, 0.f);
+          if (do_drop) v *= dropout_scale(drop, drop_off, (uint64_t)mrow * (uint64_t)N + n);
+        }
+        C[(size_t)mrow * ldc + n] = (bf16)v;
+      }
+  }
+}
+
+// C[M,N] (fp32) = sum_k A[k][m] * B[k][n];  A: [K][lda], B: [K][ldb]
+template <int BM, int BN>
+__global__ __launch_bounds__(256) void gemm_tn_bf16(const bf16* __restrict__ A, const bf16* __restrict__ Bm,
+                                                    float* __restrict__ C, int M, int N, int K, int lda,
+                                                    int ldb, int ldc) {
+  constexpr int BK = 64;
+  constexpr int PA = BM + 16, PB = BN + 16;  // row pitch in elements (+32 B)
+  constexpr int WM = BM / 2, WN = BN / 2;
+  constexpr int MT = WM / 16, NTL = WN / 16;
+  constexpr int A_CH = BK * (BM / 8) / 256, B_CH = BK * (BN / 8) / 256;
+  __shared__ __attribute__((aligned(16))) bf16 sA[BK * PA];
+  __shared__ __attribute__((aligned(16))) bf16 sB[BK * PB];
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
+  const int i16 = lane & 15, g = lane >> 4;
+  const int qr = i16 >> 2, pc = i16 & 3;
+
+  f32x4 acc[MT][NTL];
+#pragma unroll
+  for (int i = 0; i < MT; ++i)
+#pragma unroll
+    for (int j = 0; j < NTL; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  u32x4 ra[A_CH], rb[B_CH];
+  auto gload = [&](int k0) {
+#pragma unroll
+    for (int i = 0; i < A_CH; ++i) {
+      int c = tid + i * 256, row = c / (BM / 8), slot = c % (BM / 8);
+      int gk = k0 + row, gm = m0 + slot * 8;
+      ra[i] = (gk < K && gm < M) ? *reinterpret_cast<const u32x4*>(A + (size_t)gk * lda + gm)
+                                 : (u32x4){0u, 0u, 0u, 0u};
+    }
+#pragma unroll
+    for (int i = 0; i < B_CH; ++i) {
+      int c = tid + i * 256, row = c / (BN / 8), slot = c % (BN / 8);
+      int gk = k0 + row, gn = n0 + slot * 8;
+      rb[i] = (gk < K && gn < N) ? *reinterpret_cast<const u32x4*>(Bm + (size_t)gk * ldb + gn)
+                                 : (u32x4){0u, 0u, 0u, 0u};
+    }
+  };
+  auto swrite = [&]() {
+#pragma unroll
+    for (int i = 0; i < A_CH; ++i) {
+      int c = tid + i * 256, row = c / (BM / 8), slot = c % (BM / 8);
+      *reinterpret_cast<u32x4*>(sA + row * PA + slot * 8) = ra[i];
+    }
+#pragma unroll
+    for (int i = 0; i < B_CH; ++i) {
+      int c = tid + i * 256, row = c / (BN / 8), slot = c % (BN / 8);
+      *reinterpret_cast<u32x4*>(sB + row * PB + slot * 8) = rb[i];
+    }
+  };
+  typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
+  typedef __attribute__((ext_vector_type(8))) short s16x8;
+  auto tr_frag = [&](const bf16* base, int pitch, int kk, int col0) -> bf16x8 {
+    // rows kk*32 + 4g + qr (+16), columns col0 + 4*pc .. +3
+    const bf16* p0 = base + (kk * 32 + 4 * g + qr) * pitch + col0 + 4 * pc;
+    s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)p0);
+    s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(p0 + 16 * pitch));
+    s16x8 v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+    return __builtin_bit_cast(bf16x8, v);
+  };
+
+  gload(0);
+  for (int k0 = 0; k0 < K; k0 += BK) {
+    swrite();
+    __syncthreads();
+    if (k0 + BK < K) gload(k0 + BK);
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk) {
+      bf16x8 af[MT], bfv[NTL];
+#pragma unroll
+      for (int i = 0; i < MT; ++i) af[i] = tr_frag(sA, PA, kk, wm * WM + i * 16);
+#pragma unroll
+      for (int j = 0; j < NTL; ++j) bfv[j] = tr_frag(sB, PB, kk, wn * WN + j * 16);
+#pragma unroll
+      for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int j = 0; j < NTL; ++j) acc[i][j] = mfma16(af[i], bfv[j], acc[i][j]);
+    }
+    __syncthreads();
+  }
+#pragma unroll
+  for (int j = 0; j < NTL; ++j) {
+    const int n = n0 + wn * WN + j * 16 + i16;
+    if (n >= N) continue;
+#pragma unroll
+    for (int i = 0; i < MT; ++i)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int mrow = m0 + wm * WM + i * 16 + 4 * g + r;
+        if (mrow < M) C[(size_t)mrow * ldc + n] = acc[i][j][r];
+      }
+  }
+}
+
+// Tiled, batched bf16 transpose: out[z][c][r] = in[z][r][c]  (weight shadows in the
+// K-contiguous layout the NT kernels want)
+__global__ __launch_bounds__(256) void transpose_bf16(const bf16* __restrict__ in, bf16* __restrict__ out,
+                                                      int R, int Cn) {
+  __shared__ bf16 t[64][66];
+  in += (size_t)blockIdx.z * R * Cn;
+  out += (size_t)blockIdx.z * R * Cn;
+  const int r0 = blockIdx.y * 64, c0 = blockIdx.x * 64;
+  const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+  for (int i = ty; i < 64; i += 4) {
+    int r = r0 + i, c = c0 + tx;
+    t[i][tx] = (r < R && c < Cn) ? in[(size_t)r * Cn + c] : (bf16)0.f;
+  }
+  __syncthreads();
+  for (int i = ty; i < 64; i += 4) {
+    int c = c0 + i, r = r0 + tx;
+    if (r < R && c < Cn) out[(size_t)c * R + r] = t[tx][i];
+  }
+}
+
+}  // namespace dtf
+
+using namespace dtf;
+
+extern "C" {
+
+// C[M,N] bf16 = A[M,K] . B[N,K]^T ; epi 0 = store, 1 = bias+relu+dropout
+int dtf_gemm_nt(const void* A, const void* B, void* C, const void* bias, int M, int N, int K, int lda,
+                int ldb, int ldc, int epi, float keep_prob, uint64_t seed, const void* state, int tile,
+                hipStream_t s) {
+  if ((K & 7) || (lda & 7) || (ldb & 7)) return -3;
+  DropoutArgs d{keep_prob, seed, (const int64_t*)state};
+  if (tile == 0) tile = ((long)((M + 127) / 128) * ((N + 127) / 128) >= 192) ? 128 : 64;
+#define NT_CASE(BMN, E)                                                                               \
+  hipLaunchKernelGGL((gemm_nt_bf16<BMN, BMN, E>), dim3((N + BMN - 1) / BMN, (M + BMN - 1) / BMN),     \
+                     dim3(256), 0, s, (const bf16*)A, (const bf16*)B, (bf16*)C, (const float*)bias, M, \
+                     N, K, lda, ldb, ldc, d)
+  if (tile == 128 && epi == 0) NT_CASE(128, EPI_STORE);
+  else if (tile == 128 && epi == 1) NT_CASE(128, EPI_BIAS_RELU_DROPOUT);
+  else if (tile == 64 && epi == 0) NT_CASE(64, EPI_STORE);
+  else if (tile == 64 && epi == 1) NT_CASE(64, EPI_BIAS_RELU_DROPOUT);
+  else return -1;
+#undef NT_CASE
+  return (int)hipGetLastError();
+}
+
+// C[M,N] fp32 = A[K,M]^T . B[K,N]
+int dtf_gemm_tn(const void* A, const void* B, void* C, int M, int N, int K, int lda, int ldb, int ldc,
+                int tile, hipStream_t s) {
+  if ((lda & 7) || (ldb & 7) || (M & 7) || (N & 7)) return -3;
+  if (tile == 0) tile = ((long)((M + 127) / 128) * ((N + 127) / 128) >= 192) ? 128 : 64;
+  if (tile == 128)
+    hipLaunchKernelGGL((gemm_tn_bf16<128, 128>), dim3((N + 127) / 128, (M + 127) / 128), dim3(256), 0, s,
+                       (const bf16*)A, (const bf16*)B, (float*)C, M, N, K, lda, ldb, ldc);
+  else if (tile == 64)
+    hipLaunchKernelGGL((gemm_tn_bf16<64, 64>), dim3((N + 63) / 64, (M + 63) / 64), dim3(256), 0, s,
+                       (const bf16*)A, (const bf16*)B, (float*)C, M, N, K, lda, ldb, ldc);
+  else
+    return -1;
+  return (int)hipGetLastError();
+}
+
+int dtf_transpose_bf16(const void* in, void* out, int batch, int R, int C, hipStream_t s) {
+  hipLaunchKernelGGL(transpose_bf16, dim3((C + 63) / 64, (R + 63) / 64, batch), dim3(256), 0, s,
+                     (const bf16*)in, (bf16*)out, R, C);
+  return (int)hipGetLastError();
+}
+
+}  // extern "C"

@@ -1,0 +1,182 @@
+// Parameter update over the flat parameter arena (reference
+// .idea/MNISTDist.py:149: GradientDescentOptimizer(lr).minimize(cost,
+// global_step) -> ApplyGradientDescent x8 + AssignAdd(global_step) on the PS).
+//
+// All trainable tensors live in ONE fp32 arena (and their gradients in a
+// mirror arena), so the whole model is updated by a single launch with 16-byte
+// loads/stores; the same pass emits the bf16 compute copy of every weight and
+// bumps the device-resident step state (global_step, sample cursor, dropout
+// offset) so a captured HIP graph can be replayed without host involvement.
+// Hyper-parameters are read from device memory for the same reason.
+//
+// reduce_segments sums the deterministic split-K slabs the wgrad kernels write
+// (no float atomics anywhere in backward -> bitwise reproducible gradients).
+#include "common.hpp"
+
+namespace dtf {
+
+// hyper[0]=lr [1]=beta1 [2]=beta2 [3]=eps [4]=grad_scale (e.g. 1/world) [5]=weight_decay
+// state[0]=sample cursor  [1]=global_step  [2]=dropout offset  [3]=adam t
+struct StepAdvance {
+  int64_t* state;
+  int64_t cursor_inc;
+  int64_t step_inc;
+};
+
+__device__ __forceinline__ void advance_state(const StepAdvance& a) {
+  if (a.state && blockIdx.x == 0 && threadIdx.x == 0) {
+    a.state[0] += a.cursor_inc;
+    a.state[1] += a.step_inc;
+    a.state[2] += 1;
+    a.state[3] += 1;
+  }
+}
+
+__device__ __forceinline__ void store_bf16x4(bf16* p, float a, float b, float c, float d) {
+  bf16x4 v = {(bf16)a, (bf16)b, (bf16)c, (bf16)d};
+  *reinterpret_cast<bf16x4*>(p) = v;
+}
+
+// n must be a multiple of 4 (arena tensors are padded to 4 floats)
+__global__ __launch_bounds__(256) void sgd_update(float* __restrict__ w, const float* __restrict__ g,
+                                                  bf16* __restrict__ shadow, const float* __restrict__ hyper,
+                                                  long n4, StepAdvance adv) {
+  const float lr = hyper[0] * hyper[4];
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long)gridDim.x * blockDim.x) {
+    f32x4 wv = reinterpret_cast<const f32x4*>(w)[i];
+    f32x4 gv = reinterpret_cast<const f32x4*>(g)[i];
+    wv[0] = fmaf(-lr, gv[0], wv[0]);
+    wv[1] = fmaf(-lr, gv[1], wv[1]);
+    wv[2] = fmaf(-lr, gv[2], wv[2]);
+    wv[3] = fmaf(-lr, gv[3], wv[3]);
+    reinterpret_cast<f32x4*>(w)[i] = wv;
+    if (shadow) store_bf16x4(shadow + 4 * i, wv[0], wv[1], wv[2], wv[3]);
+  }
+  advance_state(adv);
+}
+
+// TF AdamOptimizer semantics: lr_t = lr * sqrt(1-b2^t)/(1-b1^t); w -= lr_t * m / (sqrt(v) + eps)
+__global__ __launch_bounds__(256) void adam_update(float* __restrict__ w, const float* __restrict__ g,
+                                                   float* __restrict__ m, float* __restrict__ v,
+                                                   bf16* __restrict__ shadow, const float* __restrict__ hyper,
+                                                   long n4, StepAdvance adv) {
+  const float lr = hyper[0], b1 = hyper[1], b2 = hyper[2], eps = hyper[3], gs = hyper[4];
+  const float t = (float)(adv.state ? adv.state[3] + 1 : 1);
+  const float lr_t = lr * sqrtf(1.f - powf(b2, t)) / (1.f - powf(b1, t));
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long)gridDim.x * blockDim.x) {
+    f32x4 wv = reinterpret_cast<const f32x4*>(w)[i];
+    f32x4 gv = reinterpret_cast<const f32x4*>(g)[i];
+    f32x4 mv = reinterpret_cast<const f32x4*>(m)[i];
+    f32x4 vv = reinterpret_cast<const f32x4*>(v)[i];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      float ge = gv[e] * gs;
+      mv[e] = fmaf(b1, mv[e], (1.f - b1) * ge);
+      vv[e] = fmaf(b2, vv[e], (1.f - b2) * ge * ge);
+      wv[e] -= lr_t * mv[e] / (sqrtf(vv[e]) + eps);
+    }
+    reinterpret_cast<f32x4*>(w)[i] = wv;
+    reinterpret_cast<f32x4*>(m)[i] = mv;
+    reinterpret_cast<f32x4*>(v)[i] = vv;
+    if (shadow) store_bf16x4(shadow + 4 * i, wv[0], wv[1], wv[2], wv[3]);
+  }
+  // state[3] is read by every block above, so it is bumped by a trailing
+  // 1-thread kernel (dtf_adam_update) rather than by whichever block ends first.
+}
+
+__global__ void advance_state_kernel(StepAdvance adv) { advance_state(adv); }
+
+__global__ __launch_bounds__(256) void cast_bf16(const float* __restrict__ w, bf16* __restrict__ shadow,
+                                                 long n4) {
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long)gridDim.x * blockDim.x) {
+    f32x4 wv = reinterpret_cast<const f32x4*>(w)[i];
+    store_bf16x4(shadow + 4 * i, wv[0], wv[1], wv[2], wv[3]);
+  }
+}
+
+struct ReduceSeg {
+  const float* part;  // [G][stride]
+  float* out;         // [n]
+  int G;
+  int n;
+  long stride;
+};
+struct ReduceSegs {
+  ReduceSeg s[4];
+  int count;
+};
+
+__global__ __launch_bounds__(256) void reduce_segments(ReduceSegs segs) {
+  long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    if (k >= segs.count) return;
+    const ReduceSeg sg = segs.s[k];
+    if (i < sg.n) {
+      float acc = 0.f;
+      for (int gI = 0; gI < sg.G; ++gI) acc += sg.part[(size_t)gI * sg.stride + i];
+      sg.out[i] = acc;
+      return;
+    }
+    i -= sg.n;
+  }
+}
+
+}  // namespace dtf
+
+using namespace dtf;
+
+extern "C" {
+
+static int grid_for(long n4) {
+  long b = (n4 + 255) / 256;
+  return (int)(b > 2048 ? 2048 : (b < 1 ? 1 : b));
+}
+
+int dtf_sgd_update(void* w, const void* g, void* shadow, const void* hyper, long n, void* state,
+                   long cursor_inc, long step_inc, hipStream_t s) {
+  if (n & 3) return -3;
+  StepAdvance adv{(int64_t*)state, cursor_inc, step_inc};
+  hipLaunchKernelGGL(sgd_update, dim3(grid_for(n / 4)), dim3(256), 0, s, (float*)w, (const float*)g,
+                     (bf16*)shadow, (const float*)hyper, n / 4, adv);
+  return (int)hipGetLastError();
+}
+
+int dtf_adam_update(void* w, const void* g, void* m, void* v, void* shadow, const void* hyper, long n,
+                    void* state, long cursor_inc, long step_inc, hipStream_t s) {
+  if (n & 3) return -3;
+  StepAdvance adv{(int64_t*)state, cursor_inc, step_inc};
+  hipLaunchKernelGGL(adam_update, dim3(grid_for(n / 4)), dim3(256), 0, s, (float*)w, (const float*)g,
+                     (float*)m, (float*)v, (bf16*)shadow, (const float*)hyper, n / 4, adv);
+  if (state) hipLaunchKernelGGL(advance_state_kernel, dim3(1), dim3(1), 0, s, adv);
+  return (int)hipGetLastError();
+}
+
+int dtf_advance_state(void* state, long cursor_inc, long step_inc, hipStream_t s) {
+  StepAdvance adv{(int64_t*)state, cursor_inc, step_inc};
+  hipLaunchKernelGGL(advance_state_kernel, dim3(1), dim3(1), 0, s, adv);
+  return (int)hipGetLastError();
+}
+
+int dtf_cast_bf16(const void* w, void* shadow, long n, hipStream_t s) {
+  if (n & 3) return -3;
+  hipLaunchKernelGGL(cast_bf16, dim3(grid_for(n / 4)), dim3(256), 0, s, (const float*)w, (bf16*)shadow, n / 4);
+  return (int)hipGetLastError();
+}
+
+// up to 4 segments: part[k] is [G[k]][stride[k]], out[k] has n[k] floats
+int dtf_reduce_segments(int count, const void** part, void** out, const int* G, const int* n,
+                        const long* stride, hipStream_t s) {
+  if (count < 1 || count > 4) return -2;
+  ReduceSegs segs;
+  long total = 0;
+  for (int k = 0; k < count; ++k) {
+    segs.s[k] = ReduceSeg{(const float*)part[k], (float*)out[k], G[k], n[k], stride[k]};
+    total += n[k];
+  }
+  segs.count = count;
+  hipLaunchKernelGGL(reduce_segments, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, segs);
+  return (int)hipGetLastError();
+}
+
+}  // extern "C"

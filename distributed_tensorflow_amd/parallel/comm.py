@@ -1,0 +1,47 @@
+"""Process-group bring-up: RCCL over xGMI on GPUs, gloo for the CPU plumbing config.
+
+Replaces the reference's ``tf.train.ClusterSpec`` + in-process gRPC
+``tf.train.Server`` (reference .idea/MNISTDist.py:94-103).  One process per
+GPU; ``torch.distributed`` backend "nccl" IS RCCL on ROCm.
+"""
+from __future__ import annotations
+
+import datetime
+import os
+from typing import Optional
+
+import torch
+import torch.distributed as dist
+
+
+def init_process_group(backend: str, rank: int, world_size: int, master_addr: Optional[str] = None,
+                       master_port: Optional[int] = None, device: Optional[torch.device] = None,
+                       timeout_s: float = 600.0):
+    """Rendezvous over a TCPStore at master_addr:master_port (env MASTER_ADDR/PORT by default)."""
+    if dist.is_initialized():
+        return
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # dmabuf IPC only on this driver
+    if master_addr is not None:
+        os.environ["MASTER_ADDR"] = master_addr
+    if master_port is not None:
+        os.environ["MASTER_PORT"] = str(master_port)
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29500")
+    kwargs = dict(backend=backend, rank=rank, world_size=world_size,
+                  timeout=datetime.timedelta(seconds=timeout_s))
+    if backend == "nccl" and device is not None:
+        kwargs["device_id"] = device
+    dist.init_process_group(**kwargs)
+
+
+def world_size() -> int:
+    return dist.get_world_size() if dist.is_initialized() else 1
+
+
+def rank() -> int:
+    return dist.get_rank() if dist.is_initialized() else 0
+
+
+def shutdown():
+    if dist.is_initialized():
+        dist.destroy_process_group()

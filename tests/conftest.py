@@ -1,0 +1,21 @@
+import os
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: test needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+@pytest.fixture(scope="session")
+def gpu_lib():
+    import torch
+    from distributed_tensorflow_amd.ops import native
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    return native.load()  # raises loudly if the in-tree .so was not built

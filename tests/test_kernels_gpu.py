@@ -1,0 +1,314 @@
+"""Numerics of every hand-written HIP kernel against a plain PyTorch fp32 reference
+of the same op (inputs pre-rounded to bf16 where the kernel consumes bf16).
+
+Run on the GPU box: python -m pytest tests -m gpu
+"""
+import ctypes
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from distributed_tensorflow_amd.data import batch_indices, synthetic_mnist
+from distributed_tensorflow_amd.ops import reference as R
+from distributed_tensorflow_amd.ops.native import check, ptr
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+
+
+def stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def bf(x):
+    return x.to(torch.bfloat16)
+
+
+def rel_err(a, b):
+    a, b = a.float(), b.float()
+    return float((a - b).norm() / (b.norm() + 1e-12))
+
+
+def conv_block_ref(x_nhwc, w_hwio, b):
+    """fp32 conv+bias+relu, then 2x2 pool with argmax (first max wins)."""
+    y = R.conv2d_same(x_nhwc.float(), w_hwio.float(), b.float())
+    return R.pool_argmax(y)
+
+
+# ------------------------------------------------------------------ data path
+def test_sample_indices_match_host(gpu_lib):
+    n, B, seed = 55000, 300, 77
+    state = torch.zeros(8, dtype=torch.int64, device=DEV)
+    idx = torch.zeros(B, dtype=torch.int32, device=DEV)
+    from distributed_tensorflow_amd.data import half_bits
+    for cursor in (0, 54900, 3 * 55000 + 17):
+        state[0] = cursor
+        check(gpu_lib.dtf_sample_indices(ptr(state), ptr(idx), B, n, half_bits(n), seed, 1, stream()), "sample")
+        want = batch_indices(cursor, B, n, seed)
+        assert np.array_equal(idx.cpu().numpy().astype(np.int64), want)
+    # one epoch is a permutation
+    state[0] = 0
+    big = torch.zeros(n, dtype=torch.int32, device=DEV)
+    check(gpu_lib.dtf_sample_indices(ptr(state), ptr(big), n, n, half_bits(n), seed, 1, stream()), "sample")
+    assert len(np.unique(big.cpu().numpy())) == n
+
+
+def test_synthetic_generator_matches_host(gpu_lib):
+    from distributed_tensorflow_amd.engine import DeviceDataset
+    ds = DeviceDataset.synthetic(500, seed=1234)
+    x, y = synthetic_mnist(500, seed=1234)
+    assert np.array_equal(ds.labels.cpu().numpy(), y)
+    assert np.array_equal(ds.images.float().cpu().numpy(), x)
+
+
+def test_init_kernels(gpu_lib):
+    n = 1 << 20
+    w = torch.empty(n, device=DEV)
+    check(gpu_lib.dtf_init_truncated_normal(ptr(w), n, 0.1, 42, 3, stream()), "init")
+    assert float(w.abs().max()) <= 0.2 + 1e-6
+    assert abs(float(w.mean())) < 1e-3
+    # std of a 2-sigma truncated normal is 0.8796 sigma
+    assert abs(float(w.std()) / 0.1 - 0.8796) < 0.01
+    check(gpu_lib.dtf_fill_f32(ptr(w), n, 0.1, stream()), "fill")
+    assert float(w.min()) == float(w.max()) == pytest.approx(0.1)
+
+
+# ---------------------------------------------------------------------- conv1
+@pytest.mark.parametrize("B,C", [(1, 32), (37, 32), (8, 128)])
+def test_conv1_fwd(gpu_lib, B, C):
+    g = torch.Generator(device="cpu").manual_seed(1)
+    N = 64
+    images = bf(torch.rand(N, 784, generator=g)).to(DEV)
+    idx = torch.randint(0, N, (B,), generator=g, dtype=torch.int32).to(DEV)
+    w = (torch.randn(5, 5, 1, C, generator=g) * 0.1).to(DEV)
+    b = (torch.randn(C, generator=g) * 0.1).to(DEV)
+    pooled = torch.empty(B, 14, 14, C, dtype=torch.bfloat16, device=DEV)
+    arg = torch.empty(B, 14, 14, C, dtype=torch.uint8, device=DEV)
+    check(gpu_lib.dtf_conv1_fwd(ptr(images), ptr(idx), ptr(w), ptr(b), ptr(pooled), ptr(arg), B, C, 0, stream()),
+          "conv1_fwd")
+    x = images[idx.long()].float().reshape(B, 28, 28, 1)
+    ref, ref_arg = conv_block_ref(x, w, b)
+    assert rel_err(pooled, ref) < 5e-3
+    live = ref > 1e-3
+    agree = (arg == ref_arg)[live].float().mean()
+    assert agree > 0.995, agree
+
+
+@pytest.mark.parametrize("B,C", [(33, 32), (6, 128)])
+def test_conv1_wgrad(gpu_lib, B, C):
+    g = torch.Generator(device="cpu").manual_seed(2)
+    images = bf(torch.rand(B, 784, generator=g)).to(DEV)
+    w = (torch.randn(5, 5, 1, C, generator=g) * 0.1).to(DEV).requires_grad_(True)
+    b = (torch.randn(C, generator=g) * 0.1).to(DEV).requires_grad_(True)
+    x = images.float().reshape(B, 28, 28, 1)
+    y = R.maxpool2d(R.conv2d_same(x, w, b))
+    gp = bf(torch.randn(y.shape, generator=g)).to(DEV)
+    y.backward(gp.float())
+    pooled, arg = conv_block_ref(x, w.detach(), b.detach())
+    G = 7
+    part = torch.empty(G, 26 * C, device=DEV)
+    check(gpu_lib.dtf_conv1_wgrad(ptr(images), None, ptr(gp), ptr(arg.contiguous()), ptr(bf(pooled).contiguous()),
+                                  ptr(part), B, C, G, stream()), "conv1_wgrad")
+    got = part.sum(0)
+    assert rel_err(got[:25 * C].reshape(5, 5, 1, C), w.grad) < 2e-3
+    assert rel_err(got[25 * C:], b.grad) < 2e-3
+
+
+# ---------------------------------------------------------------------- conv2
+def _conv2_inputs(B, C1, C2, seed):
+    g = torch.Generator(device="cpu").manual_seed(seed)
+    x = bf(torch.rand(B, 14, 14, C1, generator=g)).to(DEV)
+    w = bf(torch.randn(5, 5, C1, C2, generator=g) * (1.0 / (25 * C1) ** 0.5)).to(DEV)
+    b = (torch.randn(C2, generator=g) * 0.1).to(DEV)
+    return g, x, w, b
+
+
+@pytest.mark.parametrize("B,C1,C2", [(1, 32, 64), (5, 32, 64), (64, 32, 64), (3, 128, 256)])
+def test_conv2_fwd(gpu_lib, B, C1, C2):
+    g, x, w, b = _conv2_inputs(B, C1, C2, 3)
+    wT = w.reshape(25, C1, C2).transpose(1, 2).contiguous()
+    pooled = torch.empty(B, 7, 7, C2, dtype=torch.bfloat16, device=DEV)
+    arg = torch.empty(B, 7, 7, C2, dtype=torch.uint8, device=DEV)
+    check(gpu_lib.dtf_conv2_fwd(ptr(x), ptr(wT), ptr(b), ptr(pooled), ptr(arg), B, C1, C2, stream()), "conv2_fwd")
+    ref, ref_arg = conv_block_ref(x, w, b)
+    assert rel_err(pooled, ref) < 6e-3
+    live = ref > 1e-2
+    agree = (arg == ref_arg)[live].float().mean()
+    assert agree > 0.99, agree
+
+
+@pytest.mark.parametrize("B,C1,C2", [(1, 32, 64), (5, 32, 64), (32, 32, 64)])
+def test_conv2_backward(gpu_lib, B, C1, C2):
+    g, x, w, b = _conv2_inputs(B, C1, C2, 4)
+    xf = x.float().requires_grad_(True)
+    wf = w.float().requires_grad_(True)
+    bfp = b.clone().requires_grad_(True)
+    y = R.maxpool2d(R.conv2d_same(xf, wf, bfp))
+    gp = bf(torch.randn(y.shape, generator=g)).to(DEV)
+    y.backward(gp.float())
+    pooled, arg = conv_block_ref(x, w, b)
+    pooled_bf = bf(pooled).contiguous()
+    arg = arg.contiguous()
+    # dgrad
+    dx = torch.empty(B, 14, 14, C1, dtype=torch.bfloat16, device=DEV)
+    check(gpu_lib.dtf_conv2_dgrad(ptr(gp), ptr(arg), ptr(pooled_bf), ptr(w), ptr(dx), B, C1, C2, stream()),
+          "conv2_dgrad")
+    assert rel_err(dx, xf.grad) < 8e-3
+    # wgrad
+    G = 3
+    stride = 25 * C1 * C2 + C2
+    part = torch.zeros(G, stride, device=DEV)
+    check(gpu_lib.dtf_conv2_wgrad(ptr(x), ptr(gp), ptr(arg), ptr(pooled_bf), ptr(part), B, C1, C2, G, stream()),
+          "conv2_wgrad")
+    got = part.sum(0)
+    assert rel_err(got[:25 * C1 * C2].reshape(5, 5, C1, C2), wf.grad) < 3e-3
+    assert rel_err(got[25 * C1 * C2:], bfp.grad) < 3e-3
+
+
+# ----------------------------------------------------------------------- GEMMs
+@pytest.mark.parametrize("M,N,K,tile", [(100, 1024, 3136, 64), (128, 1024, 3136, 128), (257, 192, 64, 64),
+                                        (1000, 3136, 1024, 128), (64, 64, 128, 0)])
+def test_gemm_nt(gpu_lib, M, N, K, tile):
+    g = torch.Generator(device="cpu").manual_seed(5)
+    # asymmetric operands so a transposed/garbled fragment map cannot pass
+    A = bf(torch.randn(M, K, generator=g)).to(DEV)
+    Bm = bf(torch.randn(N, K, generator=g) * 0.05 + torch.arange(N).float()[:, None] * 1e-3).to(DEV)
+    bias = torch.randn(N, generator=g).to(DEV)
+    C = torch.empty(M, N, dtype=torch.bfloat16, device=DEV)
+    check(gpu_lib.dtf_gemm_nt(ptr(A), ptr(Bm), ptr(C), None, M, N, K, K, K, N, 0, 1.0, 0, None, tile, stream()),
+          "gemm_nt")
+    ref = A.float() @ Bm.float().t()
+    assert rel_err(C, ref) < 4e-3
+    check(gpu_lib.dtf_gemm_nt(ptr(A), ptr(Bm), ptr(C), ptr(bias), M, N, K, K, K, N, 1, 1.0, 0, None, tile, stream()),
+          "gemm_nt epi")
+    assert rel_err(C, F.relu(ref + bias)) < 4e-3
+
+
+def test_gemm_nt_dropout(gpu_lib):
+    M, N, K, keep = 256, 1024, 256, 0.75
+    g = torch.Generator(device="cpu").manual_seed(6)
+    A = bf(torch.rand(M, K, generator=g)).to(DEV)
+    Bm = bf(torch.rand(N, K, generator=g)).to(DEV)
+    bias = torch.zeros(N, device=DEV)
+    state = torch.zeros(8, dtype=torch.int64, device=DEV)
+    C0 = torch.empty(M, N, dtype=torch.bfloat16, device=DEV)
+    C1 = torch.empty_like(C0)
+    C2 = torch.empty_like(C0)
+    args = (ptr(A), ptr(Bm))
+    check(gpu_lib.dtf_gemm_nt(*args, ptr(C0), ptr(bias), M, N, K, K, K, N, 1, keep, 9, ptr(state), 0, stream()), "d0")
+    check(gpu_lib.dtf_gemm_nt(*args, ptr(C1), ptr(bias), M, N, K, K, K, N, 1, keep, 9, ptr(state), 0, stream()), "d1")
+    state[2] = 1
+    check(gpu_lib.dtf_gemm_nt(*args, ptr(C2), ptr(bias), M, N, K, K, K, N, 1, keep, 9, ptr(state), 0, stream()), "d2")
+    ref = (A.float() @ Bm.float().t())
+    kept = C0.float() > 0
+    frac = float(kept.float().mean())
+    assert abs(frac - keep) < 0.01, frac
+    assert torch.equal(C0, C1)              # same offset -> same mask
+    assert not torch.equal(C0, C2)          # new offset -> new mask
+    assert rel_err(C0.float()[kept], (ref / keep)[kept]) < 4e-3
+
+
+@pytest.mark.parametrize("M,N,K,tile", [(3136, 1024, 100, 128), (3136, 1024, 256, 64), (200, 136, 1000, 64),
+                                        (128, 128, 64, 128)])
+def test_gemm_tn(gpu_lib, M, N, K, tile):
+    g = torch.Generator(device="cpu").manual_seed(7)
+    A = bf(torch.randn(K, M, generator=g) + torch.arange(M).float()[None, :] * 1e-3).to(DEV)
+    Bm = bf(torch.randn(K, N, generator=g)).to(DEV)
+    C = torch.empty(M, N, device=DEV)
+    check(gpu_lib.dtf_gemm_tn(ptr(A), ptr(Bm), ptr(C), M, N, K, M, N, N, tile, stream()), "gemm_tn")
+    ref = A.float().t() @ Bm.float()
+    assert rel_err(C, ref) < 1e-4
+
+
+def test_transpose(gpu_lib):
+    x = bf(torch.randn(3, 100, 72)).to(DEV)
+    out = torch.empty(3, 72, 100, dtype=torch.bfloat16, device=DEV)
+    check(gpu_lib.dtf_transpose_bf16(ptr(x), ptr(out), 3, 100, 72, stream()), "transpose")
+    assert torch.equal(out, x.transpose(1, 2).contiguous())
+
+
+# ------------------------------------------------------------------------ head
+@pytest.mark.parametrize("B,H", [(1, 1024), (100, 1024), (37, 4096)])
+def test_head(gpu_lib, B, H):
+    g = torch.Generator(device="cpu").manual_seed(8)
+    h1 = bf(F.relu(torch.randn(B, H, generator=g))).to(DEV)
+    w = (torch.randn(H, 10, generator=g) * 0.1).to(DEV).requires_grad_(True)
+    b = (torch.randn(10, generator=g) * 0.1).to(DEV).requires_grad_(True)
+    labels = torch.randint(0, 10, (B,), generator=g, dtype=torch.int32).to(DEV)
+    keep = 0.5
+    hf = h1.float().requires_grad_(True)
+    z = hf @ w + b
+    loss_rows = R.softmax_cross_entropy_with_logits(z, labels)
+    loss_rows.mean().backward()
+
+    logits = torch.empty(B, 10, device=DEV)
+    lrows = torch.empty(B, device=DEV)
+    crows = torch.empty(B, device=DEV)
+    dlog = torch.empty(B, 10, device=DEV)
+    da = torch.empty(B, H, dtype=torch.bfloat16, device=DEV)
+    check(gpu_lib.dtf_head_fwd_bwd(ptr(h1), ptr(w), ptr(b), ptr(labels), None, ptr(logits), ptr(lrows), ptr(crows),
+                                   ptr(dlog), ptr(da), B, H, 1.0 / B, 1.0 / keep, 1, stream()), "head")
+    assert rel_err(logits, z) < 1e-5
+    assert rel_err(lrows, loss_rows) < 1e-5
+    assert torch.equal(crows, (z.argmax(-1) == labels.long()).float())
+    dz = (torch.softmax(z.detach(), -1) - F.one_hot(labels.long(), 10).float()) / B
+    assert rel_err(dlog, dz) < 1e-5
+    want_da = torch.where(h1.float() > 0, hf.grad / keep, torch.zeros_like(hf.grad))
+    assert rel_err(da, want_da) < 4e-3
+
+    KS = 3
+    stride = H * 10 + 12 + H
+    part = torch.empty(KS, stride, device=DEV)
+    check(gpu_lib.dtf_head_wgrad(ptr(h1), ptr(dlog), ptr(da), ptr(part), B, H, KS, stream()), "head_wgrad")
+    got = part.sum(0)
+    assert rel_err(got[:H * 10].reshape(H, 10), w.grad) < 1e-4
+    assert rel_err(got[H * 10:H * 10 + 10], b.grad) < 1e-4
+    assert float(got[H * 10 + 10:H * 10 + 12].abs().max()) == 0.0
+    assert rel_err(got[H * 10 + 12:], da.float().sum(0)) < 1e-4
+
+
+# ------------------------------------------------------------------- optimizer
+def test_reduce_segments(gpu_lib):
+    a = torch.randn(5, 1000, device=DEV)
+    b = torch.randn(3, 77, device=DEV)
+    out = torch.zeros(1000 + 80, device=DEV)
+    parts = (ctypes.c_void_p * 2)(a.data_ptr(), b.data_ptr())
+    outs = (ctypes.c_void_p * 2)(out.data_ptr(), out.data_ptr() + 4 * 1000)
+    G = (ctypes.c_int * 2)(5, 3)
+    n = (ctypes.c_int * 2)(1000, 77)
+    st = (ctypes.c_long * 2)(1000, 77)
+    check(gpu_lib.dtf_reduce_segments(2, parts, outs, G, n, st, stream()), "reduce")
+    assert torch.allclose(out[:1000], a.sum(0), atol=1e-5)
+    assert torch.allclose(out[1000:1077], b.sum(0), atol=1e-5)
+    assert float(out[1077:].abs().max()) == 0.0
+
+
+def test_sgd_and_adam(gpu_lib):
+    n = 4 * 1000 + 4
+    w0 = torch.randn(n, device=DEV)
+    g = torch.randn(n, device=DEV)
+    hyper = torch.tensor([0.01, 0.9, 0.999, 1e-8, 0.5, 0, 0, 0], device=DEV)
+    state = torch.zeros(8, dtype=torch.int64, device=DEV)
+    w = w0.clone()
+    sh = torch.empty(n, dtype=torch.bfloat16, device=DEV)
+    check(gpu_lib.dtf_sgd_update(ptr(w), ptr(g), ptr(sh), ptr(hyper), n, ptr(state), 128, 1, stream()), "sgd")
+    assert torch.allclose(w, w0 - 0.01 * 0.5 * g, atol=1e-6)
+    assert torch.equal(sh, w.to(torch.bfloat16))
+    assert state[:4].tolist() == [128, 1, 1, 1]
+    # adam, 3 steps against torch.optim.Adam (grad pre-scaled by hyper[4])
+    state.zero_()
+    w = w0.clone()
+    m = torch.zeros(n, device=DEV)
+    v = torch.zeros(n, device=DEV)
+    wt = w0.clone().requires_grad_(True)
+    opt = torch.optim.Adam([wt], lr=0.01, betas=(0.9, 0.999), eps=1e-8)
+    for _ in range(3):
+        check(gpu_lib.dtf_adam_update(ptr(w), ptr(g), ptr(m), ptr(v), ptr(sh), ptr(hyper), n, ptr(state), 0, 1,
+                                      stream()), "adam")
+        wt.grad = g * 0.5
+        opt.step()
+    # TF/our epsilon placement (eps outside the bias-corrected sqrt) differs slightly from torch's
+    assert torch.allclose(w, wt.detach(), atol=2e-5)
+    assert int(state[3]) == 3 and int(state[1]) == 3
