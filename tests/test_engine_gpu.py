@@ -30,7 +30,8 @@ def test_step_matches_oracle(gpu_lib, dataset, B):
     eng.init_params()
     # the oracle consumes the bf16-rounded parameters the kernels see
     oracle = OracleModel(spec, device="cuda", optimizer="sgd", learning_rate=0.01)
-    oracle.load_params(eng.export_params())
+    p0 = eng.export_params()
+    oracle.load_params(p0)
     idx = batch_indices(0, B, dataset.n, 5)
     x = dataset.images[torch.as_tensor(idx, device="cuda")].float()
     y = dataset.labels[torch.as_tensor(idx, device="cuda")]
@@ -48,11 +49,11 @@ def test_step_matches_oracle(gpu_lib, dataset, B):
         assert e < 5e-2, (name, e)
     assert eng.global_step == 1
     assert int(eng.state[0]) == B
-    # update applied
+    # update applied: the parameter deltas agree as well as the gradients do
     oracle.apply_gradients()
     p_ref, p = oracle.export_params(), eng.export_params()
     for name in eng.layout.names():
-        assert rel_err(p[name], p_ref[name]) < 1e-3, name
+        assert rel_err(p[name] - p0[name], p_ref[name] - p0[name]) < 5e-2, name
     # bf16 shadows/transposes follow the master weights
     wd1 = eng.pview("wd1")
     assert torch.equal(eng.wd1T, wd1.to(torch.bfloat16).t().contiguous())

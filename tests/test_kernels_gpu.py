@@ -302,13 +302,17 @@ def test_sgd_and_adam(gpu_lib):
     w = w0.clone()
     m = torch.zeros(n, device=DEV)
     v = torch.zeros(n, device=DEV)
-    wt = w0.clone().requires_grad_(True)
-    opt = torch.optim.Adam([wt], lr=0.01, betas=(0.9, 0.999), eps=1e-8)
-    for _ in range(3):
+    # reference: TF AdamOptimizer update rule (epsilon outside the bias-corrected sqrt), fp64
+    wr, mr, vr = w0.double().clone(), torch.zeros(n, dtype=torch.float64, device=DEV), torch.zeros(n, dtype=torch.float64, device=DEV)
+    b1, b2 = float(hyper[1]), float(hyper[2])
+    for t in range(1, 4):
         check(gpu_lib.dtf_adam_update(ptr(w), ptr(g), ptr(m), ptr(v), ptr(sh), ptr(hyper), n, ptr(state), 0, 1,
                                       stream()), "adam")
-        wt.grad = g * 0.5
-        opt.step()
-    # TF/our epsilon placement (eps outside the bias-corrected sqrt) differs slightly from torch's
-    assert torch.allclose(w, wt.detach(), atol=2e-5)
+        ge = g.double() * 0.5
+        mr = b1 * mr + (1 - b1) * ge
+        vr = b2 * vr + (1 - b2) * ge * ge
+        lr_t = 0.01 * (1 - b2 ** t) ** 0.5 / (1 - b1 ** t)
+        wr = wr - lr_t * mr / (vr.sqrt() + 1e-8)
+    assert float((w.double() - wr).abs().max()) < 2e-5
+    assert torch.equal(sh, w.to(torch.bfloat16))
     assert int(state[3]) == 3 and int(state[1]) == 3
