@@ -215,43 +215,56 @@ __global__ __launch_bounds__(IMGS * 2 * NW * 64) void conv5x5_igemm(
 //   arg    [B,7,7,C_OUT]  u8     saved argmax
 //   pooled [B,7,7,C_OUT]  bf16   forward pooled output (ReLU mask = pooled > 0)
 //   part   [G][25*C_IN*C_OUT + C_OUT] fp32 partial slabs (HWIO order, then bias)
-// Each block: 4 waves = (mi in {0,1}: 16 input channels) x (nh in {0,1}: 32
-// output channels); every wave walks all images of its chunk, 7 row pairs each.
-// K (=32 positions of a row pair) is ordered for the transposing LDS read:
-//   element j of lane group g  <->  dy = g>>1, x = 4*(g&1) + (j&3) + 8*(j>>2)
+// Per image the block stages two LDS images: the halo-padded input tile
+// [pos][32 ci] and the max-pool/ReLU-expanded output gradient [row pair][k][64 co]
+// (k = 16*dy + x, the K order of a row pair).  Both are K-slow, so A and B
+// fragments both come from ds_read_b64_tr_b16; 32-byte sub-slots are XOR
+// swizzled so every transposed read is bank-conflict free.
+// 4 waves = (mi: 16 input channels) x (kh: alternate row pairs); a wave owns
+// 5 taps x 4 n-tiles = 20 accumulator tiles, so each A fragment feeds 4 MFMAs
+// and each B fragment 5.  The two kh halves are summed through LDS at the end.
+// Element j of lane group g  <->  dy = g>>1, x = 4*(g&1) + (j&3) + 8*(j>>2).
 // ----------------------------------------------------------------------------
+constexpr int kWgXTileBytes = kTilePos * 32 * 2;   // 20992
+constexpr int kWgDyTileBytes = 7 * 32 * 64 * 2;    // 28672
+
 template <int C_IN, int C_OUT>
 __global__ __launch_bounds__(256) void conv5x5_wgrad(
     const bf16* __restrict__ x, const bf16* __restrict__ gpool,
     const uint8_t* __restrict__ arg, const bf16* __restrict__ pooled,
     float* __restrict__ part, int B, int imgs_per_block) {
-  constexpr int CI_T = C_IN / 32, CO_T = C_OUT / 64;
-  __shared__ __attribute__((aligned(16))) bf16 tile[kTilePos * 32];  // [pos][32 ci], halves swizzled
+  constexpr int CI_T = C_IN / 32;
+  typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
+  typedef __attribute__((ext_vector_type(8))) short s16x8;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  bf16* xt = reinterpret_cast<bf16*>(smem);                  // [328][32], halves swizzled
+  bf16* dyt = reinterpret_cast<bf16*>(smem + kWgXTileBytes);  // [7][32][64], 32-B slots swizzled
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int mi = wave & 1, nh = wave >> 1;
+  const int mi = wave & 1, kh = wave >> 1;
   const int ky = blockIdx.y;
   const int ci_t = blockIdx.z % CI_T, co_t = blockIdx.z / CI_T;
   const int g = lane >> 4, i16 = lane & 15;
-  const int qr = i16 >> 2, pc = i16 & 3;  // tr-read: row in 4-row block, 4-channel column chunk
+  const int qr = i16 >> 2, pc = i16 & 3;
+  const bool do_bias = (ky == 0) && (ci_t == 0) && (mi == 0);
 
   const int b_begin = blockIdx.x * imgs_per_block;
   const int b_end = min(B, b_begin + imgs_per_block);
 
-  f32x4 acc[5][2];
+  f32x4 acc[5][4];
 #pragma unroll
   for (int t = 0; t < 5; ++t)
 #pragma unroll
-    for (int j = 0; j < 2; ++j) acc[t][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
-  float bsum[2] = {0.f, 0.f};
+    for (int j = 0; j < 4; ++j) acc[t][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  float bsum[4] = {0.f, 0.f, 0.f, 0.f};
 
-  // zero once: halo and slack stay zero, the interior is overwritten per image
-  for (int i = tid; i < kTilePos * 32 * 2 / 16; i += 256)
-    reinterpret_cast<u32x4*>(tile)[i] = (u32x4){0u, 0u, 0u, 0u};
+  // zero once: halo, slack and the x = 14,15 dummy columns stay zero
+  for (int i = tid; i < (kWgXTileBytes + kWgDyTileBytes) / 16; i += 256)
+    reinterpret_cast<u32x4*>(smem)[i] = (u32x4){0u, 0u, 0u, 0u};
 
-  // tr-read lane address (in elements) for row pair 0, kx = 0, first read
-  const int tr_pos = (ky + (g >> 1)) * kTileW + 4 * (g & 1) + qr;
-  const int co_base = co_t * 64 + nh * 32;
+  const int tr_pos = (ky + (g >> 1)) * kTileW + 4 * (g & 1) + qr;  // A: row pair 0, kx 0, first read
+  const int kkrow = (g >> 1) * 16 + 4 * (g & 1) + qr;              // B: k row of the first read
+  const int bsw = (kkrow >> 1) & 3;                                // its slot swizzle (same for +8)
 
   for (int b = b_begin; b < b_end; ++b) {
     __syncthreads();  // previous image fully consumed (and the zero fill done)
@@ -261,72 +274,97 @@ __global__ __launch_bounds__(256) void conv5x5_wgrad(
       int y = pos / 14, xx = pos % 14;
       int tp = (y + 2) * kTileW + (xx + 2);
       int chs = ch ^ (((tp >> 2) & 1) << 1);  // swap 32-byte halves on odd 4-position groups
-      *reinterpret_cast<u32x4*>(tile + tp * 32 + chs * 8) = v;
+      *reinterpret_cast<u32x4*>(xt + tp * 32 + chs * 8) = v;
+    }
+    for (int c = tid; c < 49 * 8; c += 256) {
+      int c8 = c & 7, pp = c >> 3;
+      int r = pp / 7, w = pp % 7;
+      size_t off = ((size_t)b * 49 + pp) * C_OUT + co_t * 64 + c8 * 8;
+      bf16x8 gv = *reinterpret_cast<const bf16x8*>(gpool + off);
+      bf16x8 pv = *reinterpret_cast<const bf16x8*>(pooled + off);
+      u32x2 a2 = *reinterpret_cast<const u32x2*>(arg + off);
+      bf16x8 o[4];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        unsigned a = ((e < 4 ? a2[0] : a2[1]) >> ((e & 3) * 8)) & 0xffu;
+        bool live = (float)pv[e] > 0.f;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) o[q][e] = (live && a == (unsigned)q) ? gv[e] : (bf16)0.f;
+      }
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        int kk = (q >> 1) * 16 + 2 * w + (q & 1);
+        int slot = (((c8 >> 1) ^ ((kk >> 1) & 3)) << 1) | (c8 & 1);
+        *reinterpret_cast<bf16x8*>(dyt + (r * 32 + kk) * 64 + slot * 8) = o[q];
+      }
     }
     __syncthreads();
 #pragma unroll 1
-    for (int r = 0; r < 7; ++r) {
-      // ---- dY fragments (2 n-tiles) built from the pooled gradient ----
-      bf16x8 bfrag[2];
+    for (int r = (kh + b) & 1; r < 7; r += 2) {
+      bf16x8 bfrag[4];
 #pragma unroll
-      for (int j = 0; j < 2; ++j) {
-        const int n = co_base + j * 16 + i16;
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          // elements 2e, 2e+1 (same window, dx = 0,1)
-          const int w = 2 * (g & 1) + (e & 1) + 4 * (e >> 1);
-          float gv = 0.f;
-          int a = -1;
-          if (w < 7) {
-            size_t off = (((size_t)b * 7 + r) * 7 + w) * C_OUT + n;
-            float pv = (float)pooled[off];
-            if (pv > 0.f) { gv = (float)gpool[off]; a = arg[off]; }
-          }
-          const int q0 = (g >> 1) * 2;
-          float v0 = (a == q0) ? gv : 0.f, v1 = (a == q0 + 1) ? gv : 0.f;
-          bfrag[j][2 * e] = (bf16)v0;
-          bfrag[j][2 * e + 1] = (bf16)v1;
-          bsum[j] += v0 + v1;
-        }
+      for (int j = 0; j < 4; ++j) {
+        const bf16* p0 = dyt + (r * 32 + kkrow) * 64 + ((j ^ bsw) << 4) + pc * 4;
+        s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)p0);
+        s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(p0 + 8 * 64));
+        s16x8 v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+        bfrag[j] = __builtin_bit_cast(bf16x8, v);
       }
-      // ---- 5 taps of this tap row ----
+      if (do_bias) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+          for (int e = 0; e < 8; ++e) bsum[j] += (float)bfrag[j][e];
+      }
 #pragma unroll
       for (int kx = 0; kx < 5; ++kx) {
         const int p0 = tr_pos + 2 * r * kTileW + kx;
         const int p1 = p0 + 8;
         const int h0 = mi ^ ((p0 >> 2) & 1), h1 = mi ^ ((p1 >> 2) & 1);
-        s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
-            (__attribute__((address_space(3))) s16x4*)(tile + p0 * 32 + h0 * 16 + pc * 4));
-        s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
-            (__attribute__((address_space(3))) s16x4*)(tile + p1 * 32 + h1 * 16 + pc * 4));
-        typedef __attribute__((ext_vector_type(8))) short s16x8;
+        s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(xt + p0 * 32 + h0 * 16 + pc * 4));
+        s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(xt + p1 * 32 + h1 * 16 + pc * 4));
         s16x8 av = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
         bf16x8 afrag = __builtin_bit_cast(bf16x8, av);
-        acc[kx][0] = mfma16(afrag, bfrag[0], acc[kx][0]);
-        acc[kx][1] = mfma16(afrag, bfrag[1], acc[kx][1]);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[kx][j] = mfma16(afrag, bfrag[j], acc[kx][j]);
       }
     }
   }
 
-  // ---- write the partial slab: rows ci = 4g + r, cols co ----
+  // ---- sum the two kh halves through LDS, then write the slab ----
+  __syncthreads();
+  float* red = reinterpret_cast<float*>(smem);  // [mi][84][64 lanes]
+  if (kh == 1) {
+#pragma unroll
+    for (int kx = 0; kx < 5; ++kx)
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) red[(mi * 84 + (kx * 4 + j) * 4 + r) * 64 + lane] = acc[kx][j][r];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) red[(mi * 84 + 80 + j) * 64 + lane] = bsum[j];
+  }
+  __syncthreads();
+  if (kh == 1) return;
   float* slab = part + (size_t)blockIdx.x * (25 * C_IN * C_OUT + C_OUT);
 #pragma unroll
   for (int kx = 0; kx < 5; ++kx)
 #pragma unroll
-    for (int j = 0; j < 2; ++j)
+    for (int j = 0; j < 4; ++j)
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         int ci = ci_t * 32 + mi * 16 + 4 * g + r;
-        int co = co_base + j * 16 + i16;
-        slab[((size_t)(ky * 5 + kx) * C_IN + ci) * C_OUT + co] = acc[kx][j][r];
+        int co = co_t * 64 + j * 16 + i16;
+        slab[((size_t)(ky * 5 + kx) * C_IN + ci) * C_OUT + co] =
+            acc[kx][j][r] + red[(mi * 84 + (kx * 4 + j) * 4 + r) * 64 + lane];
       }
-  if (ky == 0 && ci_t == 0 && mi == 0) {
+  if (do_bias) {
 #pragma unroll
-    for (int j = 0; j < 2; ++j) {
-      float s = bsum[j];
+    for (int j = 0; j < 4; ++j) {
+      float s = bsum[j] + red[(mi * 84 + 80 + j) * 64 + lane];
       s += __shfl_xor(s, 16, 64);
       s += __shfl_xor(s, 32, 64);
-      if (g == 0) slab[25 * C_IN * C_OUT + co_base + j * 16 + i16] = s;
+      if (g == 0) slab[25 * C_IN * C_OUT + co_t * 64 + j * 16 + i16] = s;
     }
   }
 }
@@ -386,12 +424,12 @@ int dtf_conv2_wgrad(const void* x, const void* gpool, const void* arg, const voi
   if (G <= 0) return -2;
   int ipb = (B + G - 1) / G;
   if (cin == 32 && cout == 64) {
-    hipLaunchKernelGGL((conv5x5_wgrad<32, 64>), dim3(G, 5, 1), dim3(256), 0, s, (const bf16*)x,
+    hipLaunchKernelGGL((conv5x5_wgrad<32, 64>), dim3(G, 5, 1), dim3(256), kWgXTileBytes + kWgDyTileBytes, s, (const bf16*)x,
                        (const bf16*)gpool, (const uint8_t*)arg, (const bf16*)pooled, (float*)part, B, ipb);
     return DTF_LAUNCH_CHECK();
   }
   if (cin == 128 && cout == 256) {
-    hipLaunchKernelGGL((conv5x5_wgrad<128, 256>), dim3(G, 5, 16), dim3(256), 0, s, (const bf16*)x,
+    hipLaunchKernelGGL((conv5x5_wgrad<128, 256>), dim3(G, 5, 16), dim3(256), kWgXTileBytes + kWgDyTileBytes, s, (const bf16*)x,
                        (const bf16*)gpool, (const uint8_t*)arg, (const bf16*)pooled, (float*)part, B, ipb);
     return DTF_LAUNCH_CHECK();
   }

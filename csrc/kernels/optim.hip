@@ -98,28 +98,41 @@ struct ReduceSeg {
   const float* part;  // [G][stride]
   float* out;         // [n]
   int G;
-  int n;
-  long stride;
+  int n;              // multiple of 4
+  long stride;        // multiple of 4
 };
 struct ReduceSegs {
   ReduceSeg s[4];
+  int blocks_end[4];  // exclusive prefix of blocks per segment
   int count;
 };
 
+// 256 threads = 64 float4 columns x 4 slab groups; fixed summation order -> deterministic.
 __global__ __launch_bounds__(256) void reduce_segments(ReduceSegs segs) {
-  long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  __shared__ f32x4 red[4][64];
+  int k = 0, blk = blockIdx.x;
 #pragma unroll
-  for (int k = 0; k < 4; ++k) {
-    if (k >= segs.count) return;
-    const ReduceSeg sg = segs.s[k];
-    if (i < sg.n) {
-      float acc = 0.f;
-      for (int gI = 0; gI < sg.G; ++gI) acc += sg.part[(size_t)gI * sg.stride + i];
-      sg.out[i] = acc;
-      return;
+  for (int t = 0; t < 3; ++t)
+    if (k == t && t + 1 < segs.count && (int)blockIdx.x >= segs.blocks_end[t]) { k = t + 1; blk = blockIdx.x - segs.blocks_end[t]; }
+  const ReduceSeg sg = segs.s[k];
+  const int col = threadIdx.x & 63, grp = threadIdx.x >> 6;
+  const long i4 = (long)blk * 64 + col;
+  f32x4 a0 = {0.f, 0.f, 0.f, 0.f}, a1 = a0;
+  if (i4 * 4 < sg.n) {
+    const float* p = sg.part + i4 * 4;
+    int gI = grp;
+    for (; gI + 4 < sg.G; gI += 8) {
+      f32x4 v0 = *reinterpret_cast<const f32x4*>(p + (size_t)gI * sg.stride);
+      f32x4 v1 = *reinterpret_cast<const f32x4*>(p + (size_t)(gI + 4) * sg.stride);
+      a0 += v0;
+      a1 += v1;
     }
-    i -= sg.n;
+    if (gI < sg.G) a0 += *reinterpret_cast<const f32x4*>(p + (size_t)gI * sg.stride);
   }
+  red[grp][col] = a0 + a1;
+  __syncthreads();
+  if (grp == 0 && i4 * 4 < sg.n)
+    *reinterpret_cast<f32x4*>(sg.out + i4 * 4) = (red[0][col] + red[1][col]) + (red[2][col] + red[3][col]);
 }
 
 }  // namespace dtf
@@ -164,18 +177,25 @@ int dtf_cast_bf16(const void* w, void* shadow, long n, hipStream_t s) {
   return (int)hipGetLastError();
 }
 
-// up to 4 segments: part[k] is [G[k]][stride[k]], out[k] has n[k] floats
+// up to 4 segments: part[k] is [G[k]][stride[k]], out[k] has n[k] floats (n, stride multiples of 4,
+// pointers 16-byte aligned)
 int dtf_reduce_segments(int count, const void** part, void** out, const int* G, const int* n,
                         const long* stride, hipStream_t s) {
   if (count < 1 || count > 4) return -2;
   ReduceSegs segs;
-  long total = 0;
-  for (int k = 0; k < count; ++k) {
-    segs.s[k] = ReduceSeg{(const float*)part[k], (float*)out[k], G[k], n[k], stride[k]};
-    total += n[k];
+  int blocks = 0;
+  for (int k = 0; k < 4; ++k) {
+    if (k < count) {
+      if ((n[k] & 3) || (stride[k] & 3) || ((uintptr_t)part[k] & 15) || ((uintptr_t)out[k] & 15)) return -3;
+      segs.s[k] = ReduceSeg{(const float*)part[k], (float*)out[k], G[k], n[k], stride[k]};
+      blocks += (n[k] / 4 + 63) / 64;
+    } else {
+      segs.s[k] = ReduceSeg{nullptr, nullptr, 0, 0, 0};
+    }
+    segs.blocks_end[k] = blocks;
   }
   segs.count = count;
-  hipLaunchKernelGGL(reduce_segments, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, segs);
+  hipLaunchKernelGGL(reduce_segments, dim3(blocks), dim3(256), 0, s, segs);
   return (int)hipGetLastError();
 }
 

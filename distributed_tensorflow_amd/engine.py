@@ -134,7 +134,7 @@ class HipEngine:
         self.c2_g = max(1, min((B + 1) // 2, 102))
         self.c2_stride = 25 * C1 * C2 + C2
         self.c2_part = torch.empty((self.c2_g, self.c2_stride), **f32)
-        self.c1_g = max(1, min(B, 256))
+        self.c1_g = max(1, min(B, 512))
         self.c1_stride = 26 * C1
         self.c1_part = torch.empty((self.c1_g, self.c1_stride), **f32)
 

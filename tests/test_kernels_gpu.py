@@ -272,17 +272,17 @@ def test_head(gpu_lib, B, H):
 # ------------------------------------------------------------------- optimizer
 def test_reduce_segments(gpu_lib):
     a = torch.randn(5, 1000, device=DEV)
-    b = torch.randn(3, 77, device=DEV)
+    b = torch.randn(3, 76, device=DEV)
     out = torch.zeros(1000 + 80, device=DEV)
     parts = (ctypes.c_void_p * 2)(a.data_ptr(), b.data_ptr())
     outs = (ctypes.c_void_p * 2)(out.data_ptr(), out.data_ptr() + 4 * 1000)
     G = (ctypes.c_int * 2)(5, 3)
-    n = (ctypes.c_int * 2)(1000, 77)
-    st = (ctypes.c_long * 2)(1000, 77)
+    n = (ctypes.c_int * 2)(1000, 76)
+    st = (ctypes.c_long * 2)(1000, 76)
     check(gpu_lib.dtf_reduce_segments(2, parts, outs, G, n, st, stream()), "reduce")
     assert torch.allclose(out[:1000], a.sum(0), atol=1e-5)
-    assert torch.allclose(out[1000:1077], b.sum(0), atol=1e-5)
-    assert float(out[1077:].abs().max()) == 0.0
+    assert torch.allclose(out[1000:1076], b.sum(0), atol=1e-5)
+    assert float(out[1076:].abs().max()) == 0.0
 
 
 def test_sgd_and_adam(gpu_lib):
