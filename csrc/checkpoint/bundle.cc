@@ -1,0 +1,641 @@
+// TensorFlow "tensor bundle" (tf.train.Saver V2) checkpoint codec, from the
+// documented on-disk format -- no TensorFlow dependency.
+//
+// The reference saves its 9 unnamed variables with tf.train.Saver() through the
+// Supervisor (reference .idea/MNISTDist.py:154, :159-165); TF >= 0.12 writes that
+// as a bundle:
+//   <prefix>.index                 LevelDB-style SSTable: key "" -> BundleHeaderProto,
+//                                  key <tensor name> -> BundleEntryProto
+//   <prefix>.data-00000-of-00001   raw little-endian tensor bytes, back to back
+// This file implements both directions (so checkpoints written here load in
+// TensorFlow and TF-written ones load here):
+//   * crc32c (Castagnoli) + the LevelDB/TF mask
+//   * varint32/64, fixed32/64
+//   * SSTable blocks with prefix compression + restart array, block trailer
+//     (type byte + masked crc), index block, empty metaindex block, 48-byte footer
+//     with magic 0xdb4775248b80fb57
+//   * minimal protobuf wire encode/decode for BundleHeaderProto, BundleEntryProto,
+//     TensorShapeProto, VersionDef
+// Exposed through a C ABI (see bottom) and bound from Python with ctypes.
+#include <algorithm>
+#include <cstdint>
+#include <cstdio>
+#include <cstring>
+#include <map>
+#include <memory>
+#include <string>
+#include <vector>
+
+namespace dtfckpt {
+
+// ------------------------------------------------------------------ crc32c
+static uint32_t g_crc_table[8][256];
+static bool g_crc_init = false;
+
+static void crc_init() {
+  if (g_crc_init) return;
+  const uint32_t poly = 0x82f63b78u;  // reflected Castagnoli
+  for (uint32_t i = 0; i < 256; ++i) {
+    uint32_t c = i;
+    for (int k = 0; k < 8; ++k) c = (c & 1) ? (c >> 1) ^ poly : (c >> 1);
+    g_crc_table[0][i] = c;
+  }
+  for (uint32_t i = 0; i < 256; ++i) {
+    uint32_t c = g_crc_table[0][i];
+    for (int t = 1; t < 8; ++t) {
+      c = g_crc_table[0][c & 0xff] ^ (c >> 8);
+      g_crc_table[t][i] = c;
+    }
+  }
+  g_crc_init = true;
+}
+
+static uint32_t crc32c_extend(uint32_t crc, const uint8_t* p, size_t n) {
+  crc_init();
+  uint32_t c = crc ^ 0xffffffffu;
+  while (n >= 8) {  // slicing-by-8
+    uint32_t lo, hi;
+    memcpy(&lo, p, 4);
+    memcpy(&hi, p + 4, 4);
+    lo ^= c;
+    c = g_crc_table[7][lo & 0xff] ^ g_crc_table[6][(lo >> 8) & 0xff] ^ g_crc_table[5][(lo >> 16) & 0xff] ^
+        g_crc_table[4][lo >> 24] ^ g_crc_table[3][hi & 0xff] ^ g_crc_table[2][(hi >> 8) & 0xff] ^
+        g_crc_table[1][(hi >> 16) & 0xff] ^ g_crc_table[0][hi >> 24];
+    p += 8;
+    n -= 8;
+  }
+  while (n--) c = g_crc_table[0][(c ^ *p++) & 0xff] ^ (c >> 8);
+  return c ^ 0xffffffffu;
+}
+
+static const uint32_t kMaskDelta = 0xa282ead8u;
+static inline uint32_t crc_mask(uint32_t crc) { return ((crc >> 15) | (crc << 17)) + kMaskDelta; }
+static inline uint32_t crc_unmask(uint32_t m) {
+  uint32_t rot = m - kMaskDelta;
+  return (rot >> 17) | (rot << 15);
+}
+
+// ------------------------------------------------------------------ coding
+static void put_fixed32(std::string* s, uint32_t v) {
+  char b[4] = {(char)(v & 0xff), (char)((v >> 8) & 0xff), (char)((v >> 16) & 0xff), (char)((v >> 24) & 0xff)};
+  s->append(b, 4);
+}
+static void put_fixed64(std::string* s, uint64_t v) {
+  put_fixed32(s, (uint32_t)v);
+  put_fixed32(s, (uint32_t)(v >> 32));
+}
+static uint32_t get_fixed32(const uint8_t* p) {
+  return (uint32_t)p[0] | ((uint32_t)p[1] << 8) | ((uint32_t)p[2] << 16) | ((uint32_t)p[3] << 24);
+}
+static uint64_t get_fixed64(const uint8_t* p) { return (uint64_t)get_fixed32(p) | ((uint64_t)get_fixed32(p + 4) << 32); }
+static void put_varint64(std::string* s, uint64_t v) {
+  while (v >= 0x80) {
+    s->push_back((char)((v & 0x7f) | 0x80));
+    v >>= 7;
+  }
+  s->push_back((char)v);
+}
+static void put_varint32(std::string* s, uint32_t v) { put_varint64(s, v); }
+// returns bytes consumed, 0 on error
+static size_t get_varint64(const uint8_t* p, const uint8_t* end, uint64_t* out) {
+  uint64_t r = 0;
+  int shift = 0;
+  const uint8_t* q = p;
+  while (q < end && shift <= 63) {
+    uint8_t b = *q++;
+    r |= (uint64_t)(b & 0x7f) << shift;
+    if (!(b & 0x80)) {
+      *out = r;
+      return (size_t)(q - p);
+    }
+    shift += 7;
+  }
+  return 0;
+}
+
+// ------------------------------------------------------------------ protobuf (minimal)
+static void pb_varint_field(std::string* s, int field, uint64_t v) {
+  put_varint32(s, (uint32_t)(field << 3) | 0);
+  put_varint64(s, v);
+}
+static void pb_bytes_field(std::string* s, int field, const std::string& v) {
+  put_varint32(s, (uint32_t)(field << 3) | 2);
+  put_varint64(s, v.size());
+  s->append(v);
+}
+static void pb_fixed32_field(std::string* s, int field, uint32_t v) {
+  put_varint32(s, (uint32_t)(field << 3) | 5);
+  put_fixed32(s, v);
+}
+
+struct Entry {
+  std::string name;
+  int dtype = 0;  // tensorflow.DataType
+  std::vector<int64_t> dims;
+  int shard_id = 0;
+  int64_t offset = 0;
+  int64_t size = 0;
+  uint32_t crc = 0;  // masked crc32c of the tensor bytes
+  bool has_slices = false;
+};
+
+static std::string encode_shape(const std::vector<int64_t>& dims) {
+  std::string shape;
+  for (int64_t d : dims) {
+    std::string dim;
+    pb_varint_field(&dim, 1, (uint64_t)d);  // Dim.size (proto3 omits 0, TF still reads it as 0)
+    if (d == 0) dim.clear();
+    pb_bytes_field(&shape, 2, dim);  // TensorShapeProto.dim
+  }
+  return shape;
+}
+
+static std::string encode_entry(const Entry& e) {
+  std::string s;
+  if (e.dtype) pb_varint_field(&s, 1, (uint64_t)e.dtype);
+  pb_bytes_field(&s, 2, encode_shape(e.dims));  // TF always emits the (possibly empty) shape message
+  if (e.shard_id) pb_varint_field(&s, 3, (uint64_t)e.shard_id);
+  if (e.offset) pb_varint_field(&s, 4, (uint64_t)e.offset);
+  if (e.size) pb_varint_field(&s, 5, (uint64_t)e.size);
+  if (e.crc) pb_fixed32_field(&s, 6, e.crc);
+  return s;
+}
+
+static std::string encode_header(int num_shards) {
+  std::string s;
+  pb_varint_field(&s, 1, (uint64_t)num_shards);  // num_shards
+  // endianness LITTLE = 0 (default, omitted)
+  std::string ver;
+  pb_varint_field(&ver, 1, 1);  // VersionDef.producer = kTensorBundleVersion (1)
+  pb_bytes_field(&s, 3, ver);
+  return s;
+}
+
+struct PbReader {
+  const uint8_t* p;
+  const uint8_t* end;
+  bool ok = true;
+  bool next(int* field, int* wt) {
+    if (p >= end) return false;
+    uint64_t tag;
+    size_t n = get_varint64(p, end, &tag);
+    if (!n) { ok = false; return false; }
+    p += n;
+    *field = (int)(tag >> 3);
+    *wt = (int)(tag & 7);
+    return true;
+  }
+  uint64_t varint() {
+    uint64_t v = 0;
+    size_t n = get_varint64(p, end, &v);
+    if (!n) { ok = false; p = end; return 0; }
+    p += n;
+    return v;
+  }
+  bool bytes(const uint8_t** b, size_t* len) {
+    uint64_t l = varint();
+    if (!ok || l > (uint64_t)(end - p)) { ok = false; p = end; return false; }
+    *b = p;
+    *len = (size_t)l;
+    p += l;
+    return true;
+  }
+  void skip(int wt) {
+    if (wt == 0) varint();
+    else if (wt == 1) { if (end - p < 8) { ok = false; p = end; } else p += 8; }
+    else if (wt == 2) { const uint8_t* b; size_t l; bytes(&b, &l); }
+    else if (wt == 5) { if (end - p < 4) { ok = false; p = end; } else p += 4; }
+    else { ok = false; p = end; }
+  }
+};
+
+static bool decode_shape(const uint8_t* b, size_t len, std::vector<int64_t>* dims) {
+  PbReader r{b, b + len};
+  int f, wt;
+  while (r.next(&f, &wt)) {
+    if (f == 2 && wt == 2) {
+      const uint8_t* db; size_t dl;
+      if (!r.bytes(&db, &dl)) return false;
+      PbReader d{db, db + dl};
+      int64_t size = 0;
+      int f2, wt2;
+      while (d.next(&f2, &wt2)) {
+        if (f2 == 1 && wt2 == 0) size = (int64_t)d.varint();
+        else d.skip(wt2);
+      }
+      if (!d.ok) return false;
+      dims->push_back(size);
+    } else {
+      r.skip(wt);
+    }
+  }
+  return r.ok;
+}
+
+static bool decode_entry(const uint8_t* b, size_t len, Entry* e) {
+  PbReader r{b, b + len};
+  int f, wt;
+  while (r.next(&f, &wt)) {
+    if (f == 1 && wt == 0) e->dtype = (int)r.varint();
+    else if (f == 2 && wt == 2) {
+      const uint8_t* sb; size_t sl;
+      if (!r.bytes(&sb, &sl) || !decode_shape(sb, sl, &e->dims)) return false;
+    } else if (f == 3 && wt == 0) e->shard_id = (int)r.varint();
+    else if (f == 4 && wt == 0) e->offset = (int64_t)r.varint();
+    else if (f == 5 && wt == 0) e->size = (int64_t)r.varint();
+    else if (f == 6 && wt == 5) {
+      if (r.end - r.p < 4) return false;
+      e->crc = get_fixed32(r.p);
+      r.p += 4;
+    } else if (f == 7) { e->has_slices = true; r.skip(wt); }
+    else r.skip(wt);
+  }
+  return r.ok;
+}
+
+static bool decode_header(const uint8_t* b, size_t len, int* num_shards, int* endianness) {
+  PbReader r{b, b + len};
+  int f, wt;
+  *num_shards = 0;
+  *endianness = 0;
+  while (r.next(&f, &wt)) {
+    if (f == 1 && wt == 0) *num_shards = (int)r.varint();
+    else if (f == 2 && wt == 0) *endianness = (int)r.varint();
+    else r.skip(wt);
+  }
+  return r.ok;
+}
+
+// ------------------------------------------------------------------ SSTable writer
+static const uint64_t kTableMagic = 0xdb4775248b80fb57ull;
+static const int kRestartInterval = 16;
+
+class BlockBuilder {
+ public:
+  explicit BlockBuilder(int restart_interval) : interval_(restart_interval) { restarts_.push_back(0); }
+  void add(const std::string& key, const std::string& value) {
+    size_t shared = 0;
+    if (counter_ < interval_) {
+      size_t m = std::min(last_key_.size(), key.size());
+      while (shared < m && last_key_[shared] == key[shared]) ++shared;
+    } else {
+      restarts_.push_back((uint32_t)buf_.size());
+      counter_ = 0;
+    }
+    put_varint32(&buf_, (uint32_t)shared);
+    put_varint32(&buf_, (uint32_t)(key.size() - shared));
+    put_varint32(&buf_, (uint32_t)value.size());
+    buf_.append(key, shared, std::string::npos);
+    buf_.append(value);
+    last_key_ = key;
+    ++counter_;
+  }
+  std::string finish() {
+    for (uint32_t r : restarts_) put_fixed32(&buf_, r);
+    put_fixed32(&buf_, (uint32_t)restarts_.size());
+    return buf_;
+  }
+  bool empty() const { return buf_.empty(); }
+  size_t size_estimate() const { return buf_.size() + restarts_.size() * 4 + 4; }
+  const std::string& last_key() const { return last_key_; }
+
+ private:
+  int interval_;
+  int counter_ = 0;
+  std::string buf_, last_key_;
+  std::vector<uint32_t> restarts_;
+};
+
+static std::string encode_handle(uint64_t off, uint64_t size) {
+  std::string s;
+  put_varint64(&s, off);
+  put_varint64(&s, size);
+  return s;
+}
+
+// shortest string >= key (LevelDB BytewiseComparator::FindShortSuccessor)
+static std::string short_successor(const std::string& key) {
+  for (size_t i = 0; i < key.size(); ++i) {
+    uint8_t b = (uint8_t)key[i];
+    if (b != 0xff) {
+      std::string r = key.substr(0, i + 1);
+      r[i] = (char)(b + 1);
+      return r;
+    }
+  }
+  return key;
+}
+// LevelDB FindShortestSeparator(start, limit)
+static std::string shortest_separator(const std::string& start, const std::string& limit) {
+  size_t m = std::min(start.size(), limit.size()), d = 0;
+  while (d < m && start[d] == limit[d]) ++d;
+  if (d < m) {
+    uint8_t b = (uint8_t)start[d];
+    if (b < 0xff && b + 1 < (uint8_t)limit[d]) {
+      std::string r = start.substr(0, d + 1);
+      r[d] = (char)(b + 1);
+      return r;
+    }
+  }
+  return start;
+}
+
+static void append_block(std::string* file, const std::string& contents, uint64_t* off, uint64_t* size) {
+  *off = file->size();
+  *size = contents.size();
+  file->append(contents);
+  char type = 0;  // kNoCompression
+  uint32_t crc = crc32c_extend(0, (const uint8_t*)contents.data(), contents.size());
+  crc = crc32c_extend(crc, (const uint8_t*)&type, 1);
+  file->push_back(type);
+  put_fixed32(file, crc_mask(crc));
+}
+
+// keys must be added in sorted order
+static std::string build_table(const std::vector<std::pair<std::string, std::string>>& kv, size_t block_size) {
+  std::string file;
+  BlockBuilder index(1);
+  std::unique_ptr<BlockBuilder> data(new BlockBuilder(kRestartInterval));
+  std::string pending_last_key;
+  uint64_t pending_off = 0, pending_size = 0;
+  bool pending = false;
+  for (size_t i = 0; i < kv.size(); ++i) {
+    if (pending) {
+      index.add(shortest_separator(pending_last_key, kv[i].first), encode_handle(pending_off, pending_size));
+      pending = false;
+    }
+    data->add(kv[i].first, kv[i].second);
+    if (data->size_estimate() >= block_size) {
+      pending_last_key = data->last_key();
+      append_block(&file, data->finish(), &pending_off, &pending_size);
+      data.reset(new BlockBuilder(kRestartInterval));
+      pending = true;
+    }
+  }
+  if (!data->empty()) {
+    if (pending) {  // cannot happen (pending is flushed before each add) but keep the invariant explicit
+      index.add(short_successor(pending_last_key), encode_handle(pending_off, pending_size));
+      pending = false;
+    }
+    pending_last_key = data->last_key();
+    append_block(&file, data->finish(), &pending_off, &pending_size);
+    pending = true;
+  }
+  if (pending) index.add(short_successor(pending_last_key), encode_handle(pending_off, pending_size));
+  uint64_t meta_off, meta_size, idx_off, idx_size;
+  BlockBuilder meta(kRestartInterval);
+  append_block(&file, meta.finish(), &meta_off, &meta_size);
+  append_block(&file, index.finish(), &idx_off, &idx_size);
+  std::string footer = encode_handle(meta_off, meta_size) + encode_handle(idx_off, idx_size);
+  footer.resize(40, '\0');
+  put_fixed64(&footer, kTableMagic);
+  file.append(footer);
+  return file;
+}
+
+// ------------------------------------------------------------------ SSTable reader
+static bool read_file(const std::string& path, std::string* out) {
+  FILE* f = fopen(path.c_str(), "rb");
+  if (!f) return false;
+  fseek(f, 0, SEEK_END);
+  long n = ftell(f);
+  fseek(f, 0, SEEK_SET);
+  out->resize((size_t)n);
+  size_t got = n ? fread(&(*out)[0], 1, (size_t)n, f) : 0;
+  fclose(f);
+  return got == (size_t)n;
+}
+
+static bool read_block(const std::string& file, uint64_t off, uint64_t size, std::string* contents,
+                       std::string* err) {
+  if (off + size + 5 > file.size()) { *err = "block handle out of range"; return false; }
+  const uint8_t* p = (const uint8_t*)file.data() + off;
+  uint8_t type = p[size];
+  uint32_t want = crc_unmask(get_fixed32(p + size + 1));
+  uint32_t got = crc32c_extend(0, p, size + 1);
+  if (want != got) { *err = "block checksum mismatch"; return false; }
+  if (type != 0) { *err = "compressed table blocks are not supported (TF writes bundles uncompressed)"; return false; }
+  contents->assign((const char*)p, size);
+  return true;
+}
+
+static bool parse_block(const std::string& b, std::vector<std::pair<std::string, std::string>>* out,
+                        std::string* err) {
+  if (b.size() < 4) { *err = "block too small"; return false; }
+  uint32_t nrestart = get_fixed32((const uint8_t*)b.data() + b.size() - 4);
+  if ((uint64_t)nrestart * 4 + 4 > b.size()) { *err = "bad restart count"; return false; }
+  const uint8_t* p = (const uint8_t*)b.data();
+  const uint8_t* end = p + b.size() - 4 - (size_t)nrestart * 4;
+  std::string key;
+  while (p < end) {
+    uint64_t shared, non_shared, vlen;
+    size_t n;
+    if (!(n = get_varint64(p, end, &shared))) { *err = "bad entry"; return false; }
+    p += n;
+    if (!(n = get_varint64(p, end, &non_shared))) { *err = "bad entry"; return false; }
+    p += n;
+    if (!(n = get_varint64(p, end, &vlen))) { *err = "bad entry"; return false; }
+    p += n;
+    if (shared > key.size() || non_shared + vlen > (uint64_t)(end - p)) { *err = "bad entry lengths"; return false; }
+    key.resize((size_t)shared);
+    key.append((const char*)p, (size_t)non_shared);
+    p += non_shared;
+    out->emplace_back(key, std::string((const char*)p, (size_t)vlen));
+    p += vlen;
+  }
+  return true;
+}
+
+static bool read_table(const std::string& file, std::vector<std::pair<std::string, std::string>>* kv,
+                       std::string* err) {
+  if (file.size() < 48) { *err = "index file too small for an sstable footer"; return false; }
+  const uint8_t* foot = (const uint8_t*)file.data() + file.size() - 48;
+  if (get_fixed64(foot + 40) != kTableMagic) { *err = "bad sstable magic (not a V2 checkpoint index?)"; return false; }
+  uint64_t meta_off, meta_size, idx_off, idx_size;
+  const uint8_t* p = foot;
+  const uint8_t* end = foot + 40;
+  size_t n;
+  if (!(n = get_varint64(p, end, &meta_off))) { *err = "bad footer"; return false; }
+  p += n;
+  if (!(n = get_varint64(p, end, &meta_size))) { *err = "bad footer"; return false; }
+  p += n;
+  if (!(n = get_varint64(p, end, &idx_off))) { *err = "bad footer"; return false; }
+  p += n;
+  if (!(n = get_varint64(p, end, &idx_size))) { *err = "bad footer"; return false; }
+  std::string idx;
+  if (!read_block(file, idx_off, idx_size, &idx, err)) return false;
+  std::vector<std::pair<std::string, std::string>> handles;
+  if (!parse_block(idx, &handles, err)) return false;
+  for (auto& h : handles) {
+    uint64_t off, size;
+    const uint8_t* hp = (const uint8_t*)h.second.data();
+    const uint8_t* he = hp + h.second.size();
+    if (!(n = get_varint64(hp, he, &off))) { *err = "bad block handle"; return false; }
+    hp += n;
+    if (!(n = get_varint64(hp, he, &size))) { *err = "bad block handle"; return false; }
+    std::string blk;
+    if (!read_block(file, off, size, &blk, err)) return false;
+    if (!parse_block(blk, kv, err)) return false;
+  }
+  return true;
+}
+
+// ------------------------------------------------------------------ bundle writer / reader
+static std::string shard_name(const std::string& prefix, int shard, int num_shards) {
+  char buf[64];
+  snprintf(buf, sizeof buf, ".data-%05d-of-%05d", shard, num_shards);
+  return prefix + buf;
+}
+
+static bool write_file_atomic(const std::string& path, const std::string& data, std::string* err) {
+  std::string tmp = path + ".tempstate";
+  FILE* f = fopen(tmp.c_str(), "wb");
+  if (!f) { *err = "cannot open " + tmp; return false; }
+  bool ok = data.empty() || fwrite(data.data(), 1, data.size(), f) == data.size();
+  ok = (fclose(f) == 0) && ok;
+  if (!ok) { *err = "short write to " + tmp; return false; }
+  if (rename(tmp.c_str(), path.c_str()) != 0) { *err = "rename failed for " + path; return false; }
+  return true;
+}
+
+struct Writer {
+  std::string prefix;
+  std::map<std::string, Entry> entries;  // sorted by name
+  std::map<std::string, std::string> payload;
+  std::string err;
+};
+
+struct Reader {
+  std::string prefix;
+  int num_shards = 1;
+  std::vector<Entry> entries;  // sorted
+  std::string err;
+};
+
+}  // namespace dtfckpt
+
+using namespace dtfckpt;
+
+extern "C" {
+
+uint32_t dtf_crc32c(const void* data, size_t n) { return crc32c_extend(0, (const uint8_t*)data, n); }
+uint32_t dtf_crc32c_mask(uint32_t crc) { return crc_mask(crc); }
+uint32_t dtf_crc32c_unmask(uint32_t crc) { return crc_unmask(crc); }
+
+void* dtf_ckpt_writer_new(const char* prefix) {
+  Writer* w = new Writer();
+  w->prefix = prefix;
+  return w;
+}
+
+// dtype is a tensorflow.DataType enum value (DT_FLOAT = 1, DT_INT32 = 3, DT_INT64 = 9, ...)
+int dtf_ckpt_writer_add(void* wp, const char* name, int dtype, int ndim, const int64_t* dims, const void* data,
+                        int64_t nbytes) {
+  Writer* w = (Writer*)wp;
+  if (!*name) { w->err = "empty tensor name is reserved for the bundle header"; return -1; }
+  if (w->entries.count(name)) { w->err = std::string("duplicate tensor ") + name; return -1; }
+  Entry e;
+  e.name = name;
+  e.dtype = dtype;
+  e.dims.assign(dims, dims + ndim);
+  e.size = nbytes;
+  w->entries[name] = e;
+  w->payload[name].assign((const char*)data, (size_t)nbytes);
+  return 0;
+}
+
+int dtf_ckpt_writer_finish(void* wp) {
+  Writer* w = (Writer*)wp;
+  std::string data;
+  std::vector<std::pair<std::string, std::string>> kv;
+  kv.emplace_back("", encode_header(1));
+  for (auto& it : w->entries) {  // std::map iterates in bytewise key order, as the table requires
+    Entry& e = it.second;
+    const std::string& bytes = w->payload[it.first];
+    e.offset = (int64_t)data.size();
+    e.crc = crc_mask(crc32c_extend(0, (const uint8_t*)bytes.data(), bytes.size()));
+    data.append(bytes);
+    kv.emplace_back(e.name, encode_entry(e));
+  }
+  if (!write_file_atomic(shard_name(w->prefix, 0, 1), data, &w->err)) return -1;
+  if (!write_file_atomic(w->prefix + ".index", build_table(kv, 262144), &w->err)) return -1;
+  return 0;
+}
+
+const char* dtf_ckpt_writer_error(void* wp) { return ((Writer*)wp)->err.c_str(); }
+void dtf_ckpt_writer_free(void* wp) { delete (Writer*)wp; }
+
+void* dtf_ckpt_reader_open(const char* prefix) {
+  Reader* r = new Reader();
+  r->prefix = prefix;
+  std::string file;
+  if (!read_file(r->prefix + ".index", &file)) {
+    r->err = "cannot read " + r->prefix + ".index";
+    return r;
+  }
+  std::vector<std::pair<std::string, std::string>> kv;
+  if (!read_table(file, &kv, &r->err)) return r;
+  bool have_header = false;
+  for (auto& e : kv) {
+    if (e.first.empty()) {
+      int endian = 0;
+      if (!decode_header((const uint8_t*)e.second.data(), e.second.size(), &r->num_shards, &endian)) {
+        r->err = "bad BundleHeaderProto";
+        return r;
+      }
+      if (endian != 0) { r->err = "big-endian bundles are not supported"; return r; }
+      have_header = true;
+      continue;
+    }
+    Entry en;
+    en.name = e.first;
+    if (!decode_entry((const uint8_t*)e.second.data(), e.second.size(), &en)) {
+      r->err = "bad BundleEntryProto for " + e.first;
+      return r;
+    }
+    r->entries.push_back(en);
+  }
+  if (!have_header) r->err = "bundle header (empty key) missing";
+  return r;
+}
+
+const char* dtf_ckpt_reader_error(void* rp) { return ((Reader*)rp)->err.c_str(); }
+int dtf_ckpt_reader_num(void* rp) { return (int)((Reader*)rp)->entries.size(); }
+int dtf_ckpt_reader_num_shards(void* rp) { return ((Reader*)rp)->num_shards; }
+
+// Fills name (up to name_cap), dtype, ndim, dims (up to 8), nbytes.  Returns 0 on success.
+int dtf_ckpt_reader_entry(void* rp, int i, char* name, int name_cap, int* dtype, int* ndim, int64_t* dims,
+                          int64_t* nbytes, int* sliced) {
+  Reader* r = (Reader*)rp;
+  if (i < 0 || i >= (int)r->entries.size()) return -1;
+  const Entry& e = r->entries[i];
+  snprintf(name, (size_t)name_cap, "%s", e.name.c_str());
+  *dtype = e.dtype;
+  *ndim = (int)e.dims.size();
+  for (size_t k = 0; k < e.dims.size() && k < 8; ++k) dims[k] = e.dims[k];
+  *nbytes = e.size;
+  *sliced = e.has_slices ? 1 : 0;
+  return 0;
+}
+
+// Reads tensor i into dst (nbytes must equal the entry size); verifies the crc32c.
+int dtf_ckpt_reader_read(void* rp, int i, void* dst, int64_t nbytes) {
+  Reader* r = (Reader*)rp;
+  if (i < 0 || i >= (int)r->entries.size()) return -1;
+  const Entry& e = r->entries[i];
+  if (nbytes != e.size) { r->err = "size mismatch for " + e.name; return -1; }
+  std::string path = shard_name(r->prefix, e.shard_id, r->num_shards);
+  FILE* f = fopen(path.c_str(), "rb");
+  if (!f) { r->err = "cannot open " + path; return -1; }
+  bool ok = fseek(f, (long)e.offset, SEEK_SET) == 0 &&
+            (nbytes == 0 || fread(dst, 1, (size_t)nbytes, f) == (size_t)nbytes);
+  fclose(f);
+  if (!ok) { r->err = "short read from " + path; return -1; }
+  uint32_t got = crc32c_extend(0, (const uint8_t*)dst, (size_t)nbytes);
+  if (e.crc != 0 && crc_unmask(e.crc) != got) { r->err = "tensor checksum mismatch for " + e.name; return -2; }
+  return 0;
+}
+
+void dtf_ckpt_reader_free(void* rp) { delete (Reader*)rp; }
+
+}  // extern "C"
