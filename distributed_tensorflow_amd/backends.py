@@ -1,0 +1,222 @@
+"""Compute backends behind one small interface, so the trainer / supervisor / parallel
+strategies are identical for the MI355X engine and the CPU oracle.
+
+  HipBackend  hand-written gfx950 kernels on an HBM-resident dataset (engine.HipEngine)
+  CpuBackend  fp32 PyTorch oracle + TF-style ``next_batch`` input pipeline; this is what the
+              "1 ps + 2 workers on localhost CPU" plumbing configuration runs on (gloo)
+
+Both expose the model state as ONE flat fp32 parameter tensor and ONE flat gradient tensor
+(models.spec.ArenaLayout), which is what the collectives move.
+"""
+from __future__ import annotations
+
+from typing import Dict, Optional, Tuple
+
+import numpy as np
+import torch
+
+from .data.mnist import Datasets
+from .models.oracle import OracleModel
+from .models.spec import ArenaLayout, ModelSpec
+
+
+class Backend:
+    name = "abstract"
+    spec: ModelSpec
+    layout: ArenaLayout
+    batch: int
+
+    # flat state -----------------------------------------------------------
+    @property
+    def params(self) -> torch.Tensor: raise NotImplementedError
+    @property
+    def grads(self) -> torch.Tensor: raise NotImplementedError
+    def params_changed(self): pass
+    # step pieces ----------------------------------------------------------
+    def compute_gradients(self): raise NotImplementedError
+    def apply_gradients(self, scale: float = 1.0, step_inc: int = 1): raise NotImplementedError
+    def last_metrics(self) -> Tuple[float, float]: raise NotImplementedError
+    def evaluate(self, split: str = "test") -> Tuple[float, float]: raise NotImplementedError
+    def synchronize(self): pass
+    # state I/O ------------------------------------------------------------
+    def get_global_step(self) -> int: raise NotImplementedError
+    def set_global_step(self, v: int): raise NotImplementedError
+    def init_params(self, seed: int): raise NotImplementedError
+
+    def export_params(self) -> Dict[str, np.ndarray]:
+        flat = self.params.detach().cpu()
+        return {n: self.layout.view(flat, n).numpy().copy() for n in self.layout.names()}
+
+    def load_params(self, tensors: Dict[str, np.ndarray]):
+        flat = torch.zeros(self.layout.total, dtype=torch.float32)
+        for n in self.layout.names():
+            self.layout.view(flat, n).copy_(torch.as_tensor(np.asarray(tensors[n], dtype=np.float32)))
+        self.params.copy_(flat.to(self.params.device))
+        self.params_changed()
+
+    def export_optimizer_state(self) -> Optional[dict]: return None
+    def load_optimizer_state(self, state: dict): pass
+
+
+class CpuBackend(Backend):
+    name = "cpu"
+
+    def __init__(self, spec: ModelSpec, batch: int, data: Datasets, optimizer="sgd", learning_rate=1e-3,
+                 keep_prob=1.0, seed=0):
+        self.spec, self.batch, self.data = spec, batch, data
+        self.model = OracleModel(spec, device="cpu", seed=seed, optimizer=optimizer, learning_rate=learning_rate,
+                                 keep_prob=keep_prob)
+        self.layout = self.model.layout
+        self._metrics = (float("nan"), float("nan"))
+
+    params = property(lambda self: self.model.arena)
+    grads = property(lambda self: self.model.grad_arena)
+
+    def init_params(self, seed: int):
+        self.model.gen.manual_seed(seed)
+        self.model.init_params()
+
+    def compute_gradients(self):
+        x, y = self.data.train.next_batch(self.batch)     # reference M:178
+        self._metrics = self.model.compute_gradients(torch.from_numpy(np.ascontiguousarray(x)),
+                                                     torch.from_numpy(np.ascontiguousarray(y)))
+
+    def apply_gradients(self, scale: float = 1.0, step_inc: int = 1):
+        self.model.apply_gradients(scale=scale, step_inc=step_inc)
+
+    def last_metrics(self):
+        return self._metrics
+
+    def evaluate(self, split: str = "test"):
+        ds = getattr(self.data, split)
+        tot_l = tot_a = 0.0
+        n = ds.num_examples
+        for lo in range(0, n, 1000):
+            x = torch.from_numpy(ds.images[lo:lo + 1000])
+            y = torch.from_numpy(np.ascontiguousarray(ds.labels[lo:lo + 1000]))
+            l, a = self.model.loss_and_accuracy(x, y)
+            tot_l += float(l) * x.shape[0]
+            tot_a += float(a) * x.shape[0]
+        return tot_l / n, tot_a / n
+
+    def get_global_step(self): return self.model.global_step
+    def set_global_step(self, v): self.model.global_step = int(v)
+
+    def export_optimizer_state(self):
+        m = self.model
+        if m.optimizer != "adam" or m._adam_m is None:
+            return None
+        return {"m": {n: self.layout.view(m._adam_m, n).numpy().copy() for n in self.layout.names()},
+                "v": {n: self.layout.view(m._adam_v, n).numpy().copy() for n in self.layout.names()},
+                "t": m._adam_t}
+
+    def load_optimizer_state(self, state):
+        m = self.model
+        if m.optimizer != "adam" or not state:
+            return
+        m._adam_m = torch.zeros_like(m.arena)
+        m._adam_v = torch.zeros_like(m.arena)
+        for n in self.layout.names():
+            self.layout.view(m._adam_m, n).copy_(torch.as_tensor(state["m"][n]))
+            self.layout.view(m._adam_v, n).copy_(torch.as_tensor(state["v"][n]))
+        m._adam_t = int(state.get("t", 0))
+
+
+class HipBackend(Backend):
+    name = "hip"
+
+    def __init__(self, spec: ModelSpec, batch: int, data: Datasets, optimizer="sgd", learning_rate=1e-3,
+                 keep_prob=1.0, seed=0, device="cuda", use_graph=True):
+        from .engine import DeviceDataset, HipEngine
+        self.spec, self.batch, self.data = spec, batch, data
+        tr = data.train
+        self.train_ds = DeviceDataset.from_float(torch.from_numpy(tr.images), torch.from_numpy(tr.int_labels), device)
+        self._eval_cache = {}
+        self.engine = HipEngine(spec, batch, self.train_ds, optimizer=optimizer, learning_rate=learning_rate,
+                                keep_prob=keep_prob, seed=seed, device=device)
+        self.layout = self.engine.layout
+        self.use_graph = use_graph
+        self._host_step = 0
+
+    params = property(lambda self: self.engine.params)
+    grads = property(lambda self: self.engine.grads)
+
+    def init_params(self, seed: int):
+        self.engine.init_params(seed)
+
+    def params_changed(self):
+        self.engine.refresh_shadows()
+
+    def compute_gradients(self):
+        e, ds = self.engine, self.train_ds
+        e.launch_sample()
+        e.launch_forward(ds.images, ds.labels, e.idx, backward=True)
+        e.launch_backward_dense()
+        e.launch_backward_conv(ds.images, e.idx)
+
+    def apply_gradients(self, scale: float = 1.0, step_inc: int = 1):
+        e = self.engine
+        if scale != getattr(self, "_scale", None):
+            e.set_grad_scale(scale)
+            self._scale = scale
+        e.step_inc = step_inc
+        e.launch_update()
+        self._host_step += step_inc
+
+    def train_step_local(self):
+        """Fused single-GPU step (HIP-graph replay when enabled)."""
+        e = self.engine
+        if self.use_graph and e._graph is None:
+            e.capture()
+        e.train_step()
+        self._host_step += e.step_inc
+
+    def last_metrics(self):
+        return self.engine.last_metrics()
+
+    def evaluate(self, split: str = "test"):
+        from .engine import DeviceDataset
+        if split not in self._eval_cache:
+            ds = getattr(self.data, split)
+            self._eval_cache[split] = DeviceDataset.from_float(torch.from_numpy(ds.images),
+                                                               torch.from_numpy(ds.int_labels), self.engine.device)
+        d = self._eval_cache[split]
+        return self.engine.evaluate(d.images, d.labels)
+
+    def synchronize(self):
+        torch.cuda.synchronize(self.engine.device)
+
+    def get_global_step(self): return self.engine.global_step
+    def set_global_step(self, v):
+        self.engine.set_global_step(v)
+        self._host_step = int(v)
+
+    def export_optimizer_state(self):
+        e = self.engine
+        if e.optimizer != "adam":
+            return None
+        m, v = e.adam_m.detach().cpu(), e.adam_v.detach().cpu()
+        return {"m": {n: self.layout.view(m, n).numpy().copy() for n in self.layout.names()},
+                "v": {n: self.layout.view(v, n).numpy().copy() for n in self.layout.names()},
+                "t": int(e.state[e.STATE_ADAM_T].item())}
+
+    def load_optimizer_state(self, state):
+        e = self.engine
+        if e.optimizer != "adam" or not state:
+            return
+        for n in self.layout.names():
+            self.layout.view(e.adam_m, n).copy_(torch.as_tensor(state["m"][n]).to(e.device))
+            self.layout.view(e.adam_v, n).copy_(torch.as_tensor(state["v"][n]).to(e.device))
+        e.state[e.STATE_ADAM_T] = int(state.get("t", 0))
+
+
+def make_backend(kind: str, spec: ModelSpec, batch: int, data: Datasets, **kw) -> Backend:
+    if kind == "auto":
+        kind = "hip" if torch.cuda.is_available() else "cpu"
+    if kind == "hip":
+        return HipBackend(spec, batch, data, **kw)
+    if kind == "cpu":
+        kw.pop("device", None)
+        kw.pop("use_graph", None)
+        return CpuBackend(spec, batch, data, **kw)
+    raise ValueError(f"unknown backend {kind!r}")

@@ -1,0 +1,315 @@
+"""Distribution strategies: how one optimisation step crosses process boundaries.
+
+Reference behaviour being replaced/emulated (reference .idea/MNISTDist.py:98-111, :173-188):
+between-graph replication where every worker pulls all variables from the ps tasks and pushes
+all gradients back each step, the ps applying them with no locking (asynchronous, stale
+gradients); variables are sharded whole-tensor round-robin over ps tasks; the shared
+``global_step`` counts applied worker gradients.
+
+Strategies (all work on the backend's flat fp32 param / grad tensors):
+  LocalStrategy        single process.
+  SyncAllReduce        synchronous DP: all-reduce(mean) of the gradient arena among workers
+                       (RCCL; overlapped with backward on the GPU backend, see sync_dp.py).
+                       ps tasks, if any, only idle until the workers finish.
+  AsyncP2P             true asynchronous parameter server over point-to-point send/recv:
+                       each ps task owns its round-robin shard of the variables, applies every
+                       worker gradient the moment it arrives (arrival order, no barrier) and
+                       returns fresh parameters; tolerates dying workers.
+  AsyncRounds          parameter-server semantics on collectives (reduce to the ps rank, apply,
+                       RCCL broadcast of the parameters), with a staleness bound of 0 or 1 round:
+                       gradients are applied un-averaged and global_step advances by the number
+                       of workers per round.  This is the GPU-friendly emulation (few large
+                       collectives instead of many p2p messages).
+"""
+from __future__ import annotations
+
+import time
+from typing import Dict, List, Optional, Tuple
+
+import torch
+import torch.distributed as dist
+
+from ..backends import Backend
+from ..cluster import TaskInfo, replica_device_setter
+from ..models.spec import TF_VARIABLE_NAMES
+
+KIND_GRAD, KIND_PULL, KIND_BYE = 0.0, 1.0, 2.0
+
+
+def _creation_order() -> List[str]:
+    return [k for k in TF_VARIABLE_NAMES]  # wc1, wc2, wd1, out_w, bc1, bc2, bd1, out_b, global_step
+
+
+def ps_shards(task: TaskInfo, backend: Backend) -> Tuple[Dict[int, List[Tuple[int, int]]], int]:
+    """ps task -> list of [lo, hi) arena ranges it owns; and the ps task owning global_step."""
+    placement = replica_device_setter(task.cluster, _creation_order())
+    shards: Dict[int, List[Tuple[int, int]]] = {p: [] for p in range(max(1, task.num_ps))}
+    for name, p in placement.items():
+        if name == "global_step":
+            continue
+        lo = backend.layout.offsets[name]
+        shards[p].append((lo, lo + backend.layout.sizes[name]))
+    for p in shards:
+        shards[p].sort()
+    return shards, placement["global_step"]
+
+
+def _gather(flat: torch.Tensor, ranges, out: torch.Tensor):
+    o = 0
+    for lo, hi in ranges:
+        out[o:o + hi - lo].copy_(flat[lo:hi])
+        o += hi - lo
+
+
+def _scatter(src: torch.Tensor, ranges, flat: torch.Tensor):
+    o = 0
+    for lo, hi in ranges:
+        flat[lo:hi].copy_(src[o:o + hi - lo])
+        o += hi - lo
+
+
+def _set_int(t: torch.Tensor, i: int, v: int):
+    t[i:i + 1].view(torch.int32)[0] = int(v)
+
+
+def _get_int(t: torch.Tensor, i: int) -> int:
+    return int(t[i:i + 1].view(torch.int32)[0].item())
+
+
+class LocalStrategy:
+    name = "local"
+
+    def __init__(self, backend: Backend):
+        self.b = backend
+        self.step_count = backend.get_global_step()
+
+    def broadcast_initial(self):
+        self.step_count = self.b.get_global_step()   # the supervisor may just have restored a checkpoint
+
+    def step(self) -> int:
+        if hasattr(self.b, "train_step_local"):
+            self.b.train_step_local()
+        else:
+            self.b.compute_gradients()
+            self.b.apply_gradients()
+        self.step_count += 1
+        return self.step_count
+
+    def finish(self):
+        pass
+
+
+class SyncAllReduce:
+    """Synchronous data parallelism among the worker ranks."""
+
+    name = "sync"
+
+    def __init__(self, backend: Backend, task: TaskInfo, worker_group, chief_rank: int):
+        self.b, self.task, self.group, self.chief_rank = backend, task, worker_group, chief_rank
+        self.world = task.num_workers
+        self.step_count = backend.get_global_step()
+        self._dp = None
+        if backend.name == "hip" and dist.get_backend(worker_group) != "gloo":
+            from .sync_dp import SyncDataParallel
+            self._dp = SyncDataParallel(backend.engine, group=worker_group)
+
+    def broadcast_initial(self):
+        broadcast_state(self.b, self.chief_rank)
+        self.step_count = self.b.get_global_step()
+
+    def step(self) -> int:
+        if self._dp is not None:
+            self._dp.train_step()
+        else:
+            self.b.compute_gradients()
+            dist.all_reduce(self.b.grads, op=dist.ReduceOp.SUM, group=self.group)
+            self.b.apply_gradients(scale=1.0 / self.world)
+        self.step_count += 1
+        return self.step_count
+
+    def finish(self):
+        pass
+
+
+def broadcast_state(backend: Backend, src_rank: int, group=None):
+    """Chief -> everyone: parameters + global_step (reference: chief runs init_op / restore while
+    the other tasks wait for the variables to be initialised)."""
+    dist.broadcast(backend.params, src=src_rank, group=group)
+    dev = backend.params.device
+    st = torch.tensor([backend.get_global_step()], dtype=torch.int64, device=dev)
+    dist.broadcast(st, src=src_rank, group=group)
+    backend.set_global_step(int(st.item()))
+    backend.params_changed()
+
+
+# ----------------------------------------------------------------------------- async, p2p
+class AsyncP2PWorker:
+    name = "async-p2p"
+
+    def __init__(self, backend: Backend, task: TaskInfo, chief_rank: int):
+        self.b, self.task, self.chief_rank = backend, task, chief_rank
+        self.shards, self.step_owner = ps_shards(task, backend)
+        dev = backend.params.device
+        self.msg = {p: torch.zeros(sum(h - l for l, h in r) + 2, dtype=torch.float32, device=dev)
+                    for p, r in self.shards.items()}
+        self.resp = {p: torch.zeros_like(m) for p, m in self.msg.items()}
+        self.step_count = backend.get_global_step()
+        self.stop = False
+
+    def broadcast_initial(self):
+        broadcast_state(self.b, self.chief_rank)
+        self.step_count = self.b.get_global_step()
+
+    def _exchange(self, kind: float):
+        b = self.b
+        for p, ranges in self.shards.items():          # push to every ps task ...
+            m = self.msg[p]
+            n = m.numel() - 2
+            if kind == KIND_GRAD:
+                _gather(b.grads, ranges, m)
+            m[n] = kind
+            dist.send(m, dst=p)
+        if kind == KIND_BYE:
+            return
+        for p, ranges in self.shards.items():          # ... and pull the fresh shard back
+            r = self.resp[p]
+            n = r.numel() - 2
+            dist.recv(r, src=p)
+            _scatter(r, ranges, b.params)
+            if p == self.step_owner:
+                self.step_count = _get_int(r, n)
+                self.stop = bool(_get_int(r, n + 1))
+        b.params_changed()
+        b.set_global_step(self.step_count)
+
+    def step(self) -> int:
+        self.b.compute_gradients()
+        self._exchange(KIND_GRAD)
+        return self.step_count
+
+    def finish(self):
+        self._exchange(KIND_BYE)
+
+
+class AsyncP2PServer:
+    """One ps task: owns a shard of the variables, applies gradients in arrival order."""
+
+    def __init__(self, backend: Backend, task: TaskInfo, chief_rank: int, training_iter: int, log=None):
+        self.b, self.task, self.chief_rank, self.training_iter = backend, task, chief_rank, training_iter
+        self.shards, self.step_owner = ps_shards(task, backend)
+        self.ranges = self.shards[task.task_index]
+        self.n = sum(h - l for l, h in self.ranges)
+        self.log = log or (lambda *a: None)
+        self.applied = 0
+        self.dropped: List[int] = []
+
+    def broadcast_initial(self):
+        broadcast_state(self.b, self.chief_rank)
+
+    def serve(self):
+        """One service thread per worker (blocking recv -> apply under a lock -> send), so a slow
+        or dead worker never stalls the others; gradients are applied in arrival order."""
+        import threading
+        b, n = self.b, self.n
+        dev = b.params.device
+        workers = self.task.cluster.worker_ranks()
+        lock = threading.Lock()
+        self._step = b.get_global_step()
+        b.grads.zero_()
+
+        def service(w: int):
+            buf = torch.zeros(n + 2, dtype=torch.float32, device=dev)
+            resp = torch.zeros(n + 2, dtype=torch.float32, device=dev)
+            while True:
+                try:
+                    dist.recv(buf, src=w)
+                    kind = float(buf[n].item())
+                    if kind == KIND_BYE:
+                        return
+                    with lock:
+                        if kind == KIND_GRAD and self._step < self.training_iter:
+                            _scatter(buf, self.ranges, b.grads)      # un-averaged apply, arrival order
+                            b.apply_gradients(scale=1.0, step_inc=1)
+                            self._step += 1
+                            self.applied += 1
+                        _gather(b.params, self.ranges, resp)
+                        _set_int(resp, n, self._step)
+                        _set_int(resp, n + 1, 1 if self._step >= self.training_iter else 0)
+                    dist.send(resp, dst=w)
+                except (RuntimeError, ValueError) as e:     # worker died: keep serving the others
+                    self.log(f"ps/{self.task.task_index}: worker rank {w} lost ({type(e).__name__}); continuing")
+                    self.dropped.append(w)
+                    return
+
+        threads = [threading.Thread(target=service, args=(w,), daemon=True) for w in workers]
+        for t in threads:
+            t.start()
+        for t in threads:
+            t.join()
+        b.set_global_step(self._step)
+        return self._step
+
+
+# ----------------------------------------------------------------------------- async, collectives
+class AsyncRounds:
+    """Parameter-server emulation with reduce + broadcast collectives (ps rank 0 owns the weights)."""
+
+    name = "async-rounds"
+
+    def __init__(self, backend: Backend, task: TaskInfo, chief_rank: int, staleness: int = 1):
+        if staleness not in (0, 1):
+            raise ValueError("staleness must be 0 or 1 rounds")
+        self.b, self.task, self.chief_rank, self.staleness = backend, task, chief_rank, staleness
+        self.ps_rank = 0
+        self.W = task.num_workers
+        self.step_count = backend.get_global_step()
+        self._recv = torch.zeros_like(backend.params)
+        self._send = torch.zeros_like(backend.grads)
+        self._pending = None
+
+    def broadcast_initial(self):
+        broadcast_state(self.b, self.chief_rank)
+        self.step_count = self.b.get_global_step()
+
+    # worker side -------------------------------------------------------------
+    def step(self) -> int:
+        b = self.b
+        b.compute_gradients()
+        self._send.copy_(b.grads)
+        if self._pending is not None:                 # parameters of the previous round land now
+            self._pending.wait()
+            b.params.copy_(self._recv)
+            b.params_changed()
+            self._pending = None
+        dist.reduce(self._send, dst=self.ps_rank, op=dist.ReduceOp.SUM)
+        if self.staleness == 0:
+            dist.broadcast(b.params, src=self.ps_rank)
+            b.params_changed()
+        else:
+            self._pending = dist.broadcast(self._recv, src=self.ps_rank, async_op=True)
+        self.step_count += self.W
+        b.set_global_step(self.step_count)
+        return self.step_count
+
+    def finish(self):
+        if self._pending is not None:
+            self._pending.wait()
+            self.b.params.copy_(self._recv)
+            self.b.params_changed()
+            self._pending = None
+
+    # ps side -----------------------------------------------------------------
+    def serve(self, training_iter: int) -> int:
+        b = self.b
+        step = b.get_global_step()
+        is_owner = self.task.task_index == 0
+        while step < training_iter:
+            b.grads.zero_()
+            dist.reduce(b.grads, dst=self.ps_rank, op=dist.ReduceOp.SUM)
+            if is_owner:
+                # W sequential un-averaged SGD applications == one application of the sum
+                b.apply_gradients(scale=1.0, step_inc=self.W)
+            dist.broadcast(b.params, src=self.ps_rank)
+            step += self.W
+        b.set_global_step(step)
+        return step

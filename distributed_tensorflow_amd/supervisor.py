@@ -1,0 +1,112 @@
+"""Supervisor: chief election, init-or-restore, timed checkpoints, stop coordination.
+
+Mirrors what ``tf.train.Supervisor(is_chief, logdir, init_op, saver, global_step,
+save_model_secs=600)`` + ``sv.managed_session`` / ``should_stop`` / ``stop`` give the reference
+(reference .idea/MNISTDist.py:159-173, :192):
+  * the chief (worker task 0) restores the newest checkpoint in ``logdir`` if there is one,
+    otherwise runs the initialiser; every other task waits for the chief's variables (here: a
+    broadcast from the chief),
+  * the chief saves ``logdir/model.ckpt-<global_step>`` every ``save_model_secs`` seconds
+    (TF-bundle files + ``checkpoint`` state file, newest 5 kept) and once more at stop,
+  * ``should_stop()`` turns true after ``request_stop()`` or when the managed block raises.
+Saves happen from the training thread between steps (never concurrently with an update), so a
+checkpoint is always a consistent snapshot.
+"""
+from __future__ import annotations
+
+import contextlib
+import os
+import time
+from typing import Callable, Optional
+
+from .backends import Backend
+from .checkpoint import Saver, from_tf_names, latest_checkpoint, to_tf_names
+
+
+class Supervisor:
+    def __init__(self, backend: Backend, is_chief: bool, logdir: Optional[str] = "/tmp/train_logs",
+                 save_model_secs: float = 600.0, saver: Optional[Saver] = None, init_seed: int = 0,
+                 checkpoint_basename: str = "model.ckpt", log: Callable[[str], None] = print,
+                 adam_betas=(0.9, 0.999)):
+        self.b = backend
+        self.is_chief = is_chief
+        self.logdir = logdir
+        self.save_model_secs = save_model_secs
+        self.saver = saver or Saver()
+        self.init_seed = init_seed
+        self.basename = checkpoint_basename
+        self.log = log
+        self.betas = adam_betas
+        self._stop = False
+        self._last_save = time.monotonic()
+        self.restored_from: Optional[str] = None
+        self.saved: list = []
+
+    # -- session bring-up ----------------------------------------------------
+    def init_or_restore(self) -> bool:
+        """Chief only.  Returns True if a checkpoint was restored."""
+        assert self.is_chief
+        prefix = latest_checkpoint(self.logdir) if self.logdir else None
+        if prefix:
+            params, step, adam = from_tf_names(self.saver.restore(prefix))
+            self.b.load_params(params)
+            if step is not None:
+                self.b.set_global_step(step)
+            if adam:
+                t = step or 0
+                self.b.load_optimizer_state({"m": adam["m"], "v": adam["v"], "t": t})
+            self.restored_from = prefix
+            self.log(f"Restored from checkpoint {prefix} (global_step={self.b.get_global_step()})")
+            return True
+        self.b.init_params(self.init_seed)
+        self.b.set_global_step(0)
+        return False
+
+    @contextlib.contextmanager
+    def managed_session(self, strategy, final_save: bool = True):
+        """Init/restore on the chief, hand the state to everyone, run the block, stop cleanly."""
+        try:
+            if self.is_chief:
+                self.init_or_restore()
+            strategy.broadcast_initial()
+            self._last_save = time.monotonic()
+            yield self
+        except BaseException:
+            self._stop = True
+            raise
+        else:
+            if final_save and self.is_chief and self.logdir:
+                self.save()
+        finally:
+            self._stop = True
+
+    # -- stop coordination ---------------------------------------------------
+    def should_stop(self) -> bool:
+        return self._stop
+
+    def request_stop(self):
+        self._stop = True
+
+    def stop(self):
+        self._stop = True
+
+    # -- checkpoints ---------------------------------------------------------
+    def save(self) -> Optional[str]:
+        if not (self.is_chief and self.logdir):
+            return None
+        self.b.synchronize()
+        step = self.b.get_global_step()
+        opt = self.b.export_optimizer_state()
+        tensors = to_tf_names(self.b.export_params(), global_step=step,
+                              adam=opt, adam_t=(opt or {}).get("t", 0), betas=self.betas)
+        prefix = self.saver.save(tensors, os.path.join(self.logdir, self.basename), global_step=step)
+        self._last_save = time.monotonic()
+        self.saved.append(prefix)
+        return prefix
+
+    def maybe_save(self) -> Optional[str]:
+        """Timed save (chief): call between steps."""
+        if self.is_chief and self.logdir and self.save_model_secs > 0 and \
+                time.monotonic() - self._last_save >= self.save_model_secs:
+            return self.save()
+        return None

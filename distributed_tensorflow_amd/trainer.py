@@ -1,0 +1,178 @@
+"""Training driver: the reference's ``main`` (reference .idea/MNISTDist.py:93-193) re-designed.
+
+One process per task.  ``run(flags)`` resolves the role from (job_name, task_index), brings up
+the process group, builds the backend (MI355X engine or CPU oracle), the distribution strategy
+(sync all-reduce / async parameter server / local) and the supervisor, then runs
+
+    while not sv.should_stop() and step < training_iter:
+        step = strategy.step()            # sampler + fwd + bwd + collective + update
+        every display_step: print the reference's console line (+ throughput to JSONL)
+        sv.maybe_save()
+
+``training_iter`` bounds the GLOBAL step as in the reference (M:173, M:188): with W async
+workers each performs about training_iter / W updates; in sync mode one global step is one
+collective update over the global batch.
+"""
+from __future__ import annotations
+
+import os
+import sys
+import time
+from typing import Optional
+
+import torch
+import torch.distributed as dist
+
+from .backends import make_backend
+from .cluster import ClusterSpec, TaskInfo, single_process_cluster
+from .data.mnist import read_data_sets
+from .models.spec import ModelSpec
+from .parallel import comm
+from .parallel.strategies import (AsyncP2PServer, AsyncP2PWorker, AsyncRounds, LocalStrategy, SyncAllReduce)
+from .supervisor import Supervisor
+from .utils.metrics import MetricsLogger, StepTimer, format_display_line
+
+
+class FaultInjected(RuntimeError):
+    pass
+
+
+def resolve_task(F) -> TaskInfo:
+    if not F.job_name and not F.worker_hosts and not F.ps_hosts:
+        return single_process_cluster()
+    cluster = ClusterSpec.from_flags(F.ps_hosts, F.worker_hosts)
+    if F.job_name not in ("ps", "worker"):
+        # the reference hits a NameError on sv.stop() here; fail clearly instead
+        raise SystemExit(f"--job_name must be 'ps' or 'worker', got {F.job_name!r}")
+    return TaskInfo(cluster, F.job_name, F.task_index)
+
+
+def _pick_backend(F) -> str:
+    if F.backend != "auto":
+        return F.backend
+    return "hip" if torch.cuda.is_available() else "cpu"
+
+
+def run(F, log=print) -> dict:
+    task = resolve_task(F)
+    kind = _pick_backend(F)
+    world = task.world_size
+    mode = F.mode
+    if world == 1:
+        mode = "local"
+    if mode == "async" and task.num_ps == 0:
+        raise SystemExit("--mode=async needs at least one ps task (--ps_hosts)")
+
+    if kind == "hip":
+        local_rank = int(os.environ.get("LOCAL_RANK", F.local_rank if F.local_rank >= 0 else task.rank))
+        local_rank %= max(1, torch.cuda.device_count())
+        torch.cuda.set_device(local_rank)
+        device = torch.device("cuda", local_rank)
+    else:
+        device = torch.device("cpu")
+
+    if world > 1:
+        host, port = task.cluster.master()
+        backend_name = "gloo" if kind == "cpu" else "cpu:gloo,cuda:nccl"
+        comm.init_process_group(backend_name, task.rank, world, master_addr=host, master_port=port,
+                                device=device if kind == "hip" else None, timeout_s=F.comm_timeout)
+
+    spec = ModelSpec.from_name(F.model)
+    data = read_data_sets(F.data_dir, one_hot=(kind == "cpu"), synthetic=F.synthetic,
+                          seed=F.seed + 1000 * task.rank)   # every worker shuffles independently (ref. item 9)
+    backend = make_backend(kind, spec, F.batch_size, data, optimizer=F.optimizer, learning_rate=F.learning_rate,
+                           keep_prob=F.keep_prob, seed=F.seed + task.rank, device=device, use_graph=F.hip_graph)
+
+    chief_rank = task.cluster.rank_of("worker", 0)
+    worker_group = None
+    if world > 1 and task.num_ps > 0:
+        worker_group = dist.new_group(task.cluster.worker_ranks())   # collective call: every rank makes it
+
+    async_impl = F.async_impl
+    if async_impl == "auto":
+        async_impl = "p2p" if kind == "cpu" else "broadcast"
+
+    metrics = MetricsLogger(F.metrics_file or None)
+    result = dict(role=f"{task.job_name}/{task.task_index}", mode=mode, backend=kind)
+
+    # ------------------------------------------------------------------ ps role
+    if task.is_ps:
+        log(f"ps/{task.task_index}: serving ({mode}{'/' + async_impl if mode == 'async' else ''}) "
+            f"for {task.num_workers} worker(s)")
+        if mode == "async" and async_impl == "p2p":
+            srv = AsyncP2PServer(backend, task, chief_rank, F.training_iter, log=log)
+            srv.broadcast_initial()
+            result["global_step"] = srv.serve()
+            result["applied"], result["dropped_workers"] = srv.applied, srv.dropped
+        elif mode == "async":
+            srv = AsyncRounds(backend, task, chief_rank, staleness=F.staleness)
+            srv.broadcast_initial()
+            result["global_step"] = srv.serve(F.training_iter)
+        else:
+            # sync mode: parameters are replicated on the workers; the ps task has nothing to
+            # serve.  It takes part in the initial broadcast and then blocks like server.join()
+            # (reference M:105-106) until the workers are done.
+            from .parallel.strategies import broadcast_state
+            broadcast_state(backend, chief_rank)
+            dist.barrier()
+        log(f"ps/{task.task_index}: done")
+        comm.shutdown()
+        return result
+
+    # -------------------------------------------------------------- worker role
+    if mode == "local":
+        strategy = LocalStrategy(backend)
+    elif mode == "sync":
+        strategy = SyncAllReduce(backend, task, worker_group, chief_rank)
+    elif async_impl == "p2p":
+        strategy = AsyncP2PWorker(backend, task, chief_rank)
+    else:
+        strategy = AsyncRounds(backend, task, chief_rank, staleness=F.staleness)
+
+    sv = Supervisor(backend, is_chief=task.is_chief, logdir=F.logdir or None, save_model_secs=F.save_model_secs,
+                    init_seed=F.seed, log=log)
+    timer = StepTimer()
+    images_per_step = F.batch_size * (task.num_workers if mode == "sync" else 1)
+    t_start = time.perf_counter()
+    with sv.managed_session(strategy):
+        step = strategy.step_count
+        result["start_step"] = step
+        local_steps = 0
+        while not sv.should_stop() and step < F.training_iter:
+            prev = step
+            step = strategy.step()
+            local_steps += 1
+            timer.add(images_per_step)
+            if F.fault_inject_step >= 0 and local_steps == F.fault_inject_step and \
+                    (F.fault_inject_task < 0 or F.fault_inject_task == task.task_index):
+                log(f"worker/{task.task_index}: injected fault at local step {local_steps}")
+                os._exit(17)
+            if getattr(strategy, "stop", False):
+                sv.request_stop()
+            if prev % F.display_step == 0:
+                loss, acc = backend.last_metrics()       # batch `prev`, pre-update weights (= ref. M:182)
+                log(format_display_line(task.job_name, task.task_index, prev, loss, acc))
+                lap = timer.lap()
+                metrics.log(step=prev, loss=loss, accuracy=acc, role=result["role"], **lap)
+            sv.maybe_save()
+        strategy.finish()
+        backend.synchronize()
+        result["global_step"] = step
+        result["local_steps"] = local_steps
+        result["train_seconds"] = time.perf_counter() - t_start
+        loss, acc = backend.last_metrics() if local_steps else (float("nan"), float("nan"))
+        result["final_loss"], result["final_train_accuracy"] = loss, acc
+        if F.eval and task.is_chief:
+            tl, ta = backend.evaluate("test")
+            result["test_loss"], result["test_accuracy"] = tl, ta
+            log(f"test accuracy: {ta:.4f}  test loss: {tl:.4f}  (global_step {step})")
+            metrics.log(step=step, test_loss=tl, test_accuracy=ta, role=result["role"])
+    result["saved"] = list(sv.saved)
+    result["restored_from"] = sv.restored_from
+    if world > 1:
+        if mode == "sync" and task.num_ps > 0:
+            dist.barrier()            # releases the ps tasks blocked in their join
+        comm.shutdown()
+    metrics.close()
+    log("Optimization Finished!")    # reference M:193
+    return result

@@ -1,0 +1,64 @@
+#!/usr/bin/env python3
+"""Deep MNIST (distributed) -- MI355X-native entrypoint with the reference's flag surface.
+
+    # reference-style launch, one shell per task (reference .idea/MNISTDist.py:13-31):
+    python mnistdist.py --job_name=ps     --task_index=0 --ps_hosts=127.0.0.1:2222 --worker_hosts=127.0.0.1:2223,127.0.0.1:2224
+    python mnistdist.py --job_name=worker --task_index=0 --ps_hosts=... --worker_hosts=...
+    python mnistdist.py --job_name=worker --task_index=1 --ps_hosts=... --worker_hosts=...
+
+    # single GPU / single process:
+    python mnistdist.py --synthetic --steps 1000
+
+All ten reference flags keep their names and defaults; ``--steps`` is an alias of
+``--training_iter``.  New flags select what the TF script hard-coded or could not do.
+"""
+import os
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+
+from distributed_tensorflow_amd import flags  # noqa: E402
+
+# --- the reference's flags (names, types, defaults: reference M:14-31) ---
+flags.DEFINE_string("data_dir", "/tmp/mnist-data", "Directory for string mnist data")
+flags.DEFINE_string("ps_hosts", "", "Comma-separated list of hostname:port pairs")
+flags.DEFINE_string("worker_hosts", "", "Comma-separated list of hostname:port pairs")
+flags.DEFINE_string("job_name", "", "One of 'ps', 'worker'")
+flags.DEFINE_integer("task_index", 0, "Index of task within the   job")
+flags.DEFINE_integer("hidden_units", 100, "Number of units in the hidden layer of the NN (unused, as in the reference)")
+flags.DEFINE_integer("batch_size", 128, "Training batchsize")
+flags.DEFINE_integer("training_iter", 10000, "Training iteration")
+flags.DEFINE_float("learning_rate", 0.001, "Learning rate")
+flags.DEFINE_integer("display_step", 100, "display step")
+# --- extensions ---
+flags.DEFINE_alias("steps", "training_iter")
+flags.DEFINE_string("mode", "sync", "sync (RCCL all-reduce DP) | async (parameter-server semantics)")
+flags.DEFINE_string("async_impl", "auto", "auto | p2p (true async send/recv) | broadcast (reduce+broadcast rounds)")
+flags.DEFINE_integer("staleness", 1, "async broadcast rounds: gradient staleness bound in rounds (0 or 1)")
+flags.DEFINE_string("optimizer", "sgd", "sgd (reference) | adam (TF deep-MNIST tutorial recipe)")
+flags.DEFINE_float("keep_prob", 1.0, "dropout keep probability (the reference feeds 1.0)")
+flags.DEFINE_string("model", "deep_mnist", "deep_mnist | wide (conv 128/256, fc4096)")
+flags.DEFINE_string("backend", "auto", "auto | hip (MI355X kernels) | cpu (PyTorch oracle, gloo)")
+flags.DEFINE_string("logdir", "/tmp/train_logs", "checkpoint directory (reference hard-codes /tmp/train_logs); '' disables")
+flags.DEFINE_float("save_model_secs", 600.0, "seconds between chief checkpoints (reference: 600)")
+flags.DEFINE_boolean("synthetic", False, "use MNIST-shaped synthetic data (automatic when data_dir has no idx files)")
+flags.DEFINE_boolean("eval", True, "evaluate on the 10k test split at the end (chief)")
+flags.DEFINE_integer("seed", 0, "base random seed")
+flags.DEFINE_boolean("hip_graph", True, "replay the single-GPU step as a captured HIP graph")
+flags.DEFINE_integer("local_rank", -1, "GPU index for this process (default: LOCAL_RANK or rank % device_count)")
+flags.DEFINE_float("comm_timeout", 1800.0, "collective timeout in seconds (failure detection in sync mode)")
+flags.DEFINE_string("metrics_file", "", "append JSONL metrics here")
+flags.DEFINE_integer("fault_inject_step", -1, "test hook: crash this worker after N local steps")
+flags.DEFINE_integer("fault_inject_task", -1, "test hook: which worker task crashes (-1 = any)")
+
+FLAGS = flags.FLAGS
+
+
+def main(_):
+    from distributed_tensorflow_amd import trainer
+    trainer.run(FLAGS)
+    return 0
+
+
+if __name__ == "__main__":
+    flags.app.run(main)

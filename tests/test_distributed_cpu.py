@@ -1,0 +1,137 @@
+"""Multi-process plumbing on CPU (gloo): the reference's launch style -- one OS process per
+task, discovered only through --ps_hosts/--worker_hosts (reference .idea/MNISTDist.py:94-107).
+Covers BASELINE.json config #1 (1 ps + 2 workers, batch 100, sync), both async parameter-server
+implementations, worker-loss tolerance and chief restart/resume."""
+import os
+import re
+import socket
+import subprocess
+import sys
+import time
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+CLI = os.path.join(ROOT, "mnistdist.py")
+
+
+def free_ports(n):
+    socks, ports = [], []
+    for _ in range(n):
+        s = socket.socket()
+        s.bind(("127.0.0.1", 0))
+        socks.append(s)
+        ports.append(s.getsockname()[1])
+    for s in socks:
+        s.close()
+    return ports
+
+
+def launch(n_ps, n_workers, extra, logdir, per_task_extra=None, timeout=240):
+    ports = free_ports(n_ps + n_workers)
+    ps_hosts = ",".join(f"127.0.0.1:{p}" for p in ports[:n_ps])
+    wk_hosts = ",".join(f"127.0.0.1:{p}" for p in ports[n_ps:])
+    env = dict(os.environ, OMP_NUM_THREADS="2", MKL_NUM_THREADS="2")
+    procs = []
+    for job, n in (("ps", n_ps), ("worker", n_workers)):
+        for i in range(n):
+            cmd = [sys.executable, "-u", CLI, f"--job_name={job}", f"--task_index={i}", f"--ps_hosts={ps_hosts}",
+                   f"--worker_hosts={wk_hosts}", "--backend=cpu", "--synthetic", f"--logdir={logdir}",
+                   "--comm_timeout=120"] + list(extra) + list((per_task_extra or {}).get((job, i), []))
+            procs.append(((job, i), subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True,
+                                                     env=env, cwd=ROOT)))
+    out = {}
+    deadline = time.time() + timeout
+    for key, p in procs:
+        try:
+            o, _ = p.communicate(timeout=max(1, deadline - time.time()))
+        except subprocess.TimeoutExpired:
+            for _, q in procs:
+                q.kill()
+            o = p.communicate()[0]
+            raise AssertionError(f"{key} timed out:\n{o}")
+        out[key] = (p.returncode, o)
+    return out
+
+
+DISPLAY = re.compile(r"^job: worker/(\d+) step:  (\d+) mini_batch loss:  ([-\d.einf]+) training accuracy:  ([\d.]+)$", re.M)
+
+
+def test_sync_1ps_2workers_batch100(tmp_path):
+    logdir = str(tmp_path / "logs")
+    out = launch(1, 2, ["--mode=sync", "--batch_size=100", "--steps=12", "--display_step=4",
+                        "--learning_rate=0.01", "--noeval"], logdir)
+    for key, (rc, o) in out.items():
+        assert rc == 0, (key, o)
+    assert "ps/0: done" in out[("ps", 0)][1]
+    w0, w1 = out[("worker", 0)][1], out[("worker", 1)][1]
+    for o in (w0, w1):
+        assert "Optimization Finished!" in o
+        steps = [int(m.group(2)) for m in DISPLAY.finditer(o)]
+        assert steps == [0, 4, 8], o          # reference console format, every display_step
+    l0 = [float(m.group(3)) for m in DISPLAY.finditer(w0)]
+    assert l0[-1] < l0[0]
+    # chief-only checkpoint with the final global step
+    files = os.listdir(logdir)
+    assert "checkpoint" in files and "model.ckpt-12.index" in files and "model.ckpt-12.data-00000-of-00001" in files
+    from distributed_tensorflow_amd.checkpoint import read_bundle
+    ck = read_bundle(os.path.join(logdir, "model.ckpt-12"))
+    assert int(ck["Variable_8"]) == 12 and ck["Variable_2"].shape == (3136, 1024)
+
+
+def test_async_p2p_two_ps_shards_and_global_step_semantics(tmp_path):
+    logdir = str(tmp_path / "logs")
+    out = launch(2, 2, ["--mode=async", "--async_impl=p2p", "--batch_size=32", "--steps=20", "--display_step=1",
+                        "--learning_rate=0.01", "--noeval"], logdir)
+    for key, (rc, o) in out.items():
+        assert rc == 0, (key, o)
+    # training_iter bounds the GLOBAL step: the two workers share the 20 updates
+    steps = []
+    for w in (0, 1):
+        steps.append([int(m.group(2)) for m in DISPLAY.finditer(out[("worker", w)][1])])
+    assert 1 <= len(steps[0]) < 20 and 1 <= len(steps[1]) < 20
+    assert len(steps[0]) + len(steps[1]) in range(20, 23)
+    allsteps = sorted(steps[0] + steps[1])
+    assert allsteps[0] == 0 and allsteps[-1] <= 20
+
+
+def test_async_broadcast_rounds(tmp_path):
+    logdir = str(tmp_path / "logs")
+    out = launch(1, 2, ["--mode=async", "--async_impl=broadcast", "--staleness=1", "--batch_size=32", "--steps=16",
+                        "--display_step=2", "--learning_rate=0.01", "--noeval"], logdir)
+    for key, (rc, o) in out.items():
+        assert rc == 0, (key, o)
+    w0 = out[("worker", 0)][1]
+    steps = [int(m.group(2)) for m in DISPLAY.finditer(w0)]
+    assert steps == [0, 2, 4, 6, 8, 10, 12, 14]       # global_step advances by #workers per round
+    losses = [float(m.group(3)) for m in DISPLAY.finditer(w0)]
+    assert losses[-1] < losses[0]
+    assert "model.ckpt-16.index" in os.listdir(logdir)
+
+
+def test_async_survives_worker_loss(tmp_path):
+    logdir = str(tmp_path / "logs")
+    out = launch(1, 2, ["--mode=async", "--async_impl=p2p", "--batch_size=16", "--steps=24", "--display_step=4",
+                        "--learning_rate=0.01", "--noeval"], logdir,
+                 per_task_extra={("worker", 1): ["--fault_inject_step=3"]})
+    assert out[("worker", 1)][0] == 17                       # injected crash
+    assert out[("worker", 0)][0] == 0, out[("worker", 0)][1]
+    assert out[("ps", 0)][0] == 0, out[("ps", 0)][1]
+    assert "Optimization Finished!" in out[("worker", 0)][1]
+    assert "lost" in out[("ps", 0)][1]
+
+
+def test_chief_restart_resumes_from_checkpoint(tmp_path):
+    logdir = str(tmp_path / "logs")
+    args = ["--synthetic", "--backend=cpu", "--batch_size=32", "--learning_rate=0.01", "--display_step=5",
+            f"--logdir={logdir}", "--noeval"]
+    r1 = subprocess.run([sys.executable, CLI, "--steps=10"] + args, capture_output=True, text=True, cwd=ROOT)
+    assert r1.returncode == 0, r1.stdout + r1.stderr
+    assert "model.ckpt-10.index" in os.listdir(logdir)
+    r2 = subprocess.run([sys.executable, CLI, "--steps=20"] + args, capture_output=True, text=True, cwd=ROOT)
+    assert r2.returncode == 0, r2.stdout + r2.stderr
+    assert "Restored from checkpoint" in r2.stdout and "model.ckpt-10" in r2.stdout
+    steps = [int(m.group(2)) for m in DISPLAY.finditer(r2.stdout)]
+    assert steps == [10, 15]                                  # continues at the restored global_step
+    assert "model.ckpt-20.index" in os.listdir(logdir)
