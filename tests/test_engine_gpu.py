@@ -102,3 +102,55 @@ def test_adam_and_dropout_train(gpu_lib, dataset):
     assert last < 0.3 * first, (first, last)
     loss, acc = eng.evaluate(dataset.images[:1024], dataset.labels[:1024])
     assert acc > 0.8, acc
+
+
+def test_sync_dp_world1_rccl_matches_plain_engine(gpu_lib, dataset):
+    """The bucketed/overlapped all-reduce path over RCCL (world = 1 on the single test GPU: RCCL
+    cannot host two ranks on one device) must be a no-op numerically."""
+    import os
+    import torch.distributed as dist
+    from distributed_tensorflow_amd.engine import HipEngine
+    from distributed_tensorflow_amd.parallel import comm
+    from distributed_tensorflow_amd.parallel.sync_dp import SyncDataParallel
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", "29611"
+    comm.init_process_group("nccl", 0, 1, device=torch.device("cuda", 0))
+    try:
+        a = HipEngine(ModelSpec(), 128, dataset, learning_rate=0.01, seed=4)
+        b = HipEngine(ModelSpec(), 128, dataset, learning_rate=0.01, seed=4)
+        a.init_params(seed=2)
+        b.init_params(seed=2)
+        dp = SyncDataParallel(b, bucket_mb=1.0)
+        assert len(dp.dense_buckets) >= 12 and dp.tail_bucket[1] == b.layout.total
+        dp.broadcast_parameters()
+        for _ in range(5):
+            a.launch_train_step()
+            dp.train_step()
+        torch.cuda.synchronize()
+        assert torch.equal(a.params, b.params)
+        assert a.global_step == b.global_step == 5
+    finally:
+        dist.destroy_process_group()
+
+
+def test_cli_trains_on_gpu(gpu_lib, tmp_path):
+    """mnistdist.py end to end on the MI355X backend: console format, checkpoint, test accuracy."""
+    import os
+    import re
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    logdir = str(tmp_path / "logs")
+    r = subprocess.run([sys.executable, os.path.join(root, "mnistdist.py"), "--synthetic", "--backend=hip",
+                        "--steps=300", "--batch_size=128", "--learning_rate=0.01", "--display_step=100",
+                        f"--logdir={logdir}", f"--metrics_file={tmp_path}/m.jsonl"],
+                       capture_output=True, text=True, cwd=root, timeout=280)
+    assert r.returncode == 0, r.stdout + r.stderr
+    lines = re.findall(r"^job: worker/0 step:  (\d+) mini_batch loss:  ([\d.e-]+) training accuracy:  ([\d.]+)$",
+                       r.stdout, re.M)
+    assert [int(l[0]) for l in lines] == [0, 100, 200]
+    acc = float(re.search(r"test accuracy: ([\d.]+)", r.stdout).group(1))
+    assert acc > 0.95, r.stdout
+    assert "Optimization Finished!" in r.stdout
+    from distributed_tensorflow_amd.checkpoint import read_bundle
+    ck = read_bundle(os.path.join(logdir, "model.ckpt-300"))
+    assert int(ck["Variable_8"]) == 300 and ck["Variable_1"].shape == (5, 5, 32, 64)
