@@ -293,18 +293,29 @@ class HipEngine:
         self.launch_backward_conv(images, None)
         self.launch_update(advance_cursor=False)
 
-    def capture(self, warmup: int = 2):
-        """Capture launch_train_step into a HIP graph (hipGraph via torch.cuda.CUDAGraph)."""
+    def capture(self, warmup: int = 1):
+        """Capture launch_train_step into a HIP graph (hipGraph via torch.cuda.CUDAGraph).
+
+        The warm-up launches (lazy kernel attribute set-up must not happen under capture) run real
+        steps, so parameters / optimizer moments / step state are snapshotted and restored:
+        capturing is invisible to training."""
+        keep = [self.params, self.state, self.shadow, self.wd1T, self.wc2T]
+        if self.optimizer == "adam":
+            keep += [self.adam_m, self.adam_v]
+        snap = [t.clone() for t in keep]
         st = torch.cuda.Stream(self.device)
         st.wait_stream(torch.cuda.current_stream(self.device))
         with torch.cuda.stream(st):
-            for _ in range(warmup):
+            for _ in range(max(1, warmup)):
                 self.launch_train_step()
         torch.cuda.current_stream(self.device).wait_stream(st)
         torch.cuda.synchronize(self.device)
         g = torch.cuda.CUDAGraph()
         with torch.cuda.graph(g, stream=st):
             self.launch_train_step()
+        for t, s0 in zip(keep, snap):
+            t.copy_(s0)
+        torch.cuda.synchronize(self.device)
         self._graph, self._graph_stream = g, st
         return g
 

@@ -69,9 +69,8 @@ def test_training_converges_and_graph_replay(gpu_lib, dataset):
         eng = HipEngine(spec, 128, dataset, optimizer="sgd", learning_rate=0.01, seed=3)
         eng.init_params(seed=11)
         if graph:
-            eng.capture(warmup=0)
-            eng.state.zero_()
-            eng.init_params(seed=11)
+            eng.capture()
+            assert eng.global_step == 0
         losses = []
         for _ in range(60):
             eng.train_step()
