@@ -9,7 +9,8 @@
 //             wgrad    dwd1 = flat^T . dh1   -- K is the batch
 //
 // Tiling: 256 threads = 4 waves as 2x2, wave tile (BM/2)x(BN/2) of 16x16x32
-// MFMAs, BK = 64, one LDS buffer + register prefetch of the next K tile.
+// MFMAs, BK = 64, double-buffered LDS + two register sets (tile t+2 in flight while
+// tile t is multiplied), one barrier per K tile.
 //   NT: LDS rows are 128 B (64 bf16 of K); the 16-byte chunk index is XORed
 //       with (row & 7) so that ds_read_b128 fragment reads are conflict-free.
 //   TN: LDS keeps the global [K][M] orientation (coalesced staging) with a
@@ -21,7 +22,7 @@
 
 namespace dtf {
 
-enum { EPI_STORE = 0, EPI_BIAS_RELU_DROPOUT = 1 };
+enum { EPI_STORE = 0, EPI_BIAS_RELU_DROPOUT = 1, EPI_NOSTORE_DIAG = 2 };
 
 struct DropoutArgs {
   float keep_prob;        // 1.0 -> disabled
@@ -44,8 +45,8 @@ __global__ __launch_bounds__(256) void gemm_nt_bf16(const bf16* __restrict__ A, 
   constexpr int WM = BM / 2, WN = BN / 2;
   constexpr int MT = WM / 16, NTL = WN / 16;
   constexpr int A_CH = BM * 8 / 256, B_CH = BN * 8 / 256;  // 16-byte chunks per thread
-  __shared__ __attribute__((aligned(16))) bf16 sA[BM * BK];
-  __shared__ __attribute__((aligned(16))) bf16 sB[BN * BK];
+  __shared__ __attribute__((aligned(16))) bf16 sA[2][BM * BK];
+  __shared__ __attribute__((aligned(16))) bf16 sB[2][BN * BK];
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave >> 1, wn = wave & 1;
@@ -58,8 +59,11 @@ __global__ __launch_bounds__(256) void gemm_nt_bf16(const bf16* __restrict__ A, 
 #pragma unroll
     for (int j = 0; j < NTL; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-  u32x4 ra[A_CH], rb[B_CH];
-  auto gload = [&](int k0) {
+  // Software pipeline: two register sets + two LDS buffers.  The global loads of tile t+2 are
+  // issued before the MFMAs of tile t and only written to LDS a full phase later, so their
+  // latency hides under two compute phases; one barrier per K tile.
+  u32x4 ra0[A_CH], rb0[B_CH], ra1[A_CH], rb1[B_CH];
+  auto gload = [&](u32x4 (&ra)[A_CH], u32x4 (&rb)[B_CH], int k0) {
 #pragma unroll
     for (int i = 0; i < A_CH; ++i) {
       int c = tid + i * 256, row = c >> 3, slot = c & 7;
@@ -75,42 +79,53 @@ __global__ __launch_bounds__(256) void gemm_nt_bf16(const bf16* __restrict__ A, 
                                  : (u32x4){0u, 0u, 0u, 0u};
     }
   };
-  auto swrite = [&]() {
+  auto swrite = [&](const u32x4 (&ra)[A_CH], const u32x4 (&rb)[B_CH], int buf) {
 #pragma unroll
     for (int i = 0; i < A_CH; ++i) {
       int c = tid + i * 256, row = c >> 3, slot = c & 7;
-      *reinterpret_cast<u32x4*>(sA + row * BK + ((slot ^ (row & 7)) << 3)) = ra[i];
+      *reinterpret_cast<u32x4*>(sA[buf] + row * BK + ((slot ^ (row & 7)) << 3)) = ra[i];
     }
 #pragma unroll
     for (int i = 0; i < B_CH; ++i) {
       int c = tid + i * 256, row = c >> 3, slot = c & 7;
-      *reinterpret_cast<u32x4*>(sB + row * BK + ((slot ^ (row & 7)) << 3)) = rb[i];
+      *reinterpret_cast<u32x4*>(sB[buf] + row * BK + ((slot ^ (row & 7)) << 3)) = rb[i];
     }
   };
-
-  gload(0);
-  for (int k0 = 0; k0 < K; k0 += BK) {
-    swrite();
-    __syncthreads();
-    if (k0 + BK < K) gload(k0 + BK);
+  auto compute = [&](int buf) {
 #pragma unroll
     for (int kk = 0; kk < 2; ++kk) {
       bf16x8 af[MT], bfv[NTL];
 #pragma unroll
       for (int i = 0; i < MT; ++i) {
         int row = wm * WM + i * 16 + i16;
-        af[i] = *reinterpret_cast<const bf16x8*>(sA + row * BK + (((kk * 4 + g) ^ (row & 7)) << 3));
+        af[i] = *reinterpret_cast<const bf16x8*>(sA[buf] + row * BK + (((kk * 4 + g) ^ (row & 7)) << 3));
       }
 #pragma unroll
       for (int j = 0; j < NTL; ++j) {
         int row = wn * WN + j * 16 + i16;
-        bfv[j] = *reinterpret_cast<const bf16x8*>(sB + row * BK + (((kk * 4 + g) ^ (row & 7)) << 3));
+        bfv[j] = *reinterpret_cast<const bf16x8*>(sB[buf] + row * BK + (((kk * 4 + g) ^ (row & 7)) << 3));
       }
 #pragma unroll
       for (int i = 0; i < MT; ++i)
 #pragma unroll
         for (int j = 0; j < NTL; ++j) acc[i][j] = mfma16(af[i], bfv[j], acc[i][j]);
     }
+  };
+
+  const int T = (K + BK - 1) / BK;
+  gload(ra0, rb0, 0);
+  if (T > 1) gload(ra1, rb1, BK);
+  swrite(ra0, rb0, 0);
+  __syncthreads();
+  for (int t = 0; t < T; t += 2) {
+    if (t + 2 < T) gload(ra0, rb0, (t + 2) * BK);
+    compute(0);
+    if (t + 1 < T) swrite(ra1, rb1, 1);
+    __syncthreads();
+    if (t + 1 >= T) break;
+    if (t + 3 < T) gload(ra1, rb1, (t + 3) * BK);
+    compute(1);
+    if (t + 2 < T) swrite(ra0, rb0, 0);
     __syncthreads();
   }
 
@@ -134,7 +149,8 @@ __global__ __launch_bounds__(256) void gemm_nt_bf16(const bf16* __restrict__ A, 
           v = fmaxf(v + bv, 0.f);
           if (do_drop) v *= dropout_scale(drop, drop_off, (uint64_t)mrow * (uint64_t)N + n);
         }
-        C[(size_t)mrow * ldc + n] = (bf16)v;
+        if (EPI == EPI_NOSTORE_DIAG) { if (v != v) C[(size_t)mrow * ldc + n] = (bf16)v; }  // timing diagnostic only
+        else C[(size_t)mrow * ldc + n] = (bf16)v;
       }
   }
 }
@@ -149,8 +165,8 @@ __global__ __launch_bounds__(256) void gemm_tn_bf16(const bf16* __restrict__ A, 
   constexpr int WM = BM / 2, WN = BN / 2;
   constexpr int MT = WM / 16, NTL = WN / 16;
   constexpr int A_CH = BK * (BM / 8) / 256, B_CH = BK * (BN / 8) / 256;
-  __shared__ __attribute__((aligned(16))) bf16 sA[BK * PA];
-  __shared__ __attribute__((aligned(16))) bf16 sB[BK * PB];
+  __shared__ __attribute__((aligned(16))) bf16 sA[2][BK * PA];
+  __shared__ __attribute__((aligned(16))) bf16 sB[2][BK * PB];
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave >> 1, wn = wave & 1;
@@ -164,8 +180,8 @@ __global__ __launch_bounds__(256) void gemm_tn_bf16(const bf16* __restrict__ A, 
 #pragma unroll
     for (int j = 0; j < NTL; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-  u32x4 ra[A_CH], rb[B_CH];
-  auto gload = [&](int k0) {
+  u32x4 ra0[A_CH], rb0[B_CH], ra1[A_CH], rb1[B_CH];
+  auto gload = [&](u32x4 (&ra)[A_CH], u32x4 (&rb)[B_CH], int k0) {
 #pragma unroll
     for (int i = 0; i < A_CH; ++i) {
       int c = tid + i * 256, row = c / (BM / 8), slot = c % (BM / 8);
@@ -181,16 +197,16 @@ __global__ __launch_bounds__(256) void gemm_tn_bf16(const bf16* __restrict__ A, 
                                  : (u32x4){0u, 0u, 0u, 0u};
     }
   };
-  auto swrite = [&]() {
+  auto swrite = [&](const u32x4 (&ra)[A_CH], const u32x4 (&rb)[B_CH], int buf) {
 #pragma unroll
     for (int i = 0; i < A_CH; ++i) {
       int c = tid + i * 256, row = c / (BM / 8), slot = c % (BM / 8);
-      *reinterpret_cast<u32x4*>(sA + row * PA + slot * 8) = ra[i];
+      *reinterpret_cast<u32x4*>(sA[buf] + row * PA + slot * 8) = ra[i];
     }
 #pragma unroll
     for (int i = 0; i < B_CH; ++i) {
       int c = tid + i * 256, row = c / (BN / 8), slot = c % (BN / 8);
-      *reinterpret_cast<u32x4*>(sB + row * PB + slot * 8) = rb[i];
+      *reinterpret_cast<u32x4*>(sB[buf] + row * PB + slot * 8) = rb[i];
     }
   };
   typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
@@ -203,24 +219,35 @@ __global__ __launch_bounds__(256) void gemm_tn_bf16(const bf16* __restrict__ A, 
     s16x8 v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
     return __builtin_bit_cast(bf16x8, v);
   };
-
-  gload(0);
-  for (int k0 = 0; k0 < K; k0 += BK) {
-    swrite();
-    __syncthreads();
-    if (k0 + BK < K) gload(k0 + BK);
+  auto compute = [&](int buf) {
 #pragma unroll
     for (int kk = 0; kk < 2; ++kk) {
       bf16x8 af[MT], bfv[NTL];
 #pragma unroll
-      for (int i = 0; i < MT; ++i) af[i] = tr_frag(sA, PA, kk, wm * WM + i * 16);
+      for (int i = 0; i < MT; ++i) af[i] = tr_frag(sA[buf], PA, kk, wm * WM + i * 16);
 #pragma unroll
-      for (int j = 0; j < NTL; ++j) bfv[j] = tr_frag(sB, PB, kk, wn * WN + j * 16);
+      for (int j = 0; j < NTL; ++j) bfv[j] = tr_frag(sB[buf], PB, kk, wn * WN + j * 16);
 #pragma unroll
       for (int i = 0; i < MT; ++i)
 #pragma unroll
         for (int j = 0; j < NTL; ++j) acc[i][j] = mfma16(af[i], bfv[j], acc[i][j]);
     }
+  };
+
+  const int T = (K + BK - 1) / BK;
+  gload(ra0, rb0, 0);
+  if (T > 1) gload(ra1, rb1, BK);
+  swrite(ra0, rb0, 0);
+  __syncthreads();
+  for (int t = 0; t < T; t += 2) {
+    if (t + 2 < T) gload(ra0, rb0, (t + 2) * BK);
+    compute(0);
+    if (t + 1 < T) swrite(ra1, rb1, 1);
+    __syncthreads();
+    if (t + 1 >= T) break;
+    if (t + 3 < T) gload(ra1, rb1, (t + 3) * BK);
+    compute(1);
+    if (t + 2 < T) swrite(ra0, rb0, 0);
     __syncthreads();
   }
 #pragma unroll
@@ -278,6 +305,8 @@ int dtf_gemm_nt(const void* A, const void* B, void* C, const void* bias, int M, 
   else if (tile == 128 && epi == 1) NT_CASE(128, EPI_BIAS_RELU_DROPOUT);
   else if (tile == 64 && epi == 0) NT_CASE(64, EPI_STORE);
   else if (tile == 64 && epi == 1) NT_CASE(64, EPI_BIAS_RELU_DROPOUT);
+  else if (tile == 128 && epi == 2) NT_CASE(128, EPI_NOSTORE_DIAG);
+  else if (tile == 64 && epi == 2) NT_CASE(64, EPI_NOSTORE_DIAG);
   else return -1;
 #undef NT_CASE
   return (int)hipGetLastError();

@@ -107,23 +107,23 @@ struct ReduceSegs {
   int count;
 };
 
-// 256 threads = 64 float4 columns x 4 slab groups; fixed summation order -> deterministic.
+// 256 threads = 16 float4 columns x 16 slab groups; fixed summation order -> deterministic.
 __global__ __launch_bounds__(256) void reduce_segments(ReduceSegs segs) {
-  __shared__ f32x4 red[4][64];
+  __shared__ f32x4 red[16][17];
   int k = 0, blk = blockIdx.x;
 #pragma unroll
   for (int t = 0; t < 3; ++t)
     if (k == t && t + 1 < segs.count && (int)blockIdx.x >= segs.blocks_end[t]) { k = t + 1; blk = blockIdx.x - segs.blocks_end[t]; }
   const ReduceSeg sg = segs.s[k];
-  const int col = threadIdx.x & 63, grp = threadIdx.x >> 6;
-  const long i4 = (long)blk * 64 + col;
+  const int col = threadIdx.x & 15, grp = threadIdx.x >> 4;
+  const long i4 = (long)blk * 16 + col;
   f32x4 a0 = {0.f, 0.f, 0.f, 0.f}, a1 = a0;
   if (i4 * 4 < sg.n) {
     const float* p = sg.part + i4 * 4;
     int gI = grp;
-    for (; gI + 4 < sg.G; gI += 8) {
+    for (; gI + 16 < sg.G; gI += 32) {
       f32x4 v0 = *reinterpret_cast<const f32x4*>(p + (size_t)gI * sg.stride);
-      f32x4 v1 = *reinterpret_cast<const f32x4*>(p + (size_t)(gI + 4) * sg.stride);
+      f32x4 v1 = *reinterpret_cast<const f32x4*>(p + (size_t)(gI + 16) * sg.stride);
       a0 += v0;
       a1 += v1;
     }
@@ -131,8 +131,12 @@ __global__ __launch_bounds__(256) void reduce_segments(ReduceSegs segs) {
   }
   red[grp][col] = a0 + a1;
   __syncthreads();
-  if (grp == 0 && i4 * 4 < sg.n)
-    *reinterpret_cast<f32x4*>(sg.out + i4 * 4) = (red[0][col] + red[1][col]) + (red[2][col] + red[3][col]);
+  if (grp == 0 && i4 * 4 < sg.n) {
+    f32x4 s = red[0][col];
+#pragma unroll
+    for (int t = 1; t < 16; ++t) s += red[t][col];
+    *reinterpret_cast<f32x4*>(sg.out + i4 * 4) = s;
+  }
 }
 
 }  // namespace dtf
@@ -188,7 +192,7 @@ int dtf_reduce_segments(int count, const void** part, void** out, const int* G, 
     if (k < count) {
       if ((n[k] & 3) || (stride[k] & 3) || ((uintptr_t)part[k] & 15) || ((uintptr_t)out[k] & 15)) return -3;
       segs.s[k] = ReduceSeg{(const float*)part[k], (float*)out[k], G[k], n[k], stride[k]};
-      blocks += (n[k] / 4 + 63) / 64;
+      blocks += (n[k] / 4 + 15) / 16;
     } else {
       segs.s[k] = ReduceSeg{nullptr, nullptr, 0, 0, 0};
     }
