@@ -44,7 +44,9 @@ enum { MODE_FWD = 0, MODE_DGRAD = 1 };
 //   out  MODE_FWD  : pooled [B,7,7,NC] bf16 + argmax [B,7,7,NC] u8
 //        MODE_DGRAD: dx [B,14,14,NC] bf16
 // ----------------------------------------------------------------------------
-template <int KC, int NC, int IMGS, int NW, int MODE>
+// KTOT = reduction channels of the layer, KC = channels resident in LDS at a time (KTOT is
+// walked in KC chunks when the full tile would not fit the 160 KiB LDS).
+template <int KTOT, int KC, int NC, int IMGS, int NW, int MODE>
 __global__ __launch_bounds__(IMGS * 2 * NW * 64) void conv5x5_igemm(
     const bf16* __restrict__ in, const uint8_t* __restrict__ in_arg,
     const bf16* __restrict__ in_pooled, const bf16* __restrict__ wk,
@@ -56,7 +58,7 @@ __global__ __launch_bounds__(IMGS * 2 * NW * 64) void conv5x5_igemm(
   constexpr int CH8 = KC / 8;          // 16-byte chunks per position
   constexpr int KP = (KC % 64 == 0) ? KC + 8 : KC;  // LDS position pitch: +16 B turns the 4-way b128 conflict of 128-B pitches into 2-way
   static_assert(NC % (16 * NW) == 0, "NC must split evenly over NW waves");
-  static_assert(KC % 32 == 0, "KC must be a multiple of 32");
+  static_assert(KC % 32 == 0 && KTOT % KC == 0, "KC must be a multiple of 32 dividing KTOT");
 
   extern __shared__ __attribute__((aligned(16))) char smem[];
   bf16* tile = reinterpret_cast<bf16*>(smem);  // [IMGS][kTilePos][KP]
@@ -76,7 +78,22 @@ __global__ __launch_bounds__(IMGS * 2 * NW * 64) void conv5x5_igemm(
     constexpr int N16 = IMGS * kTilePos * KP * 2 / 16;
     for (int i = tid; i < N16; i += NTHREADS) t4[i] = z;
   }
-  __syncthreads();
+  // lane -> (row m of the 16-row tile, k-group g)
+  const int m = lane & 15, g = lane >> 4;
+  const int wl = m >> 2, q = m & 3;
+  // position of this lane's A row for m-tile 0 (row pair 0), tap (0,0), in tile coordinates
+  const int a_pos = (q >> 1) * kTileW + 2 * (4 * w_h + wl) + (q & 1);
+  const bf16* a_base = tile + ((size_t)w_img * kTilePos + a_pos) * KP + g * 8;
+
+  f32x4 acc[7][NT];
+#pragma unroll
+  for (int i = 0; i < 7; ++i)
+#pragma unroll
+    for (int j = 0; j < NT; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+#pragma unroll 1
+  for (int kc0 = 0; kc0 < KTOT; kc0 += KC) {
+  __syncthreads();  // zero fill done / previous chunk fully consumed
   if (MODE == MODE_FWD) {
     constexpr int NCHUNK = IMGS * 196 * CH8;
     for (int c = tid; c < NCHUNK; c += NTHREADS) {
@@ -85,7 +102,7 @@ __global__ __launch_bounds__(IMGS * 2 * NW * 64) void conv5x5_igemm(
       int im = c / (CH8 * 196);
       int b = img0 + im;
       if (b < B) {
-        u32x4 v = *reinterpret_cast<const u32x4*>(in + ((size_t)b * 196 + pos) * KC + ch * 8);
+        u32x4 v = *reinterpret_cast<const u32x4*>(in + ((size_t)b * 196 + pos) * KTOT + kc0 + ch * 8);
         int y = pos / 14, x = pos % 14;
         int tp = (y + 2) * kTileW + (x + 2);
         *reinterpret_cast<u32x4*>(tile + ((size_t)im * kTilePos + tp) * KP + ch * 8) = v;
@@ -100,8 +117,8 @@ __global__ __launch_bounds__(IMGS * 2 * NW * 64) void conv5x5_igemm(
       int im = c / (CH8 * 49);
       int b = img0 + im;
       if (b < B) {
-        size_t off = ((size_t)b * 49 + pp) * KC + ch * 8;
-        bf16x8 g = *reinterpret_cast<const bf16x8*>(in + off);
+        size_t off = ((size_t)b * 49 + pp) * KTOT + kc0 + ch * 8;
+        bf16x8 gq = *reinterpret_cast<const bf16x8*>(in + off);
         bf16x8 p = *reinterpret_cast<const bf16x8*>(in_pooled + off);
         u32x2 a2 = *reinterpret_cast<const u32x2*>(in_arg + off);
         int py = pp / 7, px = pp % 7;
@@ -111,33 +128,21 @@ __global__ __launch_bounds__(IMGS * 2 * NW * 64) void conv5x5_igemm(
           unsigned a = ((e < 4 ? a2[0] : a2[1]) >> ((e & 3) * 8)) & 0xffu;
           bool live = (float)p[e] > 0.f;
 #pragma unroll
-          for (int q = 0; q < 4; ++q) o[q][e] = (live && a == (unsigned)q) ? g[e] : (bf16)0.f;
+          for (int qq = 0; qq < 4; ++qq) o[qq][e] = (live && a == (unsigned)qq) ? gq[e] : (bf16)0.f;
         }
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-          int tp = (2 * py + (q >> 1) + 2) * kTileW + (2 * px + (q & 1) + 2);
-          *reinterpret_cast<bf16x8*>(tile + ((size_t)im * kTilePos + tp) * KP + ch * 8) = o[q];
+        for (int qq = 0; qq < 4; ++qq) {
+          int tp = (2 * py + (qq >> 1) + 2) * kTileW + (2 * px + (qq & 1) + 2);
+          *reinterpret_cast<bf16x8*>(tile + ((size_t)im * kTilePos + tp) * KP + ch * 8) = o[qq];
         }
       }
     }
   }
   __syncthreads();
 
-  // ---- main loop ----
-  // lane -> (row m of the 16-row tile, k-group g)
-  const int m = lane & 15, g = lane >> 4;
-  const int wl = m >> 2, q = m & 3;
-  // position of this lane's A row for m-tile 0 (row pair 0), tap (0,0), in tile coordinates
-  const int a_pos = (q >> 1) * kTileW + 2 * (4 * w_h + wl) + (q & 1);
-  const bf16* a_base = tile + ((size_t)w_img * kTilePos + a_pos) * KP + g * 8;
-  // B fragment: column n = lane&15 of n-tile nt, k = 8g..8g+7
-  const bf16* b_base = wk + ((size_t)(w_n * NT * 16 + m)) * KC + g * 8;
-
-  f32x4 acc[7][NT];
-#pragma unroll
-  for (int i = 0; i < 7; ++i)
-#pragma unroll
-    for (int j = 0; j < NT; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  // ---- main loop over this chunk ----
+  // B fragment: column n = lane&15 of n-tile nt, k = kc0 + 8g..8g+7
+  const bf16* b_base = wk + ((size_t)(w_n * NT * 16 + m)) * KTOT + kc0 + g * 8;
 
   bf16x8 bcur[NT], bnxt[NT];
   auto load_b = [&](bf16x8 (&dst)[NT], int step) {
@@ -145,7 +150,7 @@ __global__ __launch_bounds__(IMGS * 2 * NW * 64) void conv5x5_igemm(
     int wtap = (MODE == MODE_DGRAD) ? (24 - tap) : tap;
 #pragma unroll
     for (int j = 0; j < NT; ++j)
-      dst[j] = *reinterpret_cast<const bf16x8*>(b_base + ((size_t)wtap * NC + j * 16) * KC + ks * 32);
+      dst[j] = *reinterpret_cast<const bf16x8*>(b_base + ((size_t)wtap * NC + j * 16) * KTOT + ks * 32);
   };
   load_b(bcur, 0);
   constexpr int NSTEPS = 25 * KSTEPS;
@@ -166,6 +171,7 @@ __global__ __launch_bounds__(IMGS * 2 * NW * 64) void conv5x5_igemm(
 #pragma unroll
     for (int j = 0; j < NT; ++j) bcur[j] = bnxt[j];
   }
+  }  // K chunks
 
   // ---- epilogue ----
   const int b = img0 + w_img;
@@ -379,13 +385,13 @@ using namespace dtf;
 
 #define DTF_LAUNCH_CHECK() (int)hipGetLastError()
 
-template <int KC, int NC, int IMGS, int NW, int MODE>
+template <int KTOT, int KC, int NC, int IMGS, int NW, int MODE>
 static int launch_igemm(const void* in, const void* in_arg, const void* in_pooled, const void* wk,
                         const void* bias, void* out, void* out_arg, int B, hipStream_t s) {
   constexpr int threads = IMGS * 2 * NW * 64;
   constexpr int KP = (KC % 64 == 0) ? KC + 8 : KC;
   constexpr size_t lds = (size_t)IMGS * kTilePos * KP * 2;
-  auto kern = conv5x5_igemm<KC, NC, IMGS, NW, MODE>;
+  auto kern = conv5x5_igemm<KTOT, KC, NC, IMGS, NW, MODE>;
   static bool attr_set = false;
   if (!attr_set) {
     (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -404,9 +410,9 @@ extern "C" {
 int dtf_conv2_fwd(const void* x, const void* wT, const void* bias, void* pooled, void* arg, int B,
                   int cin, int cout, hipStream_t s) {
   if (cin == 32 && cout == 64)
-    return launch_igemm<32, 64, 1, 2, MODE_FWD>(x, nullptr, nullptr, wT, bias, pooled, arg, B, s);
+    return launch_igemm<32, 32, 64, 1, 2, MODE_FWD>(x, nullptr, nullptr, wT, bias, pooled, arg, B, s);
   if (cin == 128 && cout == 256)
-    return launch_igemm<128, 256, 1, 4, MODE_FWD>(x, nullptr, nullptr, wT, bias, pooled, arg, B, s);
+    return launch_igemm<128, 128, 256, 1, 4, MODE_FWD>(x, nullptr, nullptr, wT, bias, pooled, arg, B, s);
   return -1;
 }
 
@@ -414,9 +420,9 @@ int dtf_conv2_fwd(const void* x, const void* wT, const void* bias, void* pooled,
 int dtf_conv2_dgrad(const void* gpool, const void* arg, const void* pooled, const void* w, void* dx,
                     int B, int cin, int cout, hipStream_t s) {
   if (cin == 32 && cout == 64)
-    return launch_igemm<64, 32, 1, 2, MODE_DGRAD>(gpool, arg, pooled, w, nullptr, dx, nullptr, B, s);
+    return launch_igemm<64, 64, 32, 1, 2, MODE_DGRAD>(gpool, arg, pooled, w, nullptr, dx, nullptr, B, s);
   if (cin == 128 && cout == 256)
-    return -1;  // TODO(wide): KC=256 tile (173 KB) exceeds LDS; needs a K-chunked dgrad
+    return launch_igemm<256, 128, 128, 1, 2, MODE_DGRAD>(gpool, arg, pooled, w, nullptr, dx, nullptr, B, s);
   return -1;
 }
 

@@ -153,3 +153,24 @@ def test_cli_trains_on_gpu(gpu_lib, tmp_path):
     from distributed_tensorflow_amd.checkpoint import read_bundle
     ck = read_bundle(os.path.join(logdir, "model.ckpt-300"))
     assert int(ck["Variable_8"]) == 300 and ck["Variable_1"].shape == (5, 5, 32, 64)
+
+
+def test_wide_model_step_matches_oracle(gpu_lib, dataset):
+    """BASELINE.json config #5: widened CNN (conv 128/256, fc4096) through the same kernels."""
+    from distributed_tensorflow_amd.engine import HipEngine
+    spec = ModelSpec.wide()
+    B = 24
+    eng = HipEngine(spec, B, dataset, optimizer="sgd", learning_rate=0.001, seed=8)
+    eng.init_params()
+    oracle = OracleModel(spec, device="cuda", optimizer="sgd", learning_rate=0.001)
+    oracle.load_params(eng.export_params())
+    idx = torch.as_tensor(batch_indices(0, B, dataset.n, 8), device="cuda")
+    loss_ref, _ = oracle.compute_gradients(dataset.images[idx].float(), dataset.labels[idx])
+    eng.launch_train_step()
+    torch.cuda.synchronize()
+    loss, _ = eng.last_metrics()
+    assert abs(loss - loss_ref) / abs(loss_ref) < 3e-2, (loss, loss_ref)
+    g_ref, g = oracle.grads(), eng.export_grads()
+    for name in eng.layout.names():
+        e = rel_err(g[name], g_ref[name])
+        assert e < 6e-2, (name, e)

@@ -139,7 +139,7 @@ def test_conv2_fwd(gpu_lib, B, C1, C2):
     assert agree > 0.99, agree
 
 
-@pytest.mark.parametrize("B,C1,C2", [(1, 32, 64), (5, 32, 64), (32, 32, 64)])
+@pytest.mark.parametrize("B,C1,C2", [(1, 32, 64), (5, 32, 64), (32, 32, 64), (3, 128, 256)])
 def test_conv2_backward(gpu_lib, B, C1, C2):
     g, x, w, b = _conv2_inputs(B, C1, C2, 4)
     xf = x.float().requires_grad_(True)
