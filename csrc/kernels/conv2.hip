@@ -27,6 +27,13 @@
 //   by reduce_partials (optim.hip).
 #include "common.hpp"
 
+// Timing-ablation hook (tools/conv_ablate.py builds diagnostic copies with -DDTF_ABLATE=<bits>;
+// the shipped library always has 0): 1 = no B global loads in the k-loop, 2 = no A LDS reads,
+// 4 = no MFMAs, 8 = no staging loads, 16 = no epilogue stores.
+#ifndef DTF_ABLATE
+#define DTF_ABLATE 0
+#endif
+
 namespace dtf {
 
 constexpr int kTileW = 18;          // 14 + 2*2 halo
@@ -101,7 +108,7 @@ __global__ __launch_bounds__(IMGS * 2 * NW * 64) void conv5x5_igemm(
       int pos = (c / CH8) % 196;
       int im = c / (CH8 * 196);
       int b = img0 + im;
-      if (b < B) {
+      if (b < B && !(DTF_ABLATE & 8)) {
         u32x4 v = *reinterpret_cast<const u32x4*>(in + ((size_t)b * 196 + pos) * KTOT + kc0 + ch * 8);
         int y = pos / 14, x = pos % 14;
         int tp = (y + 2) * kTileW + (x + 2);
@@ -156,20 +163,25 @@ __global__ __launch_bounds__(IMGS * 2 * NW * 64) void conv5x5_igemm(
   constexpr int NSTEPS = 25 * KSTEPS;
 #pragma unroll 1
   for (int step = 0; step < NSTEPS; ++step) {
-    if (step + 1 < NSTEPS) load_b(bnxt, step + 1);
+    if (!(DTF_ABLATE & 1) && step + 1 < NSTEPS) load_b(bnxt, step + 1);
     const int tap = step / KSTEPS, ks = step % KSTEPS;
     const int ky = tap / 5, kx = tap % 5;
     const bf16* ap = a_base + (ky * kTileW + kx) * KP + ks * 32;
     bf16x8 a[7];
 #pragma unroll
     for (int i = 0; i < 7; ++i)
-      a[i] = *reinterpret_cast<const bf16x8*>(ap + i * (2 * kTileW * KP));
+      a[i] = *reinterpret_cast<const bf16x8*>((DTF_ABLATE & 2) ? a_base + i * 8 : ap + i * (2 * kTileW * KP));
 #pragma unroll
     for (int i = 0; i < 7; ++i)
 #pragma unroll
-      for (int j = 0; j < NT; ++j) acc[i][j] = mfma16(a[i], bcur[j], acc[i][j]);
+      for (int j = 0; j < NT; ++j) {
+        if (DTF_ABLATE & 4) { asm volatile("" ::"v"(a[i]), "v"(bcur[j])); }
+        else acc[i][j] = mfma16(a[i], bcur[j], acc[i][j]);
+      }
+    if (!(DTF_ABLATE & 1)) {
 #pragma unroll
-    for (int j = 0; j < NT; ++j) bcur[j] = bnxt[j];
+      for (int j = 0; j < NT; ++j) bcur[j] = bnxt[j];
+    }
   }
   }  // K chunks
 
@@ -194,6 +206,7 @@ __global__ __launch_bounds__(IMGS * 2 * NW * 64) void conv5x5_igemm(
         if (v[3] > best) { best = v[3]; bi = 3; }
         float o = fmaxf(best + bv, 0.f);
         size_t off = (((size_t)b * 7 + i) * 7 + ewin) * NC + n;
+        if ((DTF_ABLATE & 16) && o != -1.f) continue;
         out[off] = (bf16)o;
         out_arg[off] = (uint8_t)bi;
       }

@@ -210,6 +210,46 @@ class HipBackend(Backend):
         e.state[e.STATE_ADAM_T] = int(state.get("t", 0))
 
 
+class TorchBackend(CpuBackend):
+    """Reference backend: the fp32 PyTorch oracle on the GPU (ATen -> MIOpen / hipBLASLt).  Not the
+    product path -- it exists to give the fp32 configuration and an on-device baseline that the
+    hand-written kernel engine is measured against (bench/torch_reference.py)."""
+
+    name = "torch"
+
+    def __init__(self, spec, batch, data, optimizer="sgd", learning_rate=1e-3, keep_prob=1.0, seed=0,
+                 device="cuda", autocast_bf16=False):
+        from .data.sampler import batch_indices
+        self._batch_indices = batch_indices
+        self.spec, self.batch, self.data = spec, batch, data
+        self.model = OracleModel(spec, device=device, seed=seed, optimizer=optimizer, learning_rate=learning_rate,
+                                 keep_prob=keep_prob)
+        self.layout = self.model.layout
+        self.device = torch.device(device)
+        self.images = torch.from_numpy(data.train.images).to(self.device)
+        self.labels = torch.from_numpy(data.train.int_labels.astype(np.int64)).to(self.device)
+        self.seed, self.cursor = seed, 0
+        self.autocast_bf16 = autocast_bf16
+        self._metrics = (float("nan"), float("nan"))
+
+    def compute_gradients(self):
+        n = self.images.shape[0]
+        idx = torch.as_tensor(self._batch_indices(self.cursor, self.batch, n, self.seed), device=self.device)
+        self.cursor += self.batch
+        with torch.autocast("cuda", dtype=torch.bfloat16, enabled=self.autocast_bf16):
+            self._metrics = self.model.compute_gradients(self.images[idx], self.labels[idx])
+
+    def evaluate(self, split: str = "test"):
+        ds = getattr(self.data, split)
+        x = torch.from_numpy(ds.images).to(self.device)
+        y = torch.from_numpy(ds.int_labels.astype(np.int64)).to(self.device)
+        l, a = self.model.loss_and_accuracy(x, y)
+        return float(l), float(a)
+
+    def synchronize(self):
+        torch.cuda.synchronize(self.device)
+
+
 def make_backend(kind: str, spec: ModelSpec, batch: int, data: Datasets, **kw) -> Backend:
     if kind == "auto":
         kind = "hip" if torch.cuda.is_available() else "cpu"
@@ -219,4 +259,7 @@ def make_backend(kind: str, spec: ModelSpec, batch: int, data: Datasets, **kw) -
         kw.pop("device", None)
         kw.pop("use_graph", None)
         return CpuBackend(spec, batch, data, **kw)
+    if kind in ("torch", "torch_bf16"):
+        kw.pop("use_graph", None)
+        return TorchBackend(spec, batch, data, autocast_bf16=(kind == "torch_bf16"), **kw)
     raise ValueError(f"unknown backend {kind!r}")

@@ -80,7 +80,7 @@ class HipEngine:
     def __init__(self, spec: ModelSpec, batch: int, dataset: Optional[DeviceDataset] = None,
                  optimizer: str = "sgd", learning_rate: float = 1e-3, keep_prob: float = 1.0,
                  seed: int = 0, device="cuda", grad_scale: float = 1.0, shuffle: bool = True,
-                 adam_betas=(0.9, 0.999), adam_eps: float = 1e-8, step_inc: int = 1):
+                 adam_betas=(0.9, 0.999), adam_eps: float = 1e-8, step_inc: int = 1, multi_stream: bool = True):
         if not torch.cuda.is_available():
             raise RuntimeError("HipEngine needs a GPU (use backend='cpu' / models.oracle on CPU)")
         self.lib = native.load()
@@ -148,6 +148,12 @@ class HipEngine:
 
         self._graph = None
         self._graph_stream = None
+        # fork/join side streams for the independent branches of backward
+        self.multi_stream = bool(multi_stream)
+        self._side1 = torch.cuda.Stream(dev)
+        self._side2 = torch.cuda.Stream(dev)
+        self._ev_head, self._ev_fork = torch.cuda.Event(), torch.cuda.Event()
+        self._ev_join1, self._ev_join2 = torch.cuda.Event(), torch.cuda.Event()
 
     # ------------------------------------------------------------------ utils
     def _s(self) -> int:
@@ -250,17 +256,49 @@ class HipEngine:
                               sp.flat, sp.hidden, sp.hidden, 0, s), "fc1_wgrad")
 
     def launch_backward_conv(self, images: torch.Tensor, idx: Optional[torch.Tensor]):
+        """fc1 dgrad -> {conv2 dgrad -> conv1 wgrad} || conv2 wgrad -> slab reduce.
+
+        conv2's two gradient kernels only share inputs, so the filter gradient runs on a side
+        stream next to the data gradient (a fork/join that HIP-graph capture preserves): both are
+        latency-bound at this size and co-scheduling them fills the machine."""
         lib, sp, s, B = self.lib, self.spec, self._s(), self.B
+        cur = torch.cuda.current_stream(self.device)
         check(lib.dtf_gemm_nt(ptr(self.da), self._pptr(self.shadow, "wd1"), ptr(self.dflat), None, B, sp.flat,
                               sp.hidden, sp.hidden, sp.hidden, sp.flat, 0, 1.0, 0, None, 0, s), "fc1_dgrad")
+        if self.multi_stream:
+            self._ev_fork.record(cur)
+            self._side2.wait_event(self._ev_fork)
+            s2 = self._side2.cuda_stream
+        else:
+            s2 = s
+        check(lib.dtf_conv2_wgrad(ptr(self.p1), ptr(self.dflat), ptr(self.arg2), ptr(self.p2), ptr(self.c2_part), B,
+                                  sp.c1, sp.c2, self.c2_g, s2), "conv2_wgrad")
+        if self.multi_stream:
+            self._ev_join2.record(self._side2)
         check(lib.dtf_conv2_dgrad(ptr(self.dflat), ptr(self.arg2), ptr(self.p2), self._pptr(self.shadow, "wc2"),
                                   ptr(self.dp1), B, sp.c1, sp.c2, s), "conv2_dgrad")
-        check(lib.dtf_conv2_wgrad(ptr(self.p1), ptr(self.dflat), ptr(self.arg2), ptr(self.p2), ptr(self.c2_part), B,
-                                  sp.c1, sp.c2, self.c2_g, s), "conv2_wgrad")
         check(lib.dtf_conv1_wgrad(ptr(images), ptr(idx), ptr(self.dp1), ptr(self.arg1), ptr(self.p1),
                                   ptr(self.c1_part), B, sp.c1, self.c1_g, s), "conv1_wgrad")
+        if self.multi_stream:
+            cur.wait_event(self._ev_join2)
         self._reduce([(self.c2_part, self.c2_g, self._c2_seg, self.c2_stride),
                       (self.c1_part, self.c1_g, self._c1_seg, self.c1_stride)])
+
+    def launch_backward(self, images: torch.Tensor, idx: Optional[torch.Tensor]):
+        """Whole backward with the dense-layer weight gradients (head + fc1 wgrad) on a side stream
+        concurrent with the conv chain.  Returns after joining: the grad arena is final."""
+        if not self.multi_stream:
+            self.launch_backward_dense()
+            self.launch_backward_conv(images, idx)
+            return
+        cur = torch.cuda.current_stream(self.device)
+        self._ev_head.record(cur)
+        self._side1.wait_event(self._ev_head)
+        with torch.cuda.stream(self._side1):
+            self.launch_backward_dense()
+            self._ev_join1.record(self._side1)
+        self.launch_backward_conv(images, idx)
+        cur.wait_event(self._ev_join1)
 
     def launch_update(self, advance_cursor: bool = True):
         lib, s = self.lib, self._s()
@@ -281,16 +319,14 @@ class HipEngine:
         ds = self.dataset
         self.launch_sample()
         self.launch_forward(ds.images, ds.labels, self.idx, backward=True)
-        self.launch_backward_dense()
-        self.launch_backward_conv(ds.images, self.idx)
+        self.launch_backward(ds.images, self.idx)
         self.launch_update()
 
     def train_step_on(self, images: torch.Tensor, labels: torch.Tensor):
         """One step on an explicit batch (bf16 [B,784], int32 [B]) -- the feed_dict path."""
         assert images.shape[0] == self.B
         self.launch_forward(images, labels, None, backward=True)
-        self.launch_backward_dense()
-        self.launch_backward_conv(images, None)
+        self.launch_backward(images, None)
         self.launch_update(advance_cursor=False)
 
     def capture(self, warmup: int = 1):

@@ -63,7 +63,7 @@ def run(F, log=print) -> dict:
     if mode == "async" and task.num_ps == 0:
         raise SystemExit("--mode=async needs at least one ps task (--ps_hosts)")
 
-    if kind == "hip":
+    if kind in ("hip", "torch", "torch_bf16"):
         local_rank = int(os.environ.get("LOCAL_RANK", F.local_rank if F.local_rank >= 0 else task.rank))
         local_rank %= max(1, torch.cuda.device_count())
         torch.cuda.set_device(local_rank)
@@ -75,7 +75,7 @@ def run(F, log=print) -> dict:
         host, port = task.cluster.master()
         backend_name = "gloo" if kind == "cpu" else "cpu:gloo,cuda:nccl"
         comm.init_process_group(backend_name, task.rank, world, master_addr=host, master_port=port,
-                                device=device if kind == "hip" else None, timeout_s=F.comm_timeout)
+                                device=device if kind != "cpu" else None, timeout_s=F.comm_timeout)
 
     spec = ModelSpec.from_name(F.model)
     data = read_data_sets(F.data_dir, one_hot=(kind == "cpu"), synthetic=F.synthetic,

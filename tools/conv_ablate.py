@@ -1,0 +1,34 @@
+"""Ablation timing of the conv2 forward kernel: builds diagnostic copies of conv2.hip with parts
+of the kernel removed (-DDTF_ABLATE bits, see conv2.hip) and times each on the GPU.
+Build step runs on the CPU box: python tools/conv_ablate.py build ; timing: ... run"""
+import ctypes, os, subprocess, sys, time
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+OUT = os.path.join(ROOT, "diag_build")
+VARIANTS = {0: "full", 1: "no B loads", 2: "no A reads", 4: "no MFMA", 8: "no staging loads", 16: "no epilogue stores",
+            3: "no A, no B", 7: "no A,B,MFMA", 31: "empty shell"}
+if sys.argv[1] == "build":
+    os.makedirs(OUT, exist_ok=True)
+    for v in VARIANTS:
+        subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",
+                               f"-DDTF_ABLATE={v}", "-I", ROOT + "/csrc/kernels", ROOT + "/csrc/kernels/conv2.hip",
+                               "-o", f"{OUT}/conv2_ab{v}.so"])
+    print("built", len(VARIANTS))
+else:
+    import torch
+    B = 1024
+    x = torch.rand(B, 14, 14, 32, device="cuda").bfloat16()
+    wT = torch.randn(25, 64, 32, device="cuda").bfloat16()
+    bias = torch.zeros(64, device="cuda")
+    pooled = torch.empty(B, 7, 7, 64, device="cuda", dtype=torch.bfloat16)
+    arg = torch.empty(B, 7, 7, 64, device="cuda", dtype=torch.uint8)
+    s = torch.cuda.current_stream().cuda_stream
+    for v, name in VARIANTS.items():
+        lib = ctypes.CDLL(f"{OUT}/conv2_ab{v}.so")
+        f = lib.dtf_conv2_fwd
+        f.argtypes = [ctypes.c_void_p] * 5 + [ctypes.c_int] * 3 + [ctypes.c_void_p]
+        call = lambda: f(x.data_ptr(), wT.data_ptr(), bias.data_ptr(), pooled.data_ptr(), arg.data_ptr(), B, 32, 64, s)
+        for _ in range(5): call()
+        torch.cuda.synchronize(); t0 = time.perf_counter()
+        for _ in range(50): call()
+        torch.cuda.synchronize()
+        print(f"ablate={v:2d} {name:22s} {(time.perf_counter()-t0)/50*1e6:7.1f} us")
