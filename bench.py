@@ -61,7 +61,7 @@ def main():
     eng.init_params(seed=7)
 
     if world > 1:
-        dp = SyncDataParallel(eng)
+        dp = SyncDataParallel(eng, tail_group=torch.distributed.new_group())
         dp.broadcast_parameters()
         step = dp.train_step
     else:

@@ -1,0 +1,36 @@
+// C ABI of the kernel launchers (defined in the .hip files of this directory).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+extern "C" {
+int dtf_conv1_fwd(const void* images, const void* idx, const void* w, const void* bias, void* pooled, void* arg,
+                  int B, int cout, int grid, hipStream_t s);
+int dtf_conv1_wgrad(const void* images, const void* idx, const void* gpool, const void* arg, const void* pooled,
+                    void* part, int B, int cout, int grid, hipStream_t s);
+int dtf_conv2_fwd(const void* x, const void* wT, const void* bias, void* pooled, void* arg, int B, int cin, int cout,
+                  hipStream_t s);
+int dtf_conv2_dgrad(const void* gpool, const void* arg, const void* pooled, const void* w, void* dx, int B, int cin,
+                    int cout, hipStream_t s);
+int dtf_conv2_wgrad(const void* x, const void* gpool, const void* arg, const void* pooled, void* part, int B, int cin,
+                    int cout, int G, hipStream_t s);
+int dtf_gemm_nt(const void* A, const void* B, void* C, const void* bias, int M, int N, int K, int lda, int ldb,
+                int ldc, int epi, float keep_prob, uint64_t seed, const void* state, int tile, hipStream_t s);
+int dtf_gemm_tn(const void* A, const void* B, void* C, int M, int N, int K, int lda, int ldb, int ldc, int tile,
+                hipStream_t s);
+int dtf_transpose_bf16(const void* in, void* out, int batch, int R, int C, hipStream_t s);
+int dtf_head_fwd_bwd(const void* h1, const void* w, const void* bias, const void* labels, const void* idx,
+                     void* logits_out, void* loss_rows, void* correct_rows, void* dlogits, void* da, int B, int H,
+                     float grad_scale, float inv_keep, int backward, hipStream_t s);
+int dtf_head_wgrad(const void* h1, const void* dlogits, const void* da, void* part, int B, int H, int KS,
+                   hipStream_t s);
+int dtf_sgd_update(void* w, const void* g, void* shadow, const void* hyper, long n, void* state, long cursor_inc,
+                   long step_inc, long drop_inc, hipStream_t s);
+int dtf_adam_update(void* w, const void* g, void* m, void* v, void* shadow, const void* hyper, long n, void* tstate,
+                    int adam_slot, void* state, long cursor_inc, long step_inc, long drop_inc, hipStream_t s);
+int dtf_cast_bf16(const void* w, void* shadow, long n, hipStream_t s);
+int dtf_reduce_segments(int count, const void** part, void** out, const int* G, const int* n, const long* stride,
+                        hipStream_t s);
+int dtf_sample_indices(const void* state, void* idx, int B, unsigned n, unsigned hb, unsigned seed, int shuffle,
+                       hipStream_t s);
+}

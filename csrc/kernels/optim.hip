@@ -16,19 +16,22 @@
 namespace dtf {
 
 // hyper[0]=lr [1]=beta1 [2]=beta2 [3]=eps [4]=grad_scale (e.g. 1/world) [5]=weight_decay
-// state[0]=sample cursor  [1]=global_step  [2]=dropout offset  [3]=adam t
+// state[0]=sample cursor  [1]=global_step  [2]=dropout offset  [3..]=adam t counters (one per
+// independently updated arena range, so range updates on different streams never share a word)
 struct StepAdvance {
-  int64_t* state;
+  int64_t* state;       // nullptr -> no advance
   int64_t cursor_inc;
   int64_t step_inc;
+  int64_t drop_inc;
+  int adam_slot;        // >= 3 -> state[adam_slot] += 1
 };
 
 __device__ __forceinline__ void advance_state(const StepAdvance& a) {
   if (a.state && blockIdx.x == 0 && threadIdx.x == 0) {
     a.state[0] += a.cursor_inc;
     a.state[1] += a.step_inc;
-    a.state[2] += 1;
-    a.state[3] += 1;
+    a.state[2] += a.drop_inc;
+    if (a.adam_slot >= 3) a.state[a.adam_slot] += 1;
   }
 }
 
@@ -59,9 +62,9 @@ __global__ __launch_bounds__(256) void sgd_update(float* __restrict__ w, const f
 __global__ __launch_bounds__(256) void adam_update(float* __restrict__ w, const float* __restrict__ g,
                                                    float* __restrict__ m, float* __restrict__ v,
                                                    bf16* __restrict__ shadow, const float* __restrict__ hyper,
-                                                   long n4, StepAdvance adv) {
+                                                   long n4, const int64_t* __restrict__ tptr) {
   const float lr = hyper[0], b1 = hyper[1], b2 = hyper[2], eps = hyper[3], gs = hyper[4];
-  const float t = (float)(adv.state ? adv.state[3] + 1 : 1);
+  const float t = (float)(tptr ? *tptr + 1 : 1);
   const float lr_t = lr * sqrtf(1.f - powf(b2, t)) / (1.f - powf(b1, t));
   for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long)gridDim.x * blockDim.x) {
     f32x4 wv = reinterpret_cast<const f32x4*>(w)[i];
@@ -80,8 +83,8 @@ __global__ __launch_bounds__(256) void adam_update(float* __restrict__ w, const 
     reinterpret_cast<f32x4*>(v)[i] = vv;
     if (shadow) store_bf16x4(shadow + 4 * i, wv[0], wv[1], wv[2], wv[3]);
   }
-  // state[3] is read by every block above, so it is bumped by a trailing
-  // 1-thread kernel (dtf_adam_update) rather than by whichever block ends first.
+  // *tptr is read by every block above, so it is bumped by a trailing 1-thread kernel
+  // (dtf_adam_update) rather than by whichever block ends first.
 }
 
 __global__ void advance_state_kernel(StepAdvance adv) { advance_state(adv); }
@@ -150,27 +153,32 @@ static int grid_for(long n4) {
   return (int)(b > 2048 ? 2048 : (b < 1 ? 1 : b));
 }
 
+// Updates n floats at w/g (any 16-byte aligned sub-range of the arena).  state == NULL: no advance.
 int dtf_sgd_update(void* w, const void* g, void* shadow, const void* hyper, long n, void* state,
-                   long cursor_inc, long step_inc, hipStream_t s) {
+                   long cursor_inc, long step_inc, long drop_inc, hipStream_t s) {
   if (n & 3) return -3;
-  StepAdvance adv{(int64_t*)state, cursor_inc, step_inc};
+  StepAdvance adv{(int64_t*)state, cursor_inc, step_inc, drop_inc, -1};
   hipLaunchKernelGGL(sgd_update, dim3(grid_for(n / 4)), dim3(256), 0, s, (float*)w, (const float*)g,
                      (bf16*)shadow, (const float*)hyper, n / 4, adv);
   return (int)hipGetLastError();
 }
 
+// tstate: the device step-state array; Adam's t for this range is tstate[adam_slot] (bumped after
+// the update).  state == NULL: cursor/global_step/dropout are left alone.
 int dtf_adam_update(void* w, const void* g, void* m, void* v, void* shadow, const void* hyper, long n,
-                    void* state, long cursor_inc, long step_inc, hipStream_t s) {
-  if (n & 3) return -3;
-  StepAdvance adv{(int64_t*)state, cursor_inc, step_inc};
+                    void* tstate, int adam_slot, void* state, long cursor_inc, long step_inc, long drop_inc,
+                    hipStream_t s) {
+  if ((n & 3) || adam_slot < 3 || adam_slot > 7 || !tstate) return -3;
   hipLaunchKernelGGL(adam_update, dim3(grid_for(n / 4)), dim3(256), 0, s, (float*)w, (const float*)g,
-                     (float*)m, (float*)v, (bf16*)shadow, (const float*)hyper, n / 4, adv);
-  if (state) hipLaunchKernelGGL(advance_state_kernel, dim3(1), dim3(1), 0, s, adv);
+                     (float*)m, (float*)v, (bf16*)shadow, (const float*)hyper, n / 4,
+                     (const int64_t*)tstate + adam_slot);
+  StepAdvance adv{(int64_t*)tstate, state ? cursor_inc : 0, state ? step_inc : 0, state ? drop_inc : 0, adam_slot};
+  hipLaunchKernelGGL(advance_state_kernel, dim3(1), dim3(1), 0, s, adv);
   return (int)hipGetLastError();
 }
 
-int dtf_advance_state(void* state, long cursor_inc, long step_inc, hipStream_t s) {
-  StepAdvance adv{(int64_t*)state, cursor_inc, step_inc};
+int dtf_advance_state(void* state, long cursor_inc, long step_inc, long drop_inc, hipStream_t s) {
+  StepAdvance adv{(int64_t*)state, cursor_inc, step_inc, drop_inc, -1};
   hipLaunchKernelGGL(advance_state_kernel, dim3(1), dim3(1), 0, s, adv);
   return (int)hipGetLastError();
 }

@@ -1,0 +1,166 @@
+// Native step executor: the whole training step (sampler, forward, loss, backward with its
+// fork/join side streams, slab reductions, optimizer, shadow refresh) is issued from C++ so one
+// foreign call from Python enqueues a phase.  This is the replacement for the TF C++ executor that
+// runs the reference's `sess.run([optimizer, global_step], feed_dict)` (reference
+// .idea/MNISTDist.py:188): Python only decides WHAT to run; launching, stream forks/joins and
+// event plumbing are native.  Everything is enqueue-only (no allocation, no sync), so any phase
+// can be captured into a HIP graph.
+#include "api.h"
+
+extern "C" {
+
+// Plain-old-data description of one engine instance; mirrored by ctypes in engine.py.
+struct DtfEngineDesc {
+  // model / batch
+  int B, c1, c2, hidden, flat, classes;
+  int head_ks, c2_g, c1_g, optimizer /*0 sgd, 1 adam*/, shuffle, multi_stream;
+  unsigned ds_n, ds_hb, sample_seed, pad0;
+  uint64_t seed;
+  float keep_prob, pad1;
+  long n_total;
+  long off_out_w, off_out_b, off_bd1, off_wd1, off_wc2, off_bc2, off_wc1, off_bc1;  // float offsets in the arena
+  long head_stride, c2_stride, c1_stride;
+  // device buffers
+  void *params, *grads, *shadow, *wd1T, *wc2T, *adam_m, *adam_v, *state, *hyper;
+  void *idx, *p1, *arg1, *p2, *arg2, *h1, *logits, *loss_rows, *correct_rows, *dlogits, *da, *dflat, *dp1;
+  void *head_part, *c2_part, *c1_part;
+  void *ds_images, *ds_labels;
+  // native-owned handles (filled by dtf_engine_init)
+  hipStream_t side1, side2;
+  hipEvent_t ev_head, ev_fork, ev_join1, ev_join2, ev_dgrad;
+};
+
+#define DTF_TRY(x)            \
+  do {                        \
+    int rc_ = (x);            \
+    if (rc_ != 0) return rc_; \
+  } while (0)
+#define HIP_TRY(x)                          \
+  do {                                      \
+    hipError_t e_ = (x);                    \
+    if (e_ != hipSuccess) return (int)e_;   \
+  } while (0)
+
+static inline float* f32at(void* base, long off) { return (float*)base + off; }
+static inline char* bf16at(void* base, long off) { return (char*)base + 2 * off; }
+
+int dtf_engine_init(DtfEngineDesc* e) {
+  HIP_TRY(hipStreamCreateWithFlags(&e->side1, hipStreamNonBlocking));
+  HIP_TRY(hipStreamCreateWithFlags(&e->side2, hipStreamNonBlocking));
+  hipEvent_t* evs[5] = {&e->ev_head, &e->ev_fork, &e->ev_join1, &e->ev_join2, &e->ev_dgrad};
+  for (auto ev : evs) HIP_TRY(hipEventCreateWithFlags(ev, hipEventDisableTiming));
+  return 0;
+}
+
+int dtf_engine_destroy(DtfEngineDesc* e) {
+  hipEvent_t evs[5] = {e->ev_head, e->ev_fork, e->ev_join1, e->ev_join2, e->ev_dgrad};
+  for (auto ev : evs)
+    if (ev) (void)hipEventDestroy(ev);
+  if (e->side1) (void)hipStreamDestroy(e->side1);
+  if (e->side2) (void)hipStreamDestroy(e->side2);
+  return 0;
+}
+
+int dtf_stream_wait_event(hipStream_t s, hipEvent_t ev) { return (int)hipStreamWaitEvent(s, ev, 0); }
+int dtf_event_record(hipEvent_t ev, hipStream_t s) { return (int)hipEventRecord(ev, s); }
+
+int dtf_engine_sample(const DtfEngineDesc* e, hipStream_t s) {
+  return dtf_sample_indices(e->state, e->idx, e->B, e->ds_n, e->ds_hb, e->sample_seed, e->shuffle, s);
+}
+
+int dtf_engine_forward_conv(const DtfEngineDesc* e, const void* images, const void* idx, int n, hipStream_t s) {
+  DTF_TRY(dtf_conv1_fwd(images, idx, f32at(e->params, e->off_wc1), f32at(e->params, e->off_bc1), e->p1, e->arg1, n,
+                        e->c1, 0, s));
+  return dtf_conv2_fwd(e->p1, e->wc2T, f32at(e->params, e->off_bc2), e->p2, e->arg2, n, e->c1, e->c2, s);
+}
+
+int dtf_engine_forward_dense(const DtfEngineDesc* e, const void* labels, const void* idx, int backward, int n,
+                             int train_mode, hipStream_t s) {
+  const float keep = train_mode ? e->keep_prob : 1.0f;
+  DTF_TRY(dtf_gemm_nt(e->p2, e->wd1T, e->h1, f32at(e->params, e->off_bd1), n, e->hidden, e->flat, e->flat, e->flat,
+                      e->hidden, 1, keep, e->seed, e->state, 0, s));
+  return dtf_head_fwd_bwd(e->h1, f32at(e->params, e->off_out_w), f32at(e->params, e->off_out_b), labels, idx,
+                          e->logits, e->loss_rows, e->correct_rows, e->dlogits, e->da, n, e->hidden, 1.0f / n,
+                          1.0f / keep, backward, s);
+}
+
+// head wgrad + slab reduce + fc1 wgrad: finalises the (head | wd1) prefix of the gradient arena
+int dtf_engine_backward_dense(const DtfEngineDesc* e, hipStream_t s) {
+  DTF_TRY(dtf_head_wgrad(e->h1, e->dlogits, e->da, e->head_part, e->B, e->hidden, e->head_ks, s));
+  const void* part[1] = {e->head_part};
+  void* out[1] = {f32at(e->grads, e->off_out_w)};
+  int G[1] = {e->head_ks}, n[1] = {(int)e->head_stride};
+  long st[1] = {e->head_stride};
+  DTF_TRY(dtf_reduce_segments(1, part, out, G, n, st, s));
+  return dtf_gemm_tn(e->p2, e->da, f32at(e->grads, e->off_wd1), e->flat, e->hidden, e->B, e->flat, e->hidden,
+                     e->hidden, 0, s);
+}
+
+// fc1 dgrad -> {conv2 dgrad -> conv1 wgrad} || conv2 wgrad (side stream) -> slab reduce.
+// record_dgrad != 0: e->ev_dgrad is recorded right after fc1 dgrad (the last reader of bf16 wd1).
+int dtf_engine_backward_conv(const DtfEngineDesc* e, const void* images, const void* idx, int record_dgrad,
+                             hipStream_t s) {
+  DTF_TRY(dtf_gemm_nt(e->da, bf16at(e->shadow, e->off_wd1), e->dflat, nullptr, e->B, e->flat, e->hidden, e->hidden,
+                      e->hidden, e->flat, 0, 1.0f, 0, nullptr, 0, s));
+  if (record_dgrad) HIP_TRY(hipEventRecord(e->ev_dgrad, s));
+  hipStream_t s2 = s;
+  if (e->multi_stream) {
+    HIP_TRY(hipEventRecord(e->ev_fork, s));
+    HIP_TRY(hipStreamWaitEvent(e->side2, e->ev_fork, 0));
+    s2 = e->side2;
+  }
+  DTF_TRY(dtf_conv2_wgrad(e->p1, e->dflat, e->arg2, e->p2, e->c2_part, e->B, e->c1, e->c2, e->c2_g, s2));
+  if (e->multi_stream) HIP_TRY(hipEventRecord(e->ev_join2, s2));
+  DTF_TRY(dtf_conv2_dgrad(e->dflat, e->arg2, e->p2, bf16at(e->shadow, e->off_wc2), e->dp1, e->B, e->c1, e->c2, s));
+  DTF_TRY(dtf_conv1_wgrad(images, idx, e->dp1, e->arg1, e->p1, e->c1_part, e->B, e->c1, e->c1_g, s));
+  if (e->multi_stream) HIP_TRY(hipStreamWaitEvent(s, e->ev_join2, 0));
+  const void* part[2] = {e->c2_part, e->c1_part};
+  void* out[2] = {f32at(e->grads, e->off_wc2), f32at(e->grads, e->off_wc1)};
+  int G[2] = {e->c2_g, e->c1_g}, n[2] = {(int)e->c2_stride, (int)e->c1_stride};
+  long st[2] = {e->c2_stride, e->c1_stride};
+  return dtf_reduce_segments(2, part, out, G, n, st, s);
+}
+
+// whole backward; the dense-layer weight gradients run on side1 next to the conv chain
+int dtf_engine_backward(const DtfEngineDesc* e, const void* images, const void* idx, hipStream_t s) {
+  if (!e->multi_stream) {
+    DTF_TRY(dtf_engine_backward_dense(e, s));
+    return dtf_engine_backward_conv(e, images, idx, 0, s);
+  }
+  HIP_TRY(hipEventRecord(e->ev_head, s));
+  HIP_TRY(hipStreamWaitEvent(e->side1, e->ev_head, 0));
+  DTF_TRY(dtf_engine_backward_dense(e, e->side1));
+  HIP_TRY(hipEventRecord(e->ev_join1, e->side1));
+  DTF_TRY(dtf_engine_backward_conv(e, images, idx, 0, s));
+  return (int)hipStreamWaitEvent(s, e->ev_join1, 0);
+}
+
+int dtf_engine_update_range(const DtfEngineDesc* e, long lo, long hi, int advance, int advance_cursor, long step_inc,
+                            int adam_slot, hipStream_t s) {
+  const long n = hi - lo;
+  void* st = advance ? e->state : nullptr;
+  const long cinc = (advance && advance_cursor) ? e->B : 0;
+  if (e->optimizer == 0)
+    return dtf_sgd_update(f32at(e->params, lo), f32at(e->grads, lo), bf16at(e->shadow, lo), e->hyper, n, st, cinc,
+                          step_inc, 1, s);
+  return dtf_adam_update(f32at(e->params, lo), f32at(e->grads, lo), f32at(e->adam_m, lo), f32at(e->adam_v, lo),
+                         bf16at(e->shadow, lo), e->hyper, n, e->state, adam_slot, st, cinc, step_inc, 1, s);
+}
+
+int dtf_engine_transposes(const DtfEngineDesc* e, int wd1, int wc2, hipStream_t s) {
+  if (wd1) DTF_TRY(dtf_transpose_bf16(bf16at(e->shadow, e->off_wd1), e->wd1T, 1, e->flat, e->hidden, s));
+  if (wc2) DTF_TRY(dtf_transpose_bf16(bf16at(e->shadow, e->off_wc2), e->wc2T, 25, e->c1, e->c2, s));
+  return 0;
+}
+
+// one full optimisation step on the resident dataset
+int dtf_engine_train_step(const DtfEngineDesc* e, long step_inc, hipStream_t s) {
+  DTF_TRY(dtf_engine_sample(e, s));
+  DTF_TRY(dtf_engine_forward_conv(e, e->ds_images, e->idx, e->B, s));
+  DTF_TRY(dtf_engine_forward_dense(e, e->ds_labels, e->idx, 1, e->B, 1, s));
+  DTF_TRY(dtf_engine_backward(e, e->ds_images, e->idx, s));
+  DTF_TRY(dtf_engine_update_range(e, 0, e->n_total, 1, 1, step_inc, 3, s));
+  return dtf_engine_transposes(e, 1, 1, s);
+}
+
+}  // extern "C"

@@ -208,6 +208,7 @@ class HipBackend(Backend):
             self.layout.view(e.adam_m, n).copy_(torch.as_tensor(state["m"][n]).to(e.device))
             self.layout.view(e.adam_v, n).copy_(torch.as_tensor(state["v"][n]).to(e.device))
         e.state[e.STATE_ADAM_T] = int(state.get("t", 0))
+        e.state[e.STATE_ADAM_T2] = int(state.get("t", 0))
 
 
 class TorchBackend(CpuBackend):

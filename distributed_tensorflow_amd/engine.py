@@ -75,7 +75,7 @@ class DeviceDataset:
 
 
 class HipEngine:
-    STATE_CURSOR, STATE_STEP, STATE_DROPOUT, STATE_ADAM_T = 0, 1, 2, 3
+    STATE_CURSOR, STATE_STEP, STATE_DROPOUT, STATE_ADAM_T, STATE_ADAM_T2 = 0, 1, 2, 3, 4
 
     def __init__(self, spec: ModelSpec, batch: int, dataset: Optional[DeviceDataset] = None,
                  optimizer: str = "sgd", learning_rate: float = 1e-3, keep_prob: float = 1.0,
@@ -93,6 +93,7 @@ class HipEngine:
         self.shuffle = bool(shuffle)
         self.step_inc = int(step_inc)
         self.dataset = dataset
+        self.multi_stream = bool(multi_stream)
         dev, B, H, C1, C2, FLAT = self.device, self.B, spec.hidden, spec.c1, spec.c2, spec.flat
         n = self.layout.total
 
@@ -148,12 +149,44 @@ class HipEngine:
 
         self._graph = None
         self._graph_stream = None
-        # fork/join side streams for the independent branches of backward
-        self.multi_stream = bool(multi_stream)
-        self._side1 = torch.cuda.Stream(dev)
-        self._side2 = torch.cuda.Stream(dev)
-        self._ev_head, self._ev_fork = torch.cuda.Event(), torch.cuda.Event()
-        self._ev_join1, self._ev_join2 = torch.cuda.Event(), torch.cuda.Event()
+        self.multi_stream = bool(multi_stream)   # fork/join side streams inside backward (native)
+        self._build_desc()
+
+    def _build_desc(self):
+        """Fill the native executor's descriptor (csrc/runtime/engine.hip) once; every phase below is
+        then a single foreign call that enqueues all of its kernels / stream forks from C++."""
+        d = native.EngineDesc()
+        sp, lay = self.spec, self.layout
+        d.B, d.c1, d.c2, d.hidden, d.flat, d.classes = self.B, sp.c1, sp.c2, sp.hidden, sp.flat, sp.classes
+        d.head_ks, d.c2_g, d.c1_g = self.head_ks, self.c2_g, self.c1_g
+        d.optimizer = 0 if self.optimizer == "sgd" else 1
+        d.shuffle, d.multi_stream = int(self.shuffle), int(self.multi_stream)
+        d.sample_seed, d.seed, d.keep_prob = self.seed & 0xFFFFFFFF, self.seed & (2 ** 64 - 1), self.keep_prob
+        d.n_total = lay.total
+        for name in lay.names():
+            setattr(d, "off_" + name, lay.offsets[name])
+        d.head_stride, d.c2_stride, d.c1_stride = self.head_stride, self.c2_stride, self.c1_stride
+        for name in ("params", "grads", "shadow", "wd1T", "wc2T", "state", "hyper", "idx", "p1", "arg1", "p2", "arg2",
+                     "h1", "logits", "loss_rows", "correct_rows", "dlogits", "da", "dflat", "dp1", "head_part",
+                     "c2_part", "c1_part"):
+            setattr(d, name, getattr(self, name).data_ptr())
+        if self.optimizer == "adam":
+            d.adam_m, d.adam_v = self.adam_m.data_ptr(), self.adam_v.data_ptr()
+        self._desc = d
+        self._set_dataset(self.dataset)
+        check(self.lib.dtf_engine_init(ctypes.byref(d)), "engine_init")
+
+    def _set_dataset(self, ds: Optional[DeviceDataset]):
+        self.dataset = ds
+        if ds is not None:
+            self._desc.ds_images, self._desc.ds_labels = ds.images.data_ptr(), ds.labels.data_ptr()
+            self._desc.ds_n, self._desc.ds_hb = ds.n, _half_bits(ds.n)
+
+    def __del__(self):
+        try:
+            self.lib.dtf_engine_destroy(ctypes.byref(self._desc))
+        except Exception:
+            pass
 
     # ------------------------------------------------------------------ utils
     def _s(self) -> int:
@@ -208,119 +241,74 @@ class HipEngine:
         sp = self.spec
         if cast:
             check(self.lib.dtf_cast_bf16(ptr(self.params), ptr(self.shadow), self.layout.total, s), "cast_bf16")
-        check(self.lib.dtf_transpose_bf16(self._pptr(self.shadow, "wd1"), ptr(self.wd1T), 1, sp.flat, sp.hidden, s),
-              "transpose wd1")
-        check(self.lib.dtf_transpose_bf16(self._pptr(self.shadow, "wc2"), ptr(self.wc2T), 25, sp.c1, sp.c2, s),
-              "transpose wc2")
+        self.refresh_transposes()
 
     # ----------------------------------------------------------------- phases
+    # Each phase is ONE call into the native executor, which enqueues its kernels on the current
+    # stream (and forks/joins its own side streams).  No host synchronisation anywhere.
+    def _d(self):
+        return ctypes.byref(self._desc)
+
     def launch_sample(self):
-        ds = self.dataset
-        check(self.lib.dtf_sample_indices(ptr(self.state), ptr(self.idx), self.B, ds.n, _half_bits(ds.n),
-                                          self.seed & 0xFFFFFFFF, 1 if self.shuffle else 0, self._s()), "sample")
+        check(self.lib.dtf_engine_sample(self._d(), self._s()), "sample")
+
+    def launch_forward_conv(self, images: torch.Tensor, idx: Optional[torch.Tensor], n: Optional[int] = None):
+        """conv1 -> conv2 (reads only the conv parameters)."""
+        check(self.lib.dtf_engine_forward_conv(self._d(), ptr(images), ptr(idx), self.B if n is None else n,
+                                               self._s()), "forward_conv")
+
+    def launch_forward_dense(self, labels: torch.Tensor, idx: Optional[torch.Tensor], backward: bool,
+                             n: Optional[int] = None, train_mode: bool = True):
+        """fc1 -> head (loss/acc [+ dlogits, da]); reads the fc1 / head parameters."""
+        check(self.lib.dtf_engine_forward_dense(self._d(), ptr(labels), ptr(idx), int(backward),
+                                                self.B if n is None else n, int(train_mode), self._s()),
+              "forward_dense")
 
     def launch_forward(self, images: torch.Tensor, labels: torch.Tensor, idx: Optional[torch.Tensor],
                        backward: bool, n: Optional[int] = None, train_mode: bool = True):
         """conv1 -> conv2 -> fc1 -> head (loss/acc [+ dlogits, da])."""
-        lib, sp, s = self.lib, self.spec, self._s()
-        B = self.B if n is None else n
-        keep = self.keep_prob if train_mode else 1.0
-        check(lib.dtf_conv1_fwd(ptr(images), ptr(idx), self._pptr(self.params, "wc1"), self._pptr(self.params, "bc1"),
-                                ptr(self.p1), ptr(self.arg1), B, sp.c1, 0, s), "conv1_fwd")
-        check(lib.dtf_conv2_fwd(ptr(self.p1), ptr(self.wc2T), self._pptr(self.params, "bc2"), ptr(self.p2),
-                                ptr(self.arg2), B, sp.c1, sp.c2, s), "conv2_fwd")
-        check(lib.dtf_gemm_nt(ptr(self.p2), ptr(self.wd1T), ptr(self.h1), self._pptr(self.params, "bd1"), B,
-                              sp.hidden, sp.flat, sp.flat, sp.flat, sp.hidden, 1, keep, self.seed, ptr(self.state),
-                              0, s), "fc1_fwd")
-        check(lib.dtf_head_fwd_bwd(ptr(self.h1), self._pptr(self.params, "out_w"), self._pptr(self.params, "out_b"),
-                                   ptr(labels), ptr(idx), ptr(self.logits), ptr(self.loss_rows),
-                                   ptr(self.correct_rows), ptr(self.dlogits), ptr(self.da), B, sp.hidden,
-                                   1.0 / B, 1.0 / keep, 1 if backward else 0, s), "head")
-
-    def _reduce(self, segs):
-        k = len(segs)
-        parts = (ctypes.c_void_p * k)(*[p.data_ptr() for p, _, _, _ in segs])
-        outs = (ctypes.c_void_p * k)(*[self.grads.data_ptr() + 4 * lo for _, _, (lo, hi), _ in segs])
-        G = (ctypes.c_int * k)(*[g for _, g, _, _ in segs])
-        n = (ctypes.c_int * k)(*[hi - lo for _, _, (lo, hi), _ in segs])
-        st = (ctypes.c_long * k)(*[stride for _, _, _, stride in segs])
-        check(self.lib.dtf_reduce_segments(k, parts, outs, G, n, st, self._s()), "reduce_segments")
+        self.launch_forward_conv(images, idx, n)
+        self.launch_forward_dense(labels, idx, backward, n, train_mode)
 
     def launch_backward_dense(self):
         """head wgrad + fc1 wgrad: after this the first (head|wd1) part of the grad arena is final."""
-        lib, sp, s, B = self.lib, self.spec, self._s(), self.B
-        check(lib.dtf_head_wgrad(ptr(self.h1), ptr(self.dlogits), ptr(self.da), ptr(self.head_part), B, sp.hidden,
-                                 self.head_ks, s), "head_wgrad")
-        self._reduce([(self.head_part, self.head_ks, self._head_seg, self.head_stride)])
-        check(lib.dtf_gemm_tn(ptr(self.p2), ptr(self.da), self._pptr(self.grads, "wd1"), sp.flat, sp.hidden, B,
-                              sp.flat, sp.hidden, sp.hidden, 0, s), "fc1_wgrad")
+        check(self.lib.dtf_engine_backward_dense(self._d(), self._s()), "backward_dense")
 
-    def launch_backward_conv(self, images: torch.Tensor, idx: Optional[torch.Tensor]):
-        """fc1 dgrad -> {conv2 dgrad -> conv1 wgrad} || conv2 wgrad -> slab reduce.
+    def launch_backward_conv(self, images: torch.Tensor, idx: Optional[torch.Tensor], record_dgrad: bool = False):
+        """fc1 dgrad -> {conv2 dgrad -> conv1 wgrad} || conv2 wgrad (side stream) -> slab reduce.
+        ``record_dgrad`` records the native event ``ev_dgrad`` right after fc1 dgrad, the last reader
+        of the bf16 wd1 copy (see wait_dgrad_event)."""
+        check(self.lib.dtf_engine_backward_conv(self._d(), ptr(images), ptr(idx), int(record_dgrad), self._s()),
+              "backward_conv")
 
-        conv2's two gradient kernels only share inputs, so the filter gradient runs on a side
-        stream next to the data gradient (a fork/join that HIP-graph capture preserves): both are
-        latency-bound at this size and co-scheduling them fills the machine."""
-        lib, sp, s, B = self.lib, self.spec, self._s(), self.B
-        cur = torch.cuda.current_stream(self.device)
-        check(lib.dtf_gemm_nt(ptr(self.da), self._pptr(self.shadow, "wd1"), ptr(self.dflat), None, B, sp.flat,
-                              sp.hidden, sp.hidden, sp.hidden, sp.flat, 0, 1.0, 0, None, 0, s), "fc1_dgrad")
-        if self.multi_stream:
-            self._ev_fork.record(cur)
-            self._side2.wait_event(self._ev_fork)
-            s2 = self._side2.cuda_stream
-        else:
-            s2 = s
-        check(lib.dtf_conv2_wgrad(ptr(self.p1), ptr(self.dflat), ptr(self.arg2), ptr(self.p2), ptr(self.c2_part), B,
-                                  sp.c1, sp.c2, self.c2_g, s2), "conv2_wgrad")
-        if self.multi_stream:
-            self._ev_join2.record(self._side2)
-        check(lib.dtf_conv2_dgrad(ptr(self.dflat), ptr(self.arg2), ptr(self.p2), self._pptr(self.shadow, "wc2"),
-                                  ptr(self.dp1), B, sp.c1, sp.c2, s), "conv2_dgrad")
-        check(lib.dtf_conv1_wgrad(ptr(images), ptr(idx), ptr(self.dp1), ptr(self.arg1), ptr(self.p1),
-                                  ptr(self.c1_part), B, sp.c1, self.c1_g, s), "conv1_wgrad")
-        if self.multi_stream:
-            cur.wait_event(self._ev_join2)
-        self._reduce([(self.c2_part, self.c2_g, self._c2_seg, self.c2_stride),
-                      (self.c1_part, self.c1_g, self._c1_seg, self.c1_stride)])
+    def wait_dgrad_event(self):
+        """Make the current stream wait for the event recorded by launch_backward_conv(record_dgrad=True)."""
+        check(self.lib.dtf_stream_wait_event(self._s(), self._desc.ev_dgrad), "wait ev_dgrad")
 
     def launch_backward(self, images: torch.Tensor, idx: Optional[torch.Tensor]):
-        """Whole backward with the dense-layer weight gradients (head + fc1 wgrad) on a side stream
-        concurrent with the conv chain.  Returns after joining: the grad arena is final."""
-        if not self.multi_stream:
-            self.launch_backward_dense()
-            self.launch_backward_conv(images, idx)
-            return
-        cur = torch.cuda.current_stream(self.device)
-        self._ev_head.record(cur)
-        self._side1.wait_event(self._ev_head)
-        with torch.cuda.stream(self._side1):
-            self.launch_backward_dense()
-            self._ev_join1.record(self._side1)
-        self.launch_backward_conv(images, idx)
-        cur.wait_event(self._ev_join1)
+        """Whole backward; with multi_stream the dense-layer weight gradients run on a side stream
+        concurrent with the conv chain (fork/join, preserved by HIP-graph capture)."""
+        check(self.lib.dtf_engine_backward(self._d(), ptr(images), ptr(idx), self._s()), "backward")
+
+    def launch_update_range(self, lo: int, hi: int, advance: bool, advance_cursor: bool = True,
+                            adam_slot: int = 3):
+        """Optimizer over arena floats [lo, hi) (+ bf16 shadow).  ``advance`` bumps the sample cursor,
+        global_step and dropout offset (exactly one range per step does that); every range keeps its
+        own Adam step counter (state[adam_slot]) so ranges may be updated from different streams."""
+        check(self.lib.dtf_engine_update_range(self._d(), lo, hi, int(advance), int(advance_cursor), self.step_inc,
+                                               adam_slot, self._s()), "update_range")
+
+    def refresh_transposes(self, wd1: bool = True, wc2: bool = True):
+        check(self.lib.dtf_engine_transposes(self._d(), int(wd1), int(wc2), self._s()), "transposes")
 
     def launch_update(self, advance_cursor: bool = True):
-        lib, s = self.lib, self._s()
-        n = self.layout.total
-        cinc = self.B if advance_cursor else 0
-        if self.optimizer == "sgd":
-            check(lib.dtf_sgd_update(ptr(self.params), ptr(self.grads), ptr(self.shadow), ptr(self.hyper), n,
-                                     ptr(self.state), cinc, self.step_inc, s), "sgd_update")
-        else:
-            check(lib.dtf_adam_update(ptr(self.params), ptr(self.grads), ptr(self.adam_m), ptr(self.adam_v),
-                                      ptr(self.shadow), ptr(self.hyper), n, ptr(self.state), cinc, self.step_inc, s),
-                  "adam_update")
-        self.refresh_shadows(cast=False)
+        self.launch_update_range(0, self.layout.total, True, advance_cursor)
+        self.refresh_transposes()
 
     # ------------------------------------------------------------------ steps
     def launch_train_step(self):
-        """One full optimisation step on the resident dataset (all launches, no host sync)."""
-        ds = self.dataset
-        self.launch_sample()
-        self.launch_forward(ds.images, ds.labels, self.idx, backward=True)
-        self.launch_backward(ds.images, self.idx)
-        self.launch_update()
+        """One full optimisation step on the resident dataset: a single native call."""
+        check(self.lib.dtf_engine_train_step(self._d(), self.step_inc, self._s()), "train_step")
 
     def train_step_on(self, images: torch.Tensor, labels: torch.Tensor):
         """One step on an explicit batch (bf16 [B,784], int32 [B]) -- the feed_dict path."""

@@ -38,10 +38,10 @@ _SIGS = {
     "dtf_head_fwd_bwd": [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                          c_void_p, c_void_p, c_int, c_int, c_float, c_float, c_int, c_void_p],
     "dtf_head_wgrad": [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p],
-    "dtf_sgd_update": [c_void_p, c_void_p, c_void_p, c_void_p, c_long, c_void_p, c_long, c_long, c_void_p],
-    "dtf_adam_update": [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_long, c_void_p, c_long,
-                        c_long, c_void_p],
-    "dtf_advance_state": [c_void_p, c_long, c_long, c_void_p],
+    "dtf_sgd_update": [c_void_p, c_void_p, c_void_p, c_void_p, c_long, c_void_p, c_long, c_long, c_long, c_void_p],
+    "dtf_adam_update": [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_long, c_void_p, c_int,
+                        c_void_p, c_long, c_long, c_long, c_void_p],
+    "dtf_advance_state": [c_void_p, c_long, c_long, c_long, c_void_p],
     "dtf_cast_bf16": [c_void_p, c_void_p, c_long, c_void_p],
     "dtf_reduce_segments": [c_int, ctypes.POINTER(c_void_p), ctypes.POINTER(c_void_p), ctypes.POINTER(c_int),
                             ctypes.POINTER(c_int), ctypes.POINTER(c_long), c_void_p],
@@ -50,6 +50,42 @@ _SIGS = {
     "dtf_init_truncated_normal": [c_void_p, c_long, c_float, c_uint64, c_uint64, c_void_p],
     "dtf_fill_f32": [c_void_p, c_long, c_float, c_void_p],
     "dtf_u8_to_bf16_unit": [c_void_p, c_void_p, c_long, c_void_p],
+}
+
+
+class EngineDesc(ctypes.Structure):
+    """Mirror of ``struct DtfEngineDesc`` (csrc/runtime/engine.hip)."""
+
+    _fields_ = (
+        [(n, c_int) for n in ("B", "c1", "c2", "hidden", "flat", "classes", "head_ks", "c2_g", "c1_g", "optimizer",
+                              "shuffle", "multi_stream")]
+        + [(n, c_uint) for n in ("ds_n", "ds_hb", "sample_seed", "pad0")]
+        + [("seed", c_uint64), ("keep_prob", c_float), ("pad1", c_float), ("n_total", c_long)]
+        + [(n, c_long) for n in ("off_out_w", "off_out_b", "off_bd1", "off_wd1", "off_wc2", "off_bc2", "off_wc1",
+                                 "off_bc1", "head_stride", "c2_stride", "c1_stride")]
+        + [(n, c_void_p) for n in ("params", "grads", "shadow", "wd1T", "wc2T", "adam_m", "adam_v", "state", "hyper",
+                                   "idx", "p1", "arg1", "p2", "arg2", "h1", "logits", "loss_rows", "correct_rows",
+                                   "dlogits", "da", "dflat", "dp1", "head_part", "c2_part", "c1_part", "ds_images",
+                                   "ds_labels")]
+        + [(n, c_void_p) for n in ("side1", "side2", "ev_head", "ev_fork", "ev_join1", "ev_join2", "ev_dgrad")]
+    )
+
+
+_EP = ctypes.POINTER(EngineDesc)
+_ENGINE_SIGS = {
+    "dtf_engine_init": [_EP],
+    "dtf_engine_destroy": [_EP],
+    "dtf_stream_wait_event": [c_void_p, c_void_p],
+    "dtf_event_record": [c_void_p, c_void_p],
+    "dtf_engine_sample": [_EP, c_void_p],
+    "dtf_engine_forward_conv": [_EP, c_void_p, c_void_p, c_int, c_void_p],
+    "dtf_engine_forward_dense": [_EP, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p],
+    "dtf_engine_backward_dense": [_EP, c_void_p],
+    "dtf_engine_backward_conv": [_EP, c_void_p, c_void_p, c_int, c_void_p],
+    "dtf_engine_backward": [_EP, c_void_p, c_void_p, c_void_p],
+    "dtf_engine_update_range": [_EP, c_long, c_long, c_int, c_int, c_long, c_int, c_void_p],
+    "dtf_engine_transposes": [_EP, c_int, c_int, c_void_p],
+    "dtf_engine_train_step": [_EP, c_long, c_void_p],
 }
 
 
@@ -71,7 +107,7 @@ def load() -> ctypes.CDLL:
         raise NativeLibraryMissing(
             f"{p} not found: run `python tools/build_native.py` (hipcc --offload-arch=gfx950) first")
     lib = ctypes.CDLL(str(p), mode=os.RTLD_GLOBAL if hasattr(os, "RTLD_GLOBAL") else ctypes.DEFAULT_MODE)
-    for name, argtypes in _SIGS.items():
+    for name, argtypes in list(_SIGS.items()) + list(_ENGINE_SIGS.items()):
         fn = getattr(lib, name)
         fn.argtypes = argtypes
         fn.restype = c_int

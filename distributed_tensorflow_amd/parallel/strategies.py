@@ -104,14 +104,14 @@ class SyncAllReduce:
 
     name = "sync"
 
-    def __init__(self, backend: Backend, task: TaskInfo, worker_group, chief_rank: int):
+    def __init__(self, backend: Backend, task: TaskInfo, worker_group, chief_rank: int, tail_group=None):
         self.b, self.task, self.group, self.chief_rank = backend, task, worker_group, chief_rank
         self.world = task.num_workers
         self.step_count = backend.get_global_step()
         self._dp = None
         if backend.name == "hip" and dist.get_backend(worker_group) != "gloo":
             from .sync_dp import SyncDataParallel
-            self._dp = SyncDataParallel(backend.engine, group=worker_group)
+            self._dp = SyncDataParallel(backend.engine, group=worker_group, tail_group=tail_group)
 
     def broadcast_initial(self):
         broadcast_state(self.b, self.chief_rank)
@@ -128,7 +128,8 @@ class SyncAllReduce:
         return self.step_count
 
     def finish(self):
-        pass
+        if self._dp is not None:
+            self._dp.flush()
 
 
 def broadcast_state(backend: Backend, src_rank: int, group=None):

@@ -8,14 +8,20 @@ parameters are replicated, and each step moves ONE gradient arena through RCCL.
 
 Design for xGMI (point-to-point links, ring collectives are per-link bound):
   * the arena is laid out in backward order, so the head|wd1 prefix -- 98 % of
-    the bytes -- is final right after the fc1 wgrad GEMM.  It is all-reduced in
-    a few multi-MB buckets on a dedicated comm stream while the conv backward
-    kernels still run on the compute stream;
+    the bytes -- is final right after the fc1 wgrad GEMM.  It is all-reduced on a
+    dedicated comm stream while the conv backward kernels still run on the
+    compute stream.  One producer kernel finalises the whole prefix at once, so
+    the default is ONE large collective (RCCL pipelines it internally over the
+    xGMI links; every extra collective costs launch latency on both host and
+    device); ``bucket_mb`` can split it for experiments;
   * the small conv tail goes out as one last bucket;
   * buckets are byte ranges of the flat arena (no per-tensor collectives, no
     copies: RCCL reduces in place);
   * the optimizer kernel applies the 1/world scaling (hyper[4]), so no extra
-    pass touches the gradients.
+    pass touches the gradients;
+  * the update of the dense (head|wd1) range runs on the comm stream right behind
+    its all-reduce and is only waited for by the NEXT step's fc1 forward, so the
+    big all-reduce also hides behind the next step's sampler + conv forward.
 """
 from __future__ import annotations
 
@@ -39,20 +45,45 @@ def make_buckets(lo: int, hi: int, bucket_elems: int) -> List[Tuple[int, int]]:
 
 
 class SyncDataParallel:
-    def __init__(self, engine: HipEngine, bucket_mb: float = 4.0, group=None):
+    """Overlapped synchronous DP step for the HIP engine.
+
+    Timeline of step t (compute stream C, comm streams A and B):
+
+      C: sample, conv1, conv2 fwd            | needs only the conv params (updated at the end of t-1)
+      C: wait(dense params of t-1 updated)   | the dominant all-reduce of step t-1 has had the whole
+      C: fc1 fwd, head fwd/bwd               |   conv backward of t-1 AND the conv forward of t to finish
+      C: head wgrad, slab reduce, fc1 wgrad  -> event dense_ready
+      A:   all-reduce(head|wd1 buckets) ... then (after fc1 dgrad has read the old weights)
+      A:   optimizer on the dense range + wd1 transpose -> event dense_updated
+      C: fc1 dgrad, conv2 dgrad || wgrad, conv1 wgrad, slab reduce -> event tail_ready
+      B:   all-reduce(conv tail)   (second communicator: runs concurrently with A)
+      C: wait(B); optimizer on the conv tail (+ cursor / global_step advance), wc2 transpose
+
+    Semantics are exactly synchronous SGD/Adam (no stale gradients): only the *placement* of the
+    dense update moves, hidden behind work that does not read those weights.
+    """
+
+    DENSE_SLOT, TAIL_SLOT = 3, 4   # per-range Adam step counters in the device state
+
+    def __init__(self, engine: HipEngine, bucket_mb: float = 64.0, group=None, tail_group=None,
+                 defer_dense_update: bool = True):
         self.eng = engine
         self.group = group
+        self.tail_group = tail_group if tail_group is not None else group
         self.world = dist.get_world_size(group)
         self.comm_stream = torch.cuda.Stream(engine.device)
+        self.tail_stream = torch.cuda.Stream(engine.device) if tail_group is not None else self.comm_stream
+        self.defer = defer_dense_update
         lay = engine.layout
-        n_dense = lay.segment("out_w", "wd1")[1]
-        be = max(1, int(bucket_mb * (1 << 20) / 4))
-        self.dense_buckets = make_buckets(0, n_dense, be)
-        self.tail_bucket = (n_dense, lay.total)
+        self.n_dense = lay.segment("out_w", "wd1")[1]
+        be = max(1, int(bucket_mb * (1 << 20) / 4)) & ~3
+        self.dense_buckets = make_buckets(0, self.n_dense, be)
+        self.tail_bucket = (self.n_dense, lay.total)
         engine.set_grad_scale(1.0 / self.world)
-        self._ev_dense = torch.cuda.Event()
-        self._ev_tail = torch.cuda.Event()
-        self._ev_done = torch.cuda.Event()
+        E = torch.cuda.Event
+        self._ev_dense_ready, self._ev_dense_updated = E(), E()
+        self._ev_tail_ready, self._ev_tail_reduced = E(), E()
+        self._have_pending_dense = False
 
     def broadcast_parameters(self, src: int = 0):
         """Chief initialises, everybody else receives (reference: chief runs init_op)."""
@@ -62,26 +93,47 @@ class SyncDataParallel:
         self.eng.refresh_shadows()
         torch.cuda.synchronize()
 
-    def _allreduce(self, lo: int, hi: int):
-        dist.all_reduce(self.eng.grads[lo:hi], op=dist.ReduceOp.SUM, group=self.group)
+    def _allreduce(self, lo: int, hi: int, group):
+        dist.all_reduce(self.eng.grads[lo:hi], op=dist.ReduceOp.SUM, group=group)
 
     def train_step(self):
         eng = self.eng
         ds = eng.dataset
         cur = torch.cuda.current_stream(eng.device)
         eng.launch_sample()
-        eng.launch_forward(ds.images, ds.labels, eng.idx, backward=True)
+        eng.launch_forward_conv(ds.images, eng.idx)
+        if self._have_pending_dense:
+            cur.wait_event(self._ev_dense_updated)      # fc1/head weights of the previous step
+            self._have_pending_dense = False
+        eng.launch_forward_dense(ds.labels, eng.idx, backward=True)
         eng.launch_backward_dense()
-        self._ev_dense.record(cur)
+        self._ev_dense_ready.record(cur)
         with torch.cuda.stream(self.comm_stream):
-            self.comm_stream.wait_event(self._ev_dense)
+            self.comm_stream.wait_event(self._ev_dense_ready)
             for lo, hi in self.dense_buckets:
-                self._allreduce(lo, hi)
-        eng.launch_backward_conv(ds.images, eng.idx)
-        self._ev_tail.record(cur)
+                self._allreduce(lo, hi, self.group)
+        eng.launch_backward_conv(ds.images, eng.idx, record_dgrad=True)
+        self._ev_tail_ready.record(cur)
         with torch.cuda.stream(self.comm_stream):
-            self.comm_stream.wait_event(self._ev_tail)
-            self._allreduce(*self.tail_bucket)
-            self._ev_done.record(self.comm_stream)
-        cur.wait_event(self._ev_done)
-        eng.launch_update()
+            # the dense update overwrites the bf16 wd1 that fc1 dgrad reads: order it after that kernel
+            eng.wait_dgrad_event()
+            eng.launch_update_range(0, self.n_dense, advance=False, adam_slot=self.DENSE_SLOT)
+            eng.refresh_transposes(wd1=True, wc2=False)
+            self._ev_dense_updated.record(self.comm_stream)
+        with torch.cuda.stream(self.tail_stream):
+            self.tail_stream.wait_event(self._ev_tail_ready)
+            self._allreduce(*self.tail_bucket, self.tail_group)
+            self._ev_tail_reduced.record(self.tail_stream)
+        cur.wait_event(self._ev_tail_reduced)
+        eng.launch_update_range(self.n_dense, eng.layout.total, advance=True, adam_slot=self.TAIL_SLOT)
+        eng.refresh_transposes(wd1=False, wc2=True)
+        if self.defer:
+            self._have_pending_dense = True
+        else:
+            cur.wait_event(self._ev_dense_updated)
+
+    def flush(self):
+        """Make every pending update visible to the current stream (call before reading parameters)."""
+        if self._have_pending_dense:
+            torch.cuda.current_stream(self.eng.device).wait_event(self._ev_dense_updated)
+            self._have_pending_dense = False

@@ -84,9 +84,11 @@ def run(F, log=print) -> dict:
                            keep_prob=F.keep_prob, seed=F.seed + task.rank, device=device, use_graph=F.hip_graph)
 
     chief_rank = task.cluster.rank_of("worker", 0)
-    worker_group = None
-    if world > 1 and task.num_ps > 0:
-        worker_group = dist.new_group(task.cluster.worker_ranks())   # collective call: every rank makes it
+    worker_group = tail_group = None
+    if world > 1:
+        # collective calls: every rank (ps included) makes them, in the same order
+        worker_group = dist.new_group(task.cluster.worker_ranks())
+        tail_group = dist.new_group(task.cluster.worker_ranks())     # 2nd communicator: concurrent small all-reduce
 
     async_impl = F.async_impl
     if async_impl == "auto":
@@ -123,7 +125,7 @@ def run(F, log=print) -> dict:
     if mode == "local":
         strategy = LocalStrategy(backend)
     elif mode == "sync":
-        strategy = SyncAllReduce(backend, task, worker_group, chief_rank)
+        strategy = SyncAllReduce(backend, task, worker_group, chief_rank, tail_group=tail_group)
     elif async_impl == "p2p":
         strategy = AsyncP2PWorker(backend, task, chief_rank)
     else:

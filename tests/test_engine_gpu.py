@@ -118,15 +118,30 @@ def test_sync_dp_world1_rccl_matches_plain_engine(gpu_lib, dataset):
         b = HipEngine(ModelSpec(), 128, dataset, learning_rate=0.01, seed=4)
         a.init_params(seed=2)
         b.init_params(seed=2)
-        dp = SyncDataParallel(b, bucket_mb=1.0)
+        tail_group = dist.new_group([0])
+        dp = SyncDataParallel(b, bucket_mb=1.0, tail_group=tail_group)
         assert len(dp.dense_buckets) >= 12 and dp.tail_bucket[1] == b.layout.total
         dp.broadcast_parameters()
         for _ in range(5):
             a.launch_train_step()
             dp.train_step()
+        dp.flush()
         torch.cuda.synchronize()
         assert torch.equal(a.params, b.params)
+        assert torch.equal(a.wd1T, b.wd1T) and torch.equal(a.wc2T, b.wc2T)
         assert a.global_step == b.global_step == 5
+        # Adam: per-range step counters keep the deferred dense update and the tail update in step
+        a2 = HipEngine(ModelSpec(), 64, dataset, optimizer="adam", learning_rate=1e-3, seed=4)
+        b2 = HipEngine(ModelSpec(), 64, dataset, optimizer="adam", learning_rate=1e-3, seed=4)
+        a2.init_params(seed=2)
+        b2.init_params(seed=2)
+        dp2 = SyncDataParallel(b2, tail_group=tail_group)
+        for _ in range(4):
+            a2.launch_train_step()
+            dp2.train_step()
+        dp2.flush()
+        torch.cuda.synchronize()
+        assert torch.allclose(a2.params, b2.params, rtol=0, atol=1e-6)
     finally:
         dist.destroy_process_group()
 

@@ -293,10 +293,10 @@ def test_sgd_and_adam(gpu_lib):
     state = torch.zeros(8, dtype=torch.int64, device=DEV)
     w = w0.clone()
     sh = torch.empty(n, dtype=torch.bfloat16, device=DEV)
-    check(gpu_lib.dtf_sgd_update(ptr(w), ptr(g), ptr(sh), ptr(hyper), n, ptr(state), 128, 1, stream()), "sgd")
+    check(gpu_lib.dtf_sgd_update(ptr(w), ptr(g), ptr(sh), ptr(hyper), n, ptr(state), 128, 1, 1, stream()), "sgd")
     assert torch.allclose(w, w0 - 0.01 * 0.5 * g, atol=1e-6)
     assert torch.equal(sh, w.to(torch.bfloat16))
-    assert state[:4].tolist() == [128, 1, 1, 1]
+    assert state[:4].tolist() == [128, 1, 1, 0]
     # adam, 3 steps against torch.optim.Adam (grad pre-scaled by hyper[4])
     state.zero_()
     w = w0.clone()
@@ -306,8 +306,8 @@ def test_sgd_and_adam(gpu_lib):
     wr, mr, vr = w0.double().clone(), torch.zeros(n, dtype=torch.float64, device=DEV), torch.zeros(n, dtype=torch.float64, device=DEV)
     b1, b2 = float(hyper[1]), float(hyper[2])
     for t in range(1, 4):
-        check(gpu_lib.dtf_adam_update(ptr(w), ptr(g), ptr(m), ptr(v), ptr(sh), ptr(hyper), n, ptr(state), 0, 1,
-                                      stream()), "adam")
+        check(gpu_lib.dtf_adam_update(ptr(w), ptr(g), ptr(m), ptr(v), ptr(sh), ptr(hyper), n, ptr(state), 3,
+                                      ptr(state), 0, 1, 1, stream()), "adam")
         ge = g.double() * 0.5
         mr = b1 * mr + (1 - b1) * ge
         vr = b2 * vr + (1 - b2) * ge * ge

@@ -11,5 +11,5 @@ rc=$?; tail -15 gpurun_out/${TAG}_tests.log
 if [ $rc -ne 0 ]; then echo "TESTS FAILED rc=$rc"; exit $rc; fi
 timeout -k 10 300 python bench.py --steps 200 --warmup 20 > gpurun_out/${TAG}_bench.log 2>&1 || { tail -20 gpurun_out/${TAG}_bench.log; exit 1; }
 tail -1 gpurun_out/${TAG}_bench.log
-timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/${TAG}_prof -- python3 bench.py --steps 50 --warmup 5 --no_graph > gpurun_out/${TAG}_prof.log 2>&1 || { tail -20 gpurun_out/${TAG}_prof.log; exit 1; }
+timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/${TAG}_prof -- python3 bench.py --steps 50 --warmup 5 --no_graph --single_stream > gpurun_out/${TAG}_prof.log 2>&1 || { tail -20 gpurun_out/${TAG}_prof.log; exit 1; }
 python3 tools/prof_summary.py gpurun_out/${TAG}_prof 55
