@@ -1,13 +1,12 @@
 // First conv block of the deep-MNIST net: 5x5 SAME conv with ONE input channel
 // (reference .idea/MNISTDist.py:71-73: conv2d(x, wc1, bc1) -> maxpool2d).
 //
-// C_in = 1 makes this layer degenerate for the matrix cores (K = 25), so it is
-// a direct LDS stencil on the vector ALUs: the 28x28 image sits in LDS with a
-// 2-pixel zero halo, each lane owns one output channel (25 weights in
-// registers) and walks pooling windows; conv + bias + ReLU + 2x2 max-pool and
-// the argmax byte are produced in registers, so the [B,28,28,C] pre-pool tensor
-// never exists in memory.  The batch gather (dataset row = idx[b]) is fused
-// into the image load: there is no host input pipeline and no batch copy.
+// C_in = 1 gives a tiny reduction dimension (K = 25), but the layer is still run on the matrix
+// cores by padding the tap axis to 8 per filter row: the 28x28 image sits in LDS with a zero halo,
+// fragments are plain aligned reads of consecutive pixels, and conv + bias + ReLU + 2x2 max-pool
+// + the argmax byte are produced in registers, so the [B,28,28,C] pre-pool tensor never exists in
+// memory.  The batch gather (dataset row = idx[b]) is fused into the image load: there is no host
+// input pipeline and no batch copy.
 //
 // Backward needs only the filter/bias gradient (the layer input is data); it IS
 // GEMM-shaped (K = all positions of the batch), so it runs on the matrix cores --
@@ -17,10 +16,19 @@
 
 namespace dtf {
 
-constexpr int kImgW = 28;
-constexpr int kPadW = 33;  // 32 (28 + 2*2 halo) + 1 pad column
+// Forward on the matrix cores.
+//   M = output positions, N = 32 channels, K = taps ordered k = 8*ky + kx (kx < 5 carry weights,
+//   kx = 5..7 are zero columns), i.e. 64 = 2 MFMA k-steps of which the second only holds ky = 4.
+//   An A fragment (8 consecutive k of one row) is then 8 CONSECUTIVE PIXELS of image row y + ky.
+//   M tiles take every second pixel: tile E holds x = 0,2,..,30 and tile O holds x = 1,3,..,31 of one
+//   output row, so (a) both fragments come from the same five aligned ds_read_b32 of pixels
+//   [2m, 2m+10) -- O is E shifted by one pixel with v_alignbit -- and (b) pooled column px = m sits in
+//   the SAME accumulator register of the four tiles {E,O} x {row y, row y+1}: bias + ReLU + 2x2
+//   max-pool + argmax are in-register, and one lane produces four pooled columns of its channel.
+//   The pooled row is staged through wave-private LDS and leaves as 16-byte stores.
+// grid-stride over images; 4 waves split the 14 row pairs.  w: fp32 HWIO [25][C] (rounded to bf16).
+constexpr int kC1Pitch = 96;   // pixels per padded LDS row (48 dwords: rows of lane groups g, g+1 never share a bank)
 
-// images: [N,784] bf16, idx: [B] dataset rows (nullptr -> identity), w: [25][C] fp32 (HWIO, I = 1)
 template <int C>
 __global__ __launch_bounds__(256) void conv1_pool_fwd(const bf16* __restrict__ images,
                                                       const int* __restrict__ idx,
@@ -28,58 +36,103 @@ __global__ __launch_bounds__(256) void conv1_pool_fwd(const bf16* __restrict__ i
                                                       const float* __restrict__ bias,
                                                       bf16* __restrict__ pooled,
                                                       uint8_t* __restrict__ arg, int B) {
-  constexpr int PG = 256 / C;  // window groups per block
-  __shared__ float img[32 * kPadW];
-  const int tid = threadIdx.x;
-  const int c = tid % C, pg = tid / C;
+  typedef __attribute__((ext_vector_type(4))) unsigned int u4;
+  __shared__ __attribute__((aligned(16))) bf16 img[32 * kC1Pitch];          // 6 KB, zero halo
+  __shared__ __attribute__((aligned(16))) bf16 orow[4][16 * 32];            // per wave: pooled row [px][32 ch]
+  __shared__ __attribute__((aligned(16))) uint8_t arow[4][16 * 32];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int g = lane >> 4, i16 = lane & 15;
+  const int cchunk = blockIdx.y;   // 32-channel chunk
 
-  float wr[25];
+  // weight fragments: lane (n = i16, g) holds k = 8g + j  <->  (ky, kx = j)
+  bf16x8 wf[2][2];
+  float bv[2];
 #pragma unroll
-  for (int t = 0; t < 25; ++t) wr[t] = w[t * C + c];
-  const float bv = bias[c];
+  for (int nt = 0; nt < 2; ++nt) {
+    const int n = cchunk * 32 + nt * 16 + i16;
+    bv[nt] = bias[n];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      wf[0][nt][j] = (j < 5) ? (bf16)w[(g * 5 + j) * C + n] : (bf16)0.f;
+      wf[1][nt][j] = (j < 5 && g == 0) ? (bf16)w[(20 + j) * C + n] : (bf16)0.f;
+    }
+  }
 
-  for (int i = tid; i < 32 * kPadW; i += 256) img[i] = 0.f;
+  for (int i = tid; i < 32 * kC1Pitch / 8; i += 256) reinterpret_cast<u4*>(img)[i] = (u4){0u, 0u, 0u, 0u};
 
   for (int b = blockIdx.x; b < B; b += gridDim.x) {
-    __syncthreads();
+    __syncthreads();   // previous image consumed / zero fill done
     const size_t row = idx ? (size_t)idx[b] : (size_t)b;
-    const bf16* src = images + row * 784;
-    for (int i = tid; i < 392; i += 256) {  // 2 pixels per thread-iteration
-      bf16x2 v = *reinterpret_cast<const bf16x2*>(src + 2 * i);
-      int p = 2 * i, y = p / kImgW, x = p % kImgW;
-      img[(y + 2) * kPadW + x + 2] = (float)v[0];
-      img[(y + 2) * kPadW + x + 3] = (float)v[1];
+    const unsigned* src = reinterpret_cast<const unsigned*>(images + row * 784);
+    for (int i = tid; i < 392; i += 256) {   // 2 pixels (one dword) per thread-iteration
+      int y = i / 14, x2 = i % 14;
+      reinterpret_cast<unsigned*>(img)[((y + 2) * kC1Pitch + 2) / 2 + x2] = src[i];
     }
     __syncthreads();
-    for (int pp = pg; pp < 196; pp += PG) {
-      const int py = pp / 14, px = pp % 14;
-      const float* base = img + (2 * py) * kPadW + 2 * px;  // top-left of the 6x6 patch
-      float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+    for (int rp = wave; rp < 14; rp += 4) {
+      f32x4 acc[2][2][2];   // [out row][E/O][n-tile]
 #pragma unroll
-      for (int r = 0; r < 6; ++r) {
-        float v[6];
+      for (int a = 0; a < 2; ++a)
 #pragma unroll
-        for (int s = 0; s < 6; ++s) v[s] = base[r * kPadW + s];
+        for (int e = 0; e < 2; ++e)
 #pragma unroll
-        for (int kx = 0; kx < 5; ++kx) {
-          if (r < 5) {
-            a0 = fmaf(v[kx], wr[r * 5 + kx], a0);
-            a1 = fmaf(v[kx + 1], wr[r * 5 + kx], a1);
-          }
-          if (r >= 1) {
-            a2 = fmaf(v[kx], wr[(r - 1) * 5 + kx], a2);
-            a3 = fmaf(v[kx + 1], wr[(r - 1) * 5 + kx], a3);
+          for (int nt = 0; nt < 2; ++nt) acc[a][e][nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int orow_i = 0; orow_i < 2; ++orow_i) {
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+          // input row (padded coords) = y + ky, ky = g (ks 0) or 4 (ks 1); pixels 2m .. 2m+9
+          const int r = 2 * rp + orow_i + (ks == 0 ? g : 4);
+          const unsigned* p = reinterpret_cast<const unsigned*>(img) + (r * kC1Pitch) / 2 + i16;
+          unsigned d0 = p[0], d1 = p[1], d2 = p[2], d3 = p[3], d4 = p[4];
+          u4 ev = {d0, d1, d2, d3};
+          u4 od = {__builtin_amdgcn_alignbit(d1, d0, 16), __builtin_amdgcn_alignbit(d2, d1, 16),
+                   __builtin_amdgcn_alignbit(d3, d2, 16), __builtin_amdgcn_alignbit(d4, d3, 16)};
+          bf16x8 ae = __builtin_bit_cast(bf16x8, ev), ao = __builtin_bit_cast(bf16x8, od);
+#pragma unroll
+          for (int nt = 0; nt < 2; ++nt) {
+            acc[orow_i][0][nt] = mfma16(ae, wf[ks][nt], acc[orow_i][0][nt]);
+            acc[orow_i][1][nt] = mfma16(ao, wf[ks][nt], acc[orow_i][1][nt]);
           }
         }
       }
-      float best = a0;
-      int bi = 0;
-      if (a1 > best) { best = a1; bi = 1; }
-      if (a2 > best) { best = a2; bi = 2; }
-      if (a3 > best) { best = a3; bi = 3; }
-      const size_t off = ((size_t)b * 196 + pp) * C + c;
-      pooled[off] = (bf16)fmaxf(best + bv, 0.f);
-      arg[off] = (uint8_t)bi;
+      // pool: lane (g, i16) owns pooled columns px = 4g + r of channels nt*16 + i16
+#pragma unroll
+      for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          float v0 = acc[0][0][nt][r], v1 = acc[0][1][nt][r], v2 = acc[1][0][nt][r], v3 = acc[1][1][nt][r];
+          float best = v0;
+          int bi = 0;
+          if (v1 > best) { best = v1; bi = 1; }
+          if (v2 > best) { best = v2; bi = 2; }
+          if (v3 > best) { best = v3; bi = 3; }
+          const int px = 4 * g + r;
+          orow[wave][px * 32 + nt * 16 + i16] = (bf16)fmaxf(best + bv[nt], 0.f);
+          arow[wave][px * 32 + nt * 16 + i16] = (uint8_t)bi;
+        }
+      __builtin_amdgcn_wave_barrier();
+      // 14 px x 32 ch: 896 B of bf16 = 56 x 16 B, 448 B of argmax = 28 x 16 B
+      const size_t obase = ((size_t)b * 196 + rp * 14) * C + cchunk * 32;
+      if (C == 32) {
+        if (lane < 56)
+          reinterpret_cast<u4*>(pooled + obase)[lane] = reinterpret_cast<const u4*>(orow[wave])[lane];
+        if (lane < 28)
+          reinterpret_cast<u4*>(arg + obase)[lane] = reinterpret_cast<const u4*>(arow[wave])[lane];
+      } else {
+        // C > 32: a pooled pixel's 32-channel chunk is 64 B (4 x 16 B) at stride C
+        if (lane < 56) {
+          int px = lane >> 2, c4 = lane & 3;
+          *reinterpret_cast<u4*>(pooled + obase + (size_t)px * C + c4 * 8) =
+              reinterpret_cast<const u4*>(orow[wave])[lane];
+        }
+        if (lane < 28) {
+          int px = lane >> 1, c2 = lane & 1;
+          *reinterpret_cast<u4*>(arg + obase + (size_t)px * C + c2 * 16) =
+              reinterpret_cast<const u4*>(arow[wave])[lane];
+        }
+      }
+      __builtin_amdgcn_wave_barrier();
     }
   }
 }
@@ -228,12 +281,12 @@ extern "C" {
 
 int dtf_conv1_fwd(const void* images, const void* idx, const void* w, const void* bias, void* pooled,
                   void* arg, int B, int cout, int grid, hipStream_t s) {
-  if (grid <= 0) grid = B < 2048 ? B : 2048;
+  if (grid <= 0) grid = B < 1024 ? B : 1024;
   if (cout == 32)
-    hipLaunchKernelGGL((conv1_pool_fwd<32>), dim3(grid), dim3(256), 0, s, (const bf16*)images,
+    hipLaunchKernelGGL((conv1_pool_fwd<32>), dim3(grid, 1), dim3(256), 0, s, (const bf16*)images,
                        (const int*)idx, (const float*)w, (const float*)bias, (bf16*)pooled, (uint8_t*)arg, B);
   else if (cout == 128)
-    hipLaunchKernelGGL((conv1_pool_fwd<128>), dim3(grid), dim3(256), 0, s, (const bf16*)images,
+    hipLaunchKernelGGL((conv1_pool_fwd<128>), dim3(grid, 4), dim3(256), 0, s, (const bf16*)images,
                        (const int*)idx, (const float*)w, (const float*)bias, (bf16*)pooled, (uint8_t*)arg, B);
   else
     return -1;
