@@ -18,6 +18,8 @@ int dtf_gemm_nt(const void* A, const void* B, void* C, const void* bias, int M, 
                 int ldc, int epi, float keep_prob, uint64_t seed, const void* state, int tile, hipStream_t s);
 int dtf_gemm_tn(const void* A, const void* B, void* C, int M, int N, int K, int lda, int ldb, int ldc, int tile,
                 hipStream_t s);
+int dtf_gemm_nn_fwd(const void* A, const void* B, void* part, void* out, const void* bias, int M, int N, int K,
+                    int lda, int ldb, int S, float keep_prob, uint64_t seed, const void* state, hipStream_t s);
 int dtf_transpose_bf16(const void* in, void* out, int batch, int R, int C, hipStream_t s);
 int dtf_head_fwd_bwd(const void* h1, const void* w, const void* bias, const void* labels, const void* idx,
                      void* logits_out, void* loss_rows, void* correct_rows, void* dlogits, void* da, int B, int H,

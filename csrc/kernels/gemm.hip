@@ -264,6 +264,156 @@ __global__ __launch_bounds__(256) void gemm_tn_bf16(const bf16* __restrict__ A, 
   }
 }
 
+// C_part[z][M,N] (fp32) = A[M, Kz] . B[Kz, N]  -- "NN": A K-contiguous (activations), B in its
+// native [K][N] layout (e.g. wd1 [in,out] exactly as TF stores it: no transposed weight copy).
+// Split-K over blockIdx.z fills the machine when M*N alone gives too few tiles (fc1 forward at
+// batch 1024 is only 8x8 tiles of 128^2).  A fragments: ds_read_b128 from the XOR-swizzled image of
+// gemm_nt.  B fragments: ds_read_b64_tr_b16 with rows 8g+q / 8g+4+q so that element j of lane
+// group g is k = 8g + j on BOTH operands; the two 128-byte halves of every row with bit 3 set are
+// swapped, which makes these transposed reads bank-conflict free (rows r and r+8 would collide).
+template <int BM, int BN>
+__global__ __launch_bounds__(256) void gemm_nn_splitk_bf16(const bf16* __restrict__ A, const bf16* __restrict__ Bm,
+                                                           float* __restrict__ Cp, int M, int N, int K, int lda,
+                                                           int ldb, int tiles_per_split) {
+  static_assert(BN == 128, "the half-swap swizzle below assumes 256-byte B rows");
+  constexpr int BK = 64;
+  constexpr int PB = BN + 16;
+  constexpr int WM = BM / 2, WN = BN / 2;
+  constexpr int MT = WM / 16, NTL = WN / 16;
+  constexpr int A_CH = BM * 8 / 256, B_CH = BK * (BN / 8) / 256;
+  __shared__ __attribute__((aligned(16))) bf16 sA[2][BM * BK];
+  __shared__ __attribute__((aligned(16))) bf16 sB[2][BK * PB];
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
+  const int i16 = lane & 15, g = lane >> 4;
+  const int qr = i16 >> 2, pc = i16 & 3;
+  const int T_all = (K + BK - 1) / BK;
+  const int t_begin = blockIdx.z * tiles_per_split;
+  const int T = min(T_all, t_begin + tiles_per_split) - t_begin;
+  const int kbase = t_begin * BK;
+
+  f32x4 acc[MT][NTL];
+#pragma unroll
+  for (int i = 0; i < MT; ++i)
+#pragma unroll
+    for (int j = 0; j < NTL; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  u32x4 ra0[A_CH], rb0[B_CH], ra1[A_CH], rb1[B_CH];
+  auto gload = [&](u32x4 (&ra)[A_CH], u32x4 (&rb)[B_CH], int k0) {
+#pragma unroll
+    for (int i = 0; i < A_CH; ++i) {
+      int c = tid + i * 256, row = c >> 3, slot = c & 7;
+      int gm = m0 + row, gk = k0 + slot * 8;
+      ra[i] = (gm < M && gk < K) ? *reinterpret_cast<const u32x4*>(A + (size_t)gm * lda + gk)
+                                 : (u32x4){0u, 0u, 0u, 0u};
+    }
+#pragma unroll
+    for (int i = 0; i < B_CH; ++i) {
+      int c = tid + i * 256, row = c / (BN / 8), slot = c % (BN / 8);
+      int gk = k0 + row, gn = n0 + slot * 8;
+      rb[i] = (gk < K && gn < N) ? *reinterpret_cast<const u32x4*>(Bm + (size_t)gk * ldb + gn)
+                                 : (u32x4){0u, 0u, 0u, 0u};
+    }
+  };
+  auto swrite = [&](const u32x4 (&ra)[A_CH], const u32x4 (&rb)[B_CH], int buf) {
+#pragma unroll
+    for (int i = 0; i < A_CH; ++i) {
+      int c = tid + i * 256, row = c >> 3, slot = c & 7;
+      *reinterpret_cast<u32x4*>(sA[buf] + row * BK + ((slot ^ (row & 7)) << 3)) = ra[i];
+    }
+#pragma unroll
+    for (int i = 0; i < B_CH; ++i) {
+      int c = tid + i * 256, row = c / (BN / 8), slot = c % (BN / 8);
+      int col = (slot * 8) ^ (((row >> 3) & 1) << 6);   // swap the 64-element halves on rows with bit 3
+      *reinterpret_cast<u32x4*>(sB[buf] + row * PB + col) = rb[i];
+    }
+  };
+  typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
+  typedef __attribute__((ext_vector_type(8))) short s16x8;
+  auto compute = [&](int buf) {
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk) {
+      bf16x8 af[MT], bfv[NTL];
+#pragma unroll
+      for (int i = 0; i < MT; ++i) {
+        int row = wm * WM + i * 16 + i16;
+        af[i] = *reinterpret_cast<const bf16x8*>(sA[buf] + row * BK + (((kk * 4 + g) ^ (row & 7)) << 3));
+      }
+#pragma unroll
+      for (int j = 0; j < NTL; ++j) {
+        // rows kk*32 + 8g + qr and +4; bit 3 of the row is g & 1 for both
+        const int r0 = kk * 32 + 8 * g + qr;
+        const int col = (wn * WN + j * 16 + 4 * pc) ^ ((g & 1) << 6);
+        const bf16* p0 = sB[buf] + r0 * PB + col;
+        s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)p0);
+        s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(p0 + 4 * PB));
+        s16x8 v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+        bfv[j] = __builtin_bit_cast(bf16x8, v);
+      }
+#pragma unroll
+      for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int j = 0; j < NTL; ++j) acc[i][j] = mfma16(af[i], bfv[j], acc[i][j]);
+    }
+  };
+
+  if (T > 0) {
+    gload(ra0, rb0, kbase);
+    if (T > 1) gload(ra1, rb1, kbase + BK);
+    swrite(ra0, rb0, 0);
+    __syncthreads();
+    for (int t = 0; t < T; t += 2) {
+      if (t + 2 < T) gload(ra0, rb0, kbase + (t + 2) * BK);
+      compute(0);
+      if (t + 1 < T) swrite(ra1, rb1, 1);
+      __syncthreads();
+      if (t + 1 >= T) break;
+      if (t + 3 < T) gload(ra1, rb1, kbase + (t + 3) * BK);
+      compute(1);
+      if (t + 2 < T) swrite(ra0, rb0, 0);
+      __syncthreads();
+    }
+  }
+  float* C = Cp + (size_t)blockIdx.z * M * N;
+#pragma unroll
+  for (int j = 0; j < NTL; ++j) {
+    const int n = n0 + wn * WN + j * 16 + i16;
+    if (n >= N) continue;
+#pragma unroll
+    for (int i = 0; i < MT; ++i)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int mrow = m0 + wm * WM + i * 16 + 4 * g + r;
+        if (mrow < M) C[(size_t)mrow * N + n] = acc[i][j][r];
+      }
+  }
+}
+
+// out[M,N] bf16 = dropout(relu(sum_z part[z] + bias))  -- the fused epilogue of the split-K forward
+__global__ __launch_bounds__(256) void splitk_bias_relu_dropout(const float* __restrict__ part,
+                                                                const float* __restrict__ bias,
+                                                                bf16* __restrict__ out, long MN, int N, int S,
+                                                                DropoutArgs drop) {
+  const bool do_drop = drop.keep_prob < 1.0f;
+  const uint64_t drop_off = (do_drop && drop.state) ? (uint64_t)drop.state[2] : 0;
+  for (long i4 = (long)blockIdx.x * blockDim.x + threadIdx.x; i4 * 4 < MN; i4 += (long)gridDim.x * blockDim.x) {
+    f32x4 a = reinterpret_cast<const f32x4*>(part)[i4];
+    for (int z = 1; z < S; ++z) a += reinterpret_cast<const f32x4*>(part + (size_t)z * MN)[i4];
+    const int n = (int)((i4 * 4) % N);
+    f32x4 bv = *reinterpret_cast<const f32x4*>(bias + n);
+    bf16x4 o;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      float v = fmaxf(a[e] + bv[e], 0.f);
+      if (do_drop) v *= dropout_scale(drop, drop_off, (uint64_t)(i4 * 4 + e));
+      o[e] = (bf16)v;
+    }
+    reinterpret_cast<bf16x4*>(out)[i4] = o;
+  }
+}
+
 // Tiled, batched bf16 transpose: out[z][c][r] = in[z][r][c]  (weight shadows in the
 // K-contiguous layout the NT kernels want)
 __global__ __launch_bounds__(256) void transpose_bf16(const bf16* __restrict__ in, bf16* __restrict__ out,
@@ -327,6 +477,34 @@ int dtf_gemm_tn(const void* A, const void* B, void* C, int M, int N, int K, int 
     return -1;
   return (int)hipGetLastError();
 }
+
+// fc1 forward: out[M,N] bf16 = dropout(relu(A[M,K] . B[K,N] + bias)); part must hold S*M*N floats.
+// S = 0 picks a split that gives ~256 workgroups.
+int dtf_gemm_nn_fwd(const void* A, const void* B, void* part, void* out, const void* bias, int M, int N, int K,
+                    int lda, int ldb, int S, float keep_prob, uint64_t seed, const void* state, hipStream_t s) {
+  if ((K & 7) || (lda & 7) || (ldb & 7) || (N & 7)) return -3;
+  const int T = (K + 63) / 64;
+  const int tiles = ((M + 127) / 128) * ((N + 127) / 128);
+  if (S <= 0) {
+    S = (256 + tiles - 1) / tiles;
+    if (S > 8) S = 8;
+  }
+  if (S > T) S = T;
+  const int tps = (T + S - 1) / S;
+  S = (T + tps - 1) / tps;
+  hipLaunchKernelGGL((gemm_nn_splitk_bf16<128, 128>), dim3((N + 127) / 128, (M + 127) / 128, S), dim3(256), 0, s,
+                     (const bf16*)A, (const bf16*)B, (float*)part, M, N, K, lda, ldb, tps);
+  DropoutArgs d{keep_prob, seed, (const int64_t*)state};
+  const long MN = (long)M * N;
+  long blocks = (MN / 4 + 255) / 256;
+  if (blocks > 2048) blocks = 2048;
+  hipLaunchKernelGGL(splitk_bias_relu_dropout, dim3((unsigned)blocks), dim3(256), 0, s, (const float*)part,
+                     (const float*)bias, (bf16*)out, MN, N, S, d);
+  return (int)hipGetLastError();
+}
+
+// max number of K splits dtf_gemm_nn_fwd may use (sizes the partial buffer)
+int dtf_gemm_nn_max_splits() { return 8; }
 
 int dtf_transpose_bf16(const void* in, void* out, int batch, int R, int C, hipStream_t s) {
   hipLaunchKernelGGL(transpose_bf16, dim3((C + 63) / 64, (R + 63) / 64, batch), dim3(256), 0, s,

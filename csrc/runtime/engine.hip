@@ -21,7 +21,7 @@ struct DtfEngineDesc {
   long off_out_w, off_out_b, off_bd1, off_wd1, off_wc2, off_bc2, off_wc1, off_bc1;  // float offsets in the arena
   long head_stride, c2_stride, c1_stride;
   // device buffers
-  void *params, *grads, *shadow, *wd1T, *wc2T, *adam_m, *adam_v, *state, *hyper;
+  void *params, *grads, *shadow, *fc1_part, *wc2T, *adam_m, *adam_v, *state, *hyper;
   void *idx, *p1, *arg1, *p2, *arg2, *h1, *logits, *loss_rows, *correct_rows, *dlogits, *da, *dflat, *dp1;
   void *head_part, *c2_part, *c1_part;
   void *ds_images, *ds_labels;
@@ -77,8 +77,9 @@ int dtf_engine_forward_conv(const DtfEngineDesc* e, const void* images, const vo
 int dtf_engine_forward_dense(const DtfEngineDesc* e, const void* labels, const void* idx, int backward, int n,
                              int train_mode, hipStream_t s) {
   const float keep = train_mode ? e->keep_prob : 1.0f;
-  DTF_TRY(dtf_gemm_nt(e->p2, e->wd1T, e->h1, f32at(e->params, e->off_bd1), n, e->hidden, e->flat, e->flat, e->flat,
-                      e->hidden, 1, keep, e->seed, e->state, 0, s));
+  // wd1 is consumed in its native [in, out] layout (no transposed copy); split-K + fused epilogue
+  DTF_TRY(dtf_gemm_nn_fwd(e->p2, bf16at(e->shadow, e->off_wd1), e->fc1_part, e->h1, f32at(e->params, e->off_bd1), n,
+                          e->hidden, e->flat, e->flat, e->hidden, 0, keep, e->seed, e->state, s));
   return dtf_head_fwd_bwd(e->h1, f32at(e->params, e->off_out_w), f32at(e->params, e->off_out_b), labels, idx,
                           e->logits, e->loss_rows, e->correct_rows, e->dlogits, e->da, n, e->hidden, 1.0f / n,
                           1.0f / keep, backward, s);
@@ -147,8 +148,8 @@ int dtf_engine_update_range(const DtfEngineDesc* e, long lo, long hi, int advanc
                          bf16at(e->shadow, lo), e->hyper, n, e->state, adam_slot, st, cinc, step_inc, 1, s);
 }
 
-int dtf_engine_transposes(const DtfEngineDesc* e, int wd1, int wc2, hipStream_t s) {
-  if (wd1) DTF_TRY(dtf_transpose_bf16(bf16at(e->shadow, e->off_wd1), e->wd1T, 1, e->flat, e->hidden, s));
+// only wc2 still needs a K-contiguous copy (100 KB); wd1 is used in place by both fc1 GEMMs
+int dtf_engine_transposes(const DtfEngineDesc* e, int wc2, hipStream_t s) {
   if (wc2) DTF_TRY(dtf_transpose_bf16(bf16at(e->shadow, e->off_wc2), e->wc2T, 25, e->c1, e->c2, s));
   return 0;
 }
@@ -160,7 +161,7 @@ int dtf_engine_train_step(const DtfEngineDesc* e, long step_inc, hipStream_t s) 
   DTF_TRY(dtf_engine_forward_dense(e, e->ds_labels, e->idx, 1, e->B, 1, s));
   DTF_TRY(dtf_engine_backward(e, e->ds_images, e->idx, s));
   DTF_TRY(dtf_engine_update_range(e, 0, e->n_total, 1, 1, step_inc, 3, s));
-  return dtf_engine_transposes(e, 1, 1, s);
+  return dtf_engine_transposes(e, 1, s);
 }
 
 }  // extern "C"

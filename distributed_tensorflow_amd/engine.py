@@ -11,7 +11,7 @@ and global_step all live in device memory, so replays are not frozen).
 
 Memory plan (all resident, sized once for ``batch``):
   params / grads      flat fp32 arenas (ArenaLayout order = backward order)
-  shadow              bf16 copy of the arena (+ K-contiguous transposes of wd1/wc2)
+  shadow              bf16 copy of the arena (+ a K-contiguous transpose of the 100 KB conv2 filter)
   activations         bf16 NHWC, pooled only (pre-pool tensors never exist)
   split-K slabs       deterministic partial sums for the wgrad reductions
 """
@@ -103,7 +103,6 @@ class HipEngine:
         self.params = torch.zeros(n, **f32)
         self.grads = torch.zeros(n, **f32)
         self.shadow = torch.zeros(n, **bf)
-        self.wd1T = torch.zeros((H, FLAT), **bf)
         self.wc2T = torch.zeros((25, C2, C1), **bf)
         if optimizer == "adam":
             self.adam_m = torch.zeros(n, **f32)
@@ -120,6 +119,9 @@ class HipEngine:
         self.p2 = torch.empty((B, 7, 7, C2), **bf)
         self.arg2 = torch.empty((B, 7, 7, C2), **u8)
         self.h1 = torch.empty((B, H), **bf)
+        tiles = ((B + 127) // 128) * ((H + 127) // 128)
+        self.fc1_splits = max(1, min(8, -(-256 // tiles)))       # mirrors dtf_gemm_nn_fwd's choice
+        self.fc1_part = torch.empty((self.fc1_splits, B, H), **f32)
         self.logits = torch.empty((B, spec.classes), **f32)
         self.loss_rows = torch.empty(B, **f32)
         self.correct_rows = torch.empty(B, **f32)
@@ -166,7 +168,7 @@ class HipEngine:
         for name in lay.names():
             setattr(d, "off_" + name, lay.offsets[name])
         d.head_stride, d.c2_stride, d.c1_stride = self.head_stride, self.c2_stride, self.c1_stride
-        for name in ("params", "grads", "shadow", "wd1T", "wc2T", "state", "hyper", "idx", "p1", "arg1", "p2", "arg2",
+        for name in ("params", "grads", "shadow", "fc1_part", "wc2T", "state", "hyper", "idx", "p1", "arg1", "p2", "arg2",
                      "h1", "logits", "loss_rows", "correct_rows", "dlogits", "da", "dflat", "dp1", "head_part",
                      "c2_part", "c1_part"):
             setattr(d, name, getattr(self, name).data_ptr())
@@ -298,8 +300,9 @@ class HipEngine:
         check(self.lib.dtf_engine_update_range(self._d(), lo, hi, int(advance), int(advance_cursor), self.step_inc,
                                                adam_slot, self._s()), "update_range")
 
-    def refresh_transposes(self, wd1: bool = True, wc2: bool = True):
-        check(self.lib.dtf_engine_transposes(self._d(), int(wd1), int(wc2), self._s()), "transposes")
+    def refresh_transposes(self, wc2: bool = True):
+        """K-contiguous copy of the conv2 filter for the forward kernel (wd1 is used in place)."""
+        check(self.lib.dtf_engine_transposes(self._d(), int(wc2), self._s()), "transposes")
 
     def launch_update(self, advance_cursor: bool = True):
         self.launch_update_range(0, self.layout.total, True, advance_cursor)
@@ -323,7 +326,7 @@ class HipEngine:
         The warm-up launches (lazy kernel attribute set-up must not happen under capture) run real
         steps, so parameters / optimizer moments / step state are snapshotted and restored:
         capturing is invisible to training."""
-        keep = [self.params, self.state, self.shadow, self.wd1T, self.wc2T]
+        keep = [self.params, self.state, self.shadow, self.wc2T]
         if self.optimizer == "adam":
             keep += [self.adam_m, self.adam_v]
         snap = [t.clone() for t in keep]

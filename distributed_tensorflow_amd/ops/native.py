@@ -34,6 +34,8 @@ _SIGS = {
     "dtf_gemm_nt": [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_int,
                     c_float, c_uint64, c_void_p, c_int, c_void_p],
     "dtf_gemm_tn": [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p],
+    "dtf_gemm_nn_fwd": [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int,
+                        c_float, c_uint64, c_void_p, c_void_p],
     "dtf_transpose_bf16": [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p],
     "dtf_head_fwd_bwd": [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                          c_void_p, c_void_p, c_int, c_int, c_float, c_float, c_int, c_void_p],
@@ -63,7 +65,7 @@ class EngineDesc(ctypes.Structure):
         + [("seed", c_uint64), ("keep_prob", c_float), ("pad1", c_float), ("n_total", c_long)]
         + [(n, c_long) for n in ("off_out_w", "off_out_b", "off_bd1", "off_wd1", "off_wc2", "off_bc2", "off_wc1",
                                  "off_bc1", "head_stride", "c2_stride", "c1_stride")]
-        + [(n, c_void_p) for n in ("params", "grads", "shadow", "wd1T", "wc2T", "adam_m", "adam_v", "state", "hyper",
+        + [(n, c_void_p) for n in ("params", "grads", "shadow", "fc1_part", "wc2T", "adam_m", "adam_v", "state", "hyper",
                                    "idx", "p1", "arg1", "p2", "arg2", "h1", "logits", "loss_rows", "correct_rows",
                                    "dlogits", "da", "dflat", "dp1", "head_part", "c2_part", "c1_part", "ds_images",
                                    "ds_labels")]
@@ -84,7 +86,7 @@ _ENGINE_SIGS = {
     "dtf_engine_backward_conv": [_EP, c_void_p, c_void_p, c_int, c_void_p],
     "dtf_engine_backward": [_EP, c_void_p, c_void_p, c_void_p],
     "dtf_engine_update_range": [_EP, c_long, c_long, c_int, c_int, c_long, c_int, c_void_p],
-    "dtf_engine_transposes": [_EP, c_int, c_int, c_void_p],
+    "dtf_engine_transposes": [_EP, c_int, c_void_p],
     "dtf_engine_train_step": [_EP, c_long, c_void_p],
 }
 

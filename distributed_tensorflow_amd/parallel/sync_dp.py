@@ -54,7 +54,7 @@ class SyncDataParallel:
       C: fc1 fwd, head fwd/bwd               |   conv backward of t-1 AND the conv forward of t to finish
       C: head wgrad, slab reduce, fc1 wgrad  -> event dense_ready
       A:   all-reduce(head|wd1 buckets) ... then (after fc1 dgrad has read the old weights)
-      A:   optimizer on the dense range + wd1 transpose -> event dense_updated
+      A:   optimizer on the dense range (fp32 master + bf16 copy) -> event dense_updated
       C: fc1 dgrad, conv2 dgrad || wgrad, conv1 wgrad, slab reduce -> event tail_ready
       B:   all-reduce(conv tail)   (second communicator: runs concurrently with A)
       C: wait(B); optimizer on the conv tail (+ cursor / global_step advance), wc2 transpose
@@ -118,7 +118,6 @@ class SyncDataParallel:
             # the dense update overwrites the bf16 wd1 that fc1 dgrad reads: order it after that kernel
             eng.wait_dgrad_event()
             eng.launch_update_range(0, self.n_dense, advance=False, adam_slot=self.DENSE_SLOT)
-            eng.refresh_transposes(wd1=True, wc2=False)
             self._ev_dense_updated.record(self.comm_stream)
         with torch.cuda.stream(self.tail_stream):
             self.tail_stream.wait_event(self._ev_tail_ready)
@@ -126,7 +125,7 @@ class SyncDataParallel:
             self._ev_tail_reduced.record(self.tail_stream)
         cur.wait_event(self._ev_tail_reduced)
         eng.launch_update_range(self.n_dense, eng.layout.total, advance=True, adam_slot=self.TAIL_SLOT)
-        eng.refresh_transposes(wd1=False, wc2=True)
+        eng.refresh_transposes(wc2=True)
         if self.defer:
             self._have_pending_dense = True
         else:

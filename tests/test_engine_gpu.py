@@ -55,8 +55,7 @@ def test_step_matches_oracle(gpu_lib, dataset, B):
     for name in eng.layout.names():
         assert rel_err(p[name] - p0[name], p_ref[name] - p0[name]) < 5e-2, name
     # bf16 shadows/transposes follow the master weights
-    wd1 = eng.pview("wd1")
-    assert torch.equal(eng.wd1T, wd1.to(torch.bfloat16).t().contiguous())
+    assert torch.equal(eng.shadow, eng.params.to(torch.bfloat16))
     wc2 = eng.pview("wc2").reshape(25, spec.c1, spec.c2)
     assert torch.equal(eng.wc2T, wc2.to(torch.bfloat16).transpose(1, 2).contiguous())
 
@@ -128,7 +127,7 @@ def test_sync_dp_world1_rccl_matches_plain_engine(gpu_lib, dataset):
         dp.flush()
         torch.cuda.synchronize()
         assert torch.equal(a.params, b.params)
-        assert torch.equal(a.wd1T, b.wd1T) and torch.equal(a.wc2T, b.wc2T)
+        assert torch.equal(a.shadow, b.shadow) and torch.equal(a.wc2T, b.wc2T)
         assert a.global_step == b.global_step == 5
         # Adam: per-range step counters keep the deferred dense update and the tail update in step
         a2 = HipEngine(ModelSpec(), 64, dataset, optimizer="adam", learning_rate=1e-3, seed=4)

@@ -186,6 +186,28 @@ def test_gemm_nt(gpu_lib, M, N, K, tile):
     assert rel_err(C, F.relu(ref + bias)) < 4e-3
 
 
+@pytest.mark.parametrize("M,N,K,S", [(1024, 1024, 3136, 0), (100, 1024, 3136, 0), (257, 384, 192, 3), (64, 128, 64, 1)])
+def test_gemm_nn_splitk_forward(gpu_lib, M, N, K, S):
+    g = torch.Generator(device="cpu").manual_seed(15)
+    A = bf(torch.randn(M, K, generator=g)).to(DEV)
+    Bm = bf(torch.randn(K, N, generator=g) * 0.05 + torch.arange(N).float()[None, :] * 1e-3).to(DEV)
+    bias = torch.randn(N, generator=g).to(DEV)
+    part = torch.empty(8, M, N, device=DEV)
+    out = torch.empty(M, N, dtype=torch.bfloat16, device=DEV)
+    check(gpu_lib.dtf_gemm_nn_fwd(ptr(A), ptr(Bm), ptr(part), ptr(out), ptr(bias), M, N, K, K, N, S, 1.0, 0, None,
+                                  stream()), "gemm_nn_fwd")
+    ref = F.relu(A.float() @ Bm.float() + bias)
+    assert rel_err(out, ref) < 4e-3
+    # dropout through the split-K epilogue: same mask semantics as the fused GEMM epilogue
+    state = torch.zeros(8, dtype=torch.int64, device=DEV)
+    o1 = torch.empty_like(out)
+    check(gpu_lib.dtf_gemm_nn_fwd(ptr(A), ptr(Bm), ptr(part), ptr(o1), ptr(bias), M, N, K, K, N, S, 0.5, 3, ptr(state),
+                                  stream()), "gemm_nn_fwd drop")
+    kept = o1.float() > 0
+    assert abs(float(kept.float().mean()) / float((ref > 0).float().mean()) - 0.5) < 0.05
+    assert rel_err(o1.float()[kept], (2 * ref)[kept]) < 4e-3
+
+
 def test_gemm_nt_dropout(gpu_lib):
     M, N, K, keep = 256, 1024, 256, 0.75
     g = torch.Generator(device="cpu").manual_seed(6)
