@@ -53,8 +53,8 @@ enum { MODE_FWD = 0, MODE_DGRAD = 1 };
 // ----------------------------------------------------------------------------
 // KTOT = reduction channels of the layer, KC = channels resident in LDS at a time (KTOT is
 // walked in KC chunks when the full tile would not fit the 160 KiB LDS).
-template <int KTOT, int KC, int NC, int IMGS, int NW, int MODE>
-__global__ __launch_bounds__(IMGS * 2 * NW * 64) void conv5x5_igemm(
+template <int KTOT, int KC, int NC, int IMGS, int NW, int MODE, int MINW>
+__global__ __launch_bounds__(IMGS * 2 * NW * 64, MINW) void conv5x5_igemm(
     const bf16* __restrict__ in, const uint8_t* __restrict__ in_arg,
     const bf16* __restrict__ in_pooled, const bf16* __restrict__ wk,
     const float* __restrict__ bias, bf16* __restrict__ out, uint8_t* __restrict__ out_arg,
@@ -398,13 +398,13 @@ using namespace dtf;
 
 #define DTF_LAUNCH_CHECK() (int)hipGetLastError()
 
-template <int KTOT, int KC, int NC, int IMGS, int NW, int MODE>
+template <int KTOT, int KC, int NC, int IMGS, int NW, int MODE, int MINW = 1>
 static int launch_igemm(const void* in, const void* in_arg, const void* in_pooled, const void* wk,
                         const void* bias, void* out, void* out_arg, int B, hipStream_t s) {
   constexpr int threads = IMGS * 2 * NW * 64;
   constexpr int KP = (KC % 64 == 0) ? KC + 8 : KC;
   constexpr size_t lds = (size_t)IMGS * kTilePos * KP * 2;
-  auto kern = conv5x5_igemm<KTOT, KC, NC, IMGS, NW, MODE>;
+  auto kern = conv5x5_igemm<KTOT, KC, NC, IMGS, NW, MODE, MINW>;
   static bool attr_set = false;
   if (!attr_set) {
     (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -423,7 +423,7 @@ extern "C" {
 int dtf_conv2_fwd(const void* x, const void* wT, const void* bias, void* pooled, void* arg, int B,
                   int cin, int cout, hipStream_t s) {
   if (cin == 32 && cout == 64)
-    return launch_igemm<32, 32, 64, 1, 2, MODE_FWD>(x, nullptr, nullptr, wT, bias, pooled, arg, B, s);
+    return launch_igemm<32, 32, 64, 1, 2, MODE_FWD, 4>(x, nullptr, nullptr, wT, bias, pooled, arg, B, s);
   if (cin == 128 && cout == 256)
     return launch_igemm<128, 128, 256, 1, 4, MODE_FWD>(x, nullptr, nullptr, wT, bias, pooled, arg, B, s);
   return -1;
@@ -433,7 +433,7 @@ int dtf_conv2_fwd(const void* x, const void* wT, const void* bias, void* pooled,
 int dtf_conv2_dgrad(const void* gpool, const void* arg, const void* pooled, const void* w, void* dx,
                     int B, int cin, int cout, hipStream_t s) {
   if (cin == 32 && cout == 64)
-    return launch_igemm<64, 64, 32, 1, 2, MODE_DGRAD>(gpool, arg, pooled, w, nullptr, dx, nullptr, B, s);
+    return launch_igemm<64, 32, 32, 1, 2, MODE_DGRAD, 4>(gpool, arg, pooled, w, nullptr, dx, nullptr, B, s);
   if (cin == 128 && cout == 256)
     return launch_igemm<256, 128, 128, 1, 2, MODE_DGRAD>(gpool, arg, pooled, w, nullptr, dx, nullptr, B, s);
   return -1;

@@ -10,13 +10,21 @@
 
 namespace dtf {
 
-// idx[i] = perm_epoch(pos) for the global sample number cursor + i
+// idx[i] = perm_epoch(pos) for the global sample number cursor + i.  The one 64-bit division
+// (cursor / n) is done by a single lane per block; lanes then use 32-bit arithmetic only.
 __global__ void sample_indices(const int64_t* __restrict__ state, int* __restrict__ idx, int B, uint32_t n,
                                uint32_t hb, uint32_t seed, int shuffle) {
+  __shared__ uint32_t s_epoch, s_pos;
+  if (threadIdx.x == 0) {
+    uint64_t c = (uint64_t)state[0];
+    s_epoch = (uint32_t)(c / n);
+    s_pos = (uint32_t)(c % n);
+  }
+  __syncthreads();
   int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= B) return;
-  uint64_t s = (uint64_t)state[0] + (uint64_t)i;
-  uint32_t epoch = (uint32_t)(s / n), pos = (uint32_t)(s % n);
+  uint32_t epoch = s_epoch + (s_pos + (uint32_t)i) / n;   // batches may span epochs (B can exceed n)
+  uint32_t pos = (s_pos + (uint32_t)i) % n;
   idx[i] = shuffle ? (int)feistel_permute(pos, n, hb, mix32(seed + epoch * 0x9E3779B9u)) : (int)pos;
 }
 

@@ -36,6 +36,27 @@ __device__ __forceinline__ float dropout_scale(const DropoutArgs& d, uint64_t of
   return u32_to_unit_float(r[0]) < d.keep_prob ? 1.0f / d.keep_prob : 0.f;
 }
 
+// XCD-aware tile assignment.  Workgroups are dealt round-robin over the 8 XCDs (private 4 MiB
+// L2 each), so linear ids L and L+8 share an L2.  These GEMMs are small enough that every tile is
+// resident at once and the whole grid marches through K in step; what bounds them is fabric/HBM
+// traffic (measured: ~11 B/clk/CU, i.e. operand panels re-fetched by every XCD).  Giving each XCD a
+// compact BH x (chunk/BH) rectangle of tiles makes its L2 fetch each A/B panel once per rectangle
+// instead of once per tile.  Bijective for any tile count (guide T1).
+__device__ __forceinline__ void xcd_tile(int gx, int gy, int& tx, int& ty) {
+  constexpr int NX = 8, BH = 4;
+  const int total = gx * gy;
+  const int L = blockIdx.x + gx * blockIdx.y;
+  const int xcd = L % NX, slot = L / NX;
+  const int q = total / NX, r = total % NX;
+  const int idx = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + slot;
+  // banded column-major order: bands of BH tile rows, walked column by column
+  const int band = idx / (BH * gx);
+  const int rem = idx - band * BH * gx;
+  const int h = min(BH, gy - band * BH);
+  tx = rem / h;
+  ty = band * BH + rem % h;
+}
+
 template <int BM, int BN, int EPI>
 __global__ __launch_bounds__(256) void gemm_nt_bf16(const bf16* __restrict__ A, const bf16* __restrict__ Bm,
                                                     bf16* __restrict__ C, const float* __restrict__ bias,
@@ -50,7 +71,9 @@ __global__ __launch_bounds__(256) void gemm_nt_bf16(const bf16* __restrict__ A, 
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave >> 1, wn = wave & 1;
-  const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
+  int tile_x, tile_y;
+  xcd_tile(gridDim.x, gridDim.y, tile_x, tile_y);
+  const int m0 = tile_y * BM, n0 = tile_x * BN;
   const int i16 = lane & 15, g = lane >> 4;
 
   f32x4 acc[MT][NTL];
@@ -170,7 +193,9 @@ __global__ __launch_bounds__(256) void gemm_tn_bf16(const bf16* __restrict__ A, 
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave >> 1, wn = wave & 1;
-  const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
+  int tile_x, tile_y;
+  xcd_tile(gridDim.x, gridDim.y, tile_x, tile_y);
+  const int m0 = tile_y * BM, n0 = tile_x * BN;
   const int i16 = lane & 15, g = lane >> 4;
   const int qr = i16 >> 2, pc = i16 & 3;
 
@@ -286,7 +311,9 @@ __global__ __launch_bounds__(256) void gemm_nn_splitk_bf16(const bf16* __restric
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave >> 1, wn = wave & 1;
-  const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
+  int tile_x, tile_y;
+  xcd_tile(gridDim.x, gridDim.y, tile_x, tile_y);
+  const int m0 = tile_y * BM, n0 = tile_x * BN;
   const int i16 = lane & 15, g = lane >> 4;
   const int qr = i16 >> 2, pc = i16 & 3;
   const int T_all = (K + BK - 1) / BK;

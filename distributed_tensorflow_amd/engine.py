@@ -131,7 +131,7 @@ class HipEngine:
         self.dp1 = torch.empty((B, 14, 14, C1), **bf)
 
         # split-K geometry
-        self.head_ks = max(1, min(16, B // 16))
+        self.head_ks = max(1, min(32, B // 8))
         self.head_stride = H * spec.classes + 12 + H
         self.head_part = torch.empty((self.head_ks, self.head_stride), **f32)
         self.c2_g = max(1, min((B + 1) // 2, 102))
