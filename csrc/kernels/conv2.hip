@@ -19,17 +19,17 @@
 //   the taps flipped.
 //
 // wgrad (conv5x5_wgrad): dW[tap][ci][co] = sum_pos X[pos+tap][ci] * dY[pos][co]
-//   M = 32 input channels, N = 64 output channels, K = positions.  The X tile
-//   is [pos][ci] in LDS (K-slow), so A fragments come from the gfx950
-//   transposing LDS read (ds_read_b64_tr_b16); the dY fragment is built in
-//   registers straight from the pooled gradient + argmax (never expanded in
-//   memory).  Split-K over images across workgroups; partial slabs are summed
-//   by reduce_partials (optim.hip).
+//   M = input channels, N = output channels, K = positions.  Both the X tile [pos][ci] and the
+//   max-pool/ReLU-expanded dY tile [pos][co] are K-slow in LDS, so both fragments come from the
+//   gfx950 transposing LDS read (ds_read_b64_tr_b16); dY is expanded in LDS only, never in
+//   memory.  Split-K over images across workgroups; partial slabs are summed by
+//   reduce_segments (optim.hip).
 #include "common.hpp"
 
 // Timing-ablation hook (tools/conv_ablate.py builds diagnostic copies with -DDTF_ABLATE=<bits>;
 // the shipped library always has 0): 1 = no B global loads in the k-loop, 2 = no A LDS reads,
-// 4 = no MFMAs, 8 = no staging loads, 16 = no epilogue stores.
+// 4 = no MFMAs, 8 = no staging loads, 16 = no epilogue stores; wgrad: 32 = no x staging,
+// 64 = no MFMAs, 128 = no dY staging/expansion, 256 = no k-loop at all, 512 = no slab write.
 #ifndef DTF_ABLATE
 #define DTF_ABLATE 0
 #endif
@@ -229,162 +229,198 @@ __global__ __launch_bounds__(IMGS * 2 * NW * 64, MINW) void conv5x5_igemm(
 }
 
 // ----------------------------------------------------------------------------
-// wgrad.  grid = (G image chunks, 5 tap rows ky, (C_IN/32)*(C_OUT/64) tiles)
+// wgrad.  grid = (G image chunks, (C_IN/16) * (C_OUT/32) output tiles)
 //   x      [B,14,14,C_IN] bf16   layer input
 //   gpool  [B,7,7,C_OUT]  bf16   gradient wrt pooled output
 //   arg    [B,7,7,C_OUT]  u8     saved argmax
 //   pooled [B,7,7,C_OUT]  bf16   forward pooled output (ReLU mask = pooled > 0)
 //   part   [G][25*C_IN*C_OUT + C_OUT] fp32 partial slabs (HWIO order, then bias)
-// Per image the block stages two LDS images: the halo-padded input tile
-// [pos][32 ci] and the max-pool/ReLU-expanded output gradient [row pair][k][64 co]
-// (k = 16*dy + x, the K order of a row pair).  Both are K-slow, so A and B
-// fragments both come from ds_read_b64_tr_b16; 32-byte sub-slots are XOR
-// swizzled so every transposed read is bank-conflict free.
-// 4 waves = (mi: 16 input channels) x (kh: alternate row pairs); a wave owns
-// 5 taps x 4 n-tiles = 20 accumulator tiles, so each A fragment feeds 4 MFMAs
-// and each B fragment 5.  The two kh halves are summed through LDS at the end.
+// A block owns ALL 25 taps of a 16(ci) x 32(co) output tile, so the two LDS images it stages per
+// image -- the halo-padded input [pos][16 ci] and the max-pool/ReLU-expanded output gradient
+// [row pair][k][32 co] (k = 16*dy + x) -- are each staged by only C_OUT/32 resp. C_IN/16 blocks.
+// Both images are K-slow, so A and B fragments come from ds_read_b64_tr_b16 (the input image
+// is conflict-free as is; the 32-byte halves of the gradient image are XOR-swizzled by k>>2).
+// Waves split the taps (7/6/6/6): a wave holds 7 taps x 2 n-tiles of accumulators and each B
+// fragment feeds every tap.
 // Element j of lane group g  <->  dy = g>>1, x = 4*(g&1) + (j&3) + 8*(j>>2).
 // ----------------------------------------------------------------------------
-constexpr int kWgXTileBytes = kTilePos * 32 * 2;   // 20992
-constexpr int kWgDyTileBytes = 7 * 32 * 64 * 2;    // 28672
+constexpr int kWgXTileBytes = kTilePos * 16 * 2;   // 10496
+constexpr int kWgDyTileBytes = 7 * 32 * 32 * 2;    // 14336
+constexpr int kWgRedBytes = 4 * 58 * 64 * 4;       // 59392: end-of-kernel reduction of the two k halves
 
+// 8 waves = (tw: tap group, taps tw, tw+4, ..) x (kh: alternate row pairs).  Two waves per SIMD let
+// the transposed LDS reads of one wave run under the MFMAs of the other; the global loads of image
+// b+1 are issued before the k-loop of image b (register prefetch) and expanded/written to LDS after
+// it.  The two kh halves are summed through LDS once, at the end.
 template <int C_IN, int C_OUT>
-__global__ __launch_bounds__(256) void conv5x5_wgrad(
+__global__ __launch_bounds__(512, 2) void conv5x5_wgrad(
     const bf16* __restrict__ x, const bf16* __restrict__ gpool,
     const uint8_t* __restrict__ arg, const bf16* __restrict__ pooled,
     float* __restrict__ part, int B, int imgs_per_block) {
-  constexpr int CI_T = C_IN / 32;
+  constexpr int CI_T = C_IN / 16;
   typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
   typedef __attribute__((ext_vector_type(8))) short s16x8;
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  bf16* xt = reinterpret_cast<bf16*>(smem);                  // [328][32], halves swizzled
-  bf16* dyt = reinterpret_cast<bf16*>(smem + kWgXTileBytes);  // [7][32][64], 32-B slots swizzled
+  __shared__ __attribute__((aligned(16))) char smem[kWgRedBytes];
+  bf16* xt = reinterpret_cast<bf16*>(smem);                   // [328][16]
+  bf16* dyt = reinterpret_cast<bf16*>(smem + kWgXTileBytes);  // [7][32][32], 32-B halves swizzled
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int mi = wave & 1, kh = wave >> 1;
-  const int ky = blockIdx.y;
-  const int ci_t = blockIdx.z % CI_T, co_t = blockIdx.z / CI_T;
+  const int tw = wave & 3, kh = wave >> 2;
+  const int ci_t = blockIdx.y % CI_T, co_t = blockIdx.y / CI_T;
   const int g = lane >> 4, i16 = lane & 15;
   const int qr = i16 >> 2, pc = i16 & 3;
-  const bool do_bias = (ky == 0) && (ci_t == 0) && (mi == 0);
+  const bool do_bias = (ci_t == 0) && (tw == 0);
 
   const int b_begin = blockIdx.x * imgs_per_block;
   const int b_end = min(B, b_begin + imgs_per_block);
 
-  f32x4 acc[5][4];
+  f32x4 acc[7][2];
 #pragma unroll
-  for (int t = 0; t < 5; ++t)
+  for (int t = 0; t < 7; ++t)
 #pragma unroll
-    for (int j = 0; j < 4; ++j) acc[t][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
-  float bsum[4] = {0.f, 0.f, 0.f, 0.f};
+    for (int j = 0; j < 2; ++j) acc[t][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  float bsum[2] = {0.f, 0.f};
 
   // zero once: halo, slack and the x = 14,15 dummy columns stay zero
-  for (int i = tid; i < (kWgXTileBytes + kWgDyTileBytes) / 16; i += 256)
+  for (int i = tid; i < (kWgXTileBytes + kWgDyTileBytes) / 16; i += 512)
     reinterpret_cast<u32x4*>(smem)[i] = (u32x4){0u, 0u, 0u, 0u};
 
-  const int tr_pos = (ky + (g >> 1)) * kTileW + 4 * (g & 1) + qr;  // A: row pair 0, kx 0, first read
-  const int kkrow = (g >> 1) * 16 + 4 * (g & 1) + qr;              // B: k row of the first read
-  const int bsw = (kkrow >> 1) & 3;                                // its slot swizzle (same for +8)
+  const int tr_pos = (g >> 1) * kTileW + 4 * (g & 1) + qr;   // A: row pair 0, tap (0,0), first read
+  const int kkrow = (g >> 1) * 16 + 4 * (g & 1) + qr;        // B: k row of the first read
+  const int bsw = (kkrow >> 2) & 1;                          // its half swizzle; the +8 read has the same
+  // element offsets of this wave's taps (tw + 4t; the 7th tap of groups 1..3 does not exist and is
+  // clamped to tap 24: computed branch-free and discarded, so the k-loop has no control flow)
+  int tap_off[7];
+#pragma unroll
+  for (int t = 0; t < 7; ++t) {
+    const int tap = min(tw + 4 * t, 24);
+    tap_off[t] = ((tap / 5) * kTileW + tap % 5) * 16;
+  }
+  const bf16* a_lane = xt + tr_pos * 16 + pc * 4;
 
-  for (int b = b_begin; b < b_end; ++b) {
-    __syncthreads();  // previous image fully consumed (and the zero fill done)
-    for (int c = tid; c < 196 * 4; c += 256) {
-      int ch = c & 3, pos = c >> 2;
-      u32x4 v = *reinterpret_cast<const u32x4*>(x + ((size_t)b * 196 + pos) * C_IN + ci_t * 32 + ch * 8);
-      int y = pos / 14, xx = pos % 14;
-      int tp = (y + 2) * kTileW + (xx + 2);
-      int chs = ch ^ (((tp >> 2) & 1) << 1);  // swap 32-byte halves on odd 4-position groups
-      *reinterpret_cast<u32x4*>(xt + tp * 32 + chs * 8) = v;
+  // staging roles: threads 0..391 own one 16-byte chunk of the input tile, threads 0..195 one
+  // (pooled position, 8-channel chunk) item of the gradient expansion
+  const bool has_x = tid < 196 * 2, has_dy = tid < 49 * 4;
+  const int x_ch = tid & 1, x_pos = tid >> 1;
+  const int x_tp = (x_pos / 14 + 2) * kTileW + (x_pos % 14 + 2);
+  const int d_c8 = tid & 3, d_pp = tid >> 2;
+  u32x4 xr = {0u, 0u, 0u, 0u};
+  bf16x8 gv_r, pv_r;
+  u32x2 ar_r = {0u, 0u};
+  auto prefetch = [&](int b) {
+    if (has_x && !(DTF_ABLATE & 32))
+      xr = *reinterpret_cast<const u32x4*>(x + ((size_t)b * 196 + x_pos) * C_IN + ci_t * 16 + x_ch * 8);
+    if (has_dy && !(DTF_ABLATE & 128)) {
+      size_t off = ((size_t)b * 49 + d_pp) * C_OUT + co_t * 32 + d_c8 * 8;
+      gv_r = *reinterpret_cast<const bf16x8*>(gpool + off);
+      pv_r = *reinterpret_cast<const bf16x8*>(pooled + off);
+      ar_r = *reinterpret_cast<const u32x2*>(arg + off);
     }
-    for (int c = tid; c < 49 * 8; c += 256) {
-      int c8 = c & 7, pp = c >> 3;
-      int r = pp / 7, w = pp % 7;
-      size_t off = ((size_t)b * 49 + pp) * C_OUT + co_t * 64 + c8 * 8;
-      bf16x8 gv = *reinterpret_cast<const bf16x8*>(gpool + off);
-      bf16x8 pv = *reinterpret_cast<const bf16x8*>(pooled + off);
-      u32x2 a2 = *reinterpret_cast<const u32x2*>(arg + off);
+  };
+  auto stage = [&]() {
+    if (has_x && !(DTF_ABLATE & 32)) *reinterpret_cast<u32x4*>(xt + x_tp * 16 + x_ch * 8) = xr;
+    if (has_dy && !(DTF_ABLATE & 128)) {
+      const int r = d_pp / 7, w = d_pp % 7;
       bf16x8 o[4];
 #pragma unroll
       for (int e = 0; e < 8; ++e) {
-        unsigned a = ((e < 4 ? a2[0] : a2[1]) >> ((e & 3) * 8)) & 0xffu;
-        bool live = (float)pv[e] > 0.f;
+        unsigned a = ((e < 4 ? ar_r[0] : ar_r[1]) >> ((e & 3) * 8)) & 0xffu;
+        bool live = (float)pv_r[e] > 0.f;
 #pragma unroll
-        for (int q = 0; q < 4; ++q) o[q][e] = (live && a == (unsigned)q) ? gv[e] : (bf16)0.f;
+        for (int q = 0; q < 4; ++q) o[q][e] = (live && a == (unsigned)q) ? gv_r[e] : (bf16)0.f;
       }
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
         int kk = (q >> 1) * 16 + 2 * w + (q & 1);
-        int slot = (((c8 >> 1) ^ ((kk >> 1) & 3)) << 1) | (c8 & 1);
-        *reinterpret_cast<bf16x8*>(dyt + (r * 32 + kk) * 64 + slot * 8) = o[q];
+        int slot = (((d_c8 >> 1) ^ ((kk >> 2) & 1)) << 1) | (d_c8 & 1);
+        *reinterpret_cast<bf16x8*>(dyt + (r * 32 + kk) * 32 + slot * 8) = o[q];
       }
     }
+  };
+
+  if (b_begin < b_end) prefetch(b_begin);
+  for (int b = b_begin; b < b_end; ++b) {
+    __syncthreads();  // previous image fully consumed (and the zero fill done)
+    stage();
     __syncthreads();
+    if (b + 1 < b_end) prefetch(b + 1);
 #pragma unroll 1
-    for (int r = (kh + b) & 1; r < 7; r += 2) {
-      bf16x8 bfrag[4];
+    for (int r = (kh + b) & 1; r < ((DTF_ABLATE & 256) ? 0 : 7); r += 2) {
+      bf16x8 bfrag[2];
 #pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        const bf16* p0 = dyt + (r * 32 + kkrow) * 64 + ((j ^ bsw) << 4) + pc * 4;
+      for (int j = 0; j < 2; ++j) {
+        const bf16* p0 = dyt + (r * 32 + kkrow) * 32 + ((j ^ bsw) << 4) + pc * 4;
         s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)p0);
-        s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(p0 + 8 * 64));
+        s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(p0 + 8 * 32));
         s16x8 v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
         bfrag[j] = __builtin_bit_cast(bf16x8, v);
       }
       if (do_bias) {
 #pragma unroll
-        for (int j = 0; j < 4; ++j)
+        for (int j = 0; j < 2; ++j)
 #pragma unroll
           for (int e = 0; e < 8; ++e) bsum[j] += (float)bfrag[j][e];
       }
+      bf16x8 afrag[7];
 #pragma unroll
-      for (int kx = 0; kx < 5; ++kx) {
-        const int p0 = tr_pos + 2 * r * kTileW + kx;
-        const int p1 = p0 + 8;
-        const int h0 = mi ^ ((p0 >> 2) & 1), h1 = mi ^ ((p1 >> 2) & 1);
-        s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(xt + p0 * 32 + h0 * 16 + pc * 4));
-        s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(xt + p1 * 32 + h1 * 16 + pc * 4));
+      for (int t = 0; t < 7; ++t) {
+        const bf16* p0 = a_lane + 2 * r * kTileW * 16 + tap_off[t];
+        s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)p0);
+        s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(p0 + 8 * 16));
         s16x8 av = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
-        bf16x8 afrag = __builtin_bit_cast(bf16x8, av);
+        afrag[t] = __builtin_bit_cast(bf16x8, av);
+      }
 #pragma unroll
-        for (int j = 0; j < 4; ++j) acc[kx][j] = mfma16(afrag, bfrag[j], acc[kx][j]);
+      for (int t = 0; t < 7; ++t) {
+        if (DTF_ABLATE & 64) {
+          asm volatile("" ::"v"(afrag[t]), "v"(bfrag[0]), "v"(bfrag[1]));
+        } else {
+          acc[t][0] = mfma16(afrag[t], bfrag[0], acc[t][0]);
+          acc[t][1] = mfma16(afrag[t], bfrag[1], acc[t][1]);
+        }
       }
     }
   }
 
-  // ---- sum the two kh halves through LDS, then write the slab ----
+  // ---- sum the two kh halves through LDS; kh = 0 waves write their taps: rows ci, cols co ----
   __syncthreads();
-  float* red = reinterpret_cast<float*>(smem);  // [mi][84][64 lanes]
+  float* red = reinterpret_cast<float*>(smem);  // [tw][58][64 lanes]
   if (kh == 1) {
 #pragma unroll
-    for (int kx = 0; kx < 5; ++kx)
+    for (int t = 0; t < 7; ++t)
 #pragma unroll
-      for (int j = 0; j < 4; ++j)
+      for (int j = 0; j < 2; ++j)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) red[(mi * 84 + (kx * 4 + j) * 4 + r) * 64 + lane] = acc[kx][j][r];
-#pragma unroll
-    for (int j = 0; j < 4; ++j) red[(mi * 84 + 80 + j) * 64 + lane] = bsum[j];
+        for (int r = 0; r < 4; ++r) red[(tw * 58 + (t * 2 + j) * 4 + r) * 64 + lane] = acc[t][j][r];
+    red[(tw * 58 + 56) * 64 + lane] = bsum[0];
+    red[(tw * 58 + 57) * 64 + lane] = bsum[1];
   }
   __syncthreads();
   if (kh == 1) return;
   float* slab = part + (size_t)blockIdx.x * (25 * C_IN * C_OUT + C_OUT);
 #pragma unroll
-  for (int kx = 0; kx < 5; ++kx)
+  for (int t = 0; t < 7; ++t) {
+    const int tap = tw + 4 * t;
+    if (tap < 25) {
 #pragma unroll
-    for (int j = 0; j < 4; ++j)
+      for (int j = 0; j < 2; ++j)
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        int ci = ci_t * 32 + mi * 16 + 4 * g + r;
-        int co = co_t * 64 + j * 16 + i16;
-        slab[((size_t)(ky * 5 + kx) * C_IN + ci) * C_OUT + co] =
-            acc[kx][j][r] + red[(mi * 84 + (kx * 4 + j) * 4 + r) * 64 + lane];
-      }
+        for (int r = 0; r < 4; ++r) {
+          int ci = ci_t * 16 + 4 * g + r;
+          int co = co_t * 32 + j * 16 + i16;
+          float v = acc[t][j][r] + red[(tw * 58 + (t * 2 + j) * 4 + r) * 64 + lane];
+          if ((DTF_ABLATE & 512) && v != 12345.f) continue;
+          slab[((size_t)tap * C_IN + ci) * C_OUT + co] = v;
+        }
+    }
+  }
   if (do_bias) {
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      float s = bsum[j] + red[(mi * 84 + 80 + j) * 64 + lane];
+    for (int j = 0; j < 2; ++j) {
+      float s = bsum[j] + red[(tw * 58 + 56 + j) * 64 + lane];
       s += __shfl_xor(s, 16, 64);
       s += __shfl_xor(s, 32, 64);
-      if (g == 0) slab[25 * C_IN * C_OUT + co_t * 64 + j * 16 + i16] = s;
+      if (g == 0) slab[25 * C_IN * C_OUT + co_t * 32 + j * 16 + i16] = s;
     }
   }
 }
@@ -445,12 +481,12 @@ int dtf_conv2_wgrad(const void* x, const void* gpool, const void* arg, const voi
   if (G <= 0) return -2;
   int ipb = (B + G - 1) / G;
   if (cin == 32 && cout == 64) {
-    hipLaunchKernelGGL((conv5x5_wgrad<32, 64>), dim3(G, 5, 1), dim3(256), kWgXTileBytes + kWgDyTileBytes, s, (const bf16*)x,
+    hipLaunchKernelGGL((conv5x5_wgrad<32, 64>), dim3(G, 4), dim3(512), 0, s, (const bf16*)x,
                        (const bf16*)gpool, (const uint8_t*)arg, (const bf16*)pooled, (float*)part, B, ipb);
     return DTF_LAUNCH_CHECK();
   }
   if (cin == 128 && cout == 256) {
-    hipLaunchKernelGGL((conv5x5_wgrad<128, 256>), dim3(G, 5, 16), dim3(256), kWgXTileBytes + kWgDyTileBytes, s, (const bf16*)x,
+    hipLaunchKernelGGL((conv5x5_wgrad<128, 256>), dim3(G, 64), dim3(512), 0, s, (const bf16*)x,
                        (const bf16*)gpool, (const uint8_t*)arg, (const bf16*)pooled, (float*)part, B, ipb);
     return DTF_LAUNCH_CHECK();
   }

@@ -18,6 +18,7 @@ Memory plan (all resident, sized once for ``batch``):
 from __future__ import annotations
 
 import ctypes
+import os
 from dataclasses import dataclass
 from typing import Dict, Optional
 
@@ -134,7 +135,7 @@ class HipEngine:
         self.head_ks = max(1, min(32, B // 8))
         self.head_stride = H * spec.classes + 12 + H
         self.head_part = torch.empty((self.head_ks, self.head_stride), **f32)
-        self.c2_g = max(1, min((B + 1) // 2, 102))
+        self.c2_g = max(1, min((B + 1) // 2, int(os.environ.get("DTF_C2_G", "64"))))
         self.c2_stride = 25 * C1 * C2 + C2
         self.c2_part = torch.empty((self.c2_g, self.c2_stride), **f32)
         self.c1_g = max(1, min(B, 512))

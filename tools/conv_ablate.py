@@ -1,11 +1,11 @@
-"""Ablation timing of the conv2 forward kernel: builds diagnostic copies of conv2.hip with parts
+"""Ablation timing of the conv2 wgrad kernel (edit VARIANTS/call for fwd/dgrad): builds diagnostic copies of conv2.hip with parts
 of the kernel removed (-DDTF_ABLATE bits, see conv2.hip) and times each on the GPU.
 Build step runs on the CPU box: python tools/conv_ablate.py build ; timing: ... run"""
 import ctypes, os, subprocess, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 OUT = os.path.join(ROOT, "diag_build")
-VARIANTS = {0: "full", 1: "no B loads", 2: "no A reads", 4: "no MFMA", 8: "no staging loads", 16: "no epilogue stores",
-            3: "no A, no B", 7: "no A,B,MFMA", 31: "empty shell"}
+VARIANTS = {0: "full", 32: "no x staging", 128: "no dY staging", 160: "no staging at all", 64: "no MFMA",
+            256: "no k-loop", 416: "syncs+slab write only", 512: "no slab write", 928: "empty"}
 if sys.argv[1] == "build":
     os.makedirs(OUT, exist_ok=True)
     for v in VARIANTS:
@@ -16,17 +16,18 @@ if sys.argv[1] == "build":
 else:
     import torch
     B = 1024
+    G = int(sys.argv[2]) if len(sys.argv) > 2 else 64
     x = torch.rand(B, 14, 14, 32, device="cuda").bfloat16()
-    wT = torch.randn(25, 64, 32, device="cuda").bfloat16()
-    bias = torch.zeros(64, device="cuda")
-    pooled = torch.empty(B, 7, 7, 64, device="cuda", dtype=torch.bfloat16)
-    arg = torch.empty(B, 7, 7, 64, device="cuda", dtype=torch.uint8)
+    gp = torch.randn(B, 7, 7, 64, device="cuda").bfloat16()
+    pooled = torch.rand(B, 7, 7, 64, device="cuda").bfloat16()
+    arg = torch.randint(0, 4, (B, 7, 7, 64), device="cuda", dtype=torch.uint8)
+    part = torch.empty(G, 25 * 32 * 64 + 64, device="cuda")
     s = torch.cuda.current_stream().cuda_stream
     for v, name in VARIANTS.items():
         lib = ctypes.CDLL(f"{OUT}/conv2_ab{v}.so")
-        f = lib.dtf_conv2_fwd
-        f.argtypes = [ctypes.c_void_p] * 5 + [ctypes.c_int] * 3 + [ctypes.c_void_p]
-        call = lambda: f(x.data_ptr(), wT.data_ptr(), bias.data_ptr(), pooled.data_ptr(), arg.data_ptr(), B, 32, 64, s)
+        f = lib.dtf_conv2_wgrad
+        f.argtypes = [ctypes.c_void_p] * 5 + [ctypes.c_int] * 4 + [ctypes.c_void_p]
+        call = lambda: f(x.data_ptr(), gp.data_ptr(), arg.data_ptr(), pooled.data_ptr(), part.data_ptr(), B, 32, 64, G, s)
         for _ in range(5): call()
         torch.cuda.synchronize(); t0 = time.perf_counter()
         for _ in range(50): call()
