@@ -40,7 +40,7 @@ __global__ __launch_bounds__(256) void conv1_pool_fwd(const bf16* __restrict__ i
   __shared__ __attribute__((aligned(16))) bf16 img[32 * kC1Pitch];          // 6 KB, zero halo
   __shared__ __attribute__((aligned(16))) bf16 orow[4][16 * 32];            // per wave: pooled row [px][32 ch]
   __shared__ __attribute__((aligned(16))) uint8_t arow[4][16 * 32];
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int g = lane >> 4, i16 = lane & 15;
   const int cchunk = blockIdx.y;   // 32-channel chunk
 
@@ -164,7 +164,7 @@ __global__ __launch_bounds__(256) void conv1_wgrad(const bf16* __restrict__ imag
   bf16* cp = reinterpret_cast<bf16*>(smem);
   bf16* dyt = reinterpret_cast<bf16*>(smem + kCpBytes);
 
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int g = lane >> 4, i16 = lane & 15, qr = i16 >> 2, pc = i16 & 3;
   const int cchunk = blockIdx.y;
 

@@ -72,7 +72,7 @@ __global__ __launch_bounds__(IMGS * 2 * NW * 64, MINW) void conv5x5_igemm(
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
-  const int wave = tid >> 6;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int w_img = wave / (2 * NW);
   const int w_h = (wave / NW) & 1;
   const int w_n = wave % NW;
@@ -261,10 +261,12 @@ __global__ __launch_bounds__(512, 2) void conv5x5_wgrad(
   typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
   typedef __attribute__((ext_vector_type(8))) short s16x8;
   __shared__ __attribute__((aligned(16))) char smem[kWgRedBytes];
-  bf16* xt = reinterpret_cast<bf16*>(smem);                   // [328][16]
-  bf16* dyt = reinterpret_cast<bf16*>(smem + kWgXTileBytes);  // [7][32][32], 32-B halves swizzled
+  // two image buffers, each: xt [328][16] | dyt [7][32][32] (32-B halves swizzled)
+  constexpr int kBufElems = (kWgXTileBytes + kWgDyTileBytes) / 2;
+  bf16* xt = reinterpret_cast<bf16*>(smem);
+  bf16* dyt = reinterpret_cast<bf16*>(smem + kWgXTileBytes);
 
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int tw = wave & 3, kh = wave >> 2;
   const int ci_t = blockIdx.y % CI_T, co_t = blockIdx.y / CI_T;
   const int g = lane >> 4, i16 = lane & 15;
@@ -282,7 +284,7 @@ __global__ __launch_bounds__(512, 2) void conv5x5_wgrad(
   float bsum[2] = {0.f, 0.f};
 
   // zero once: halo, slack and the x = 14,15 dummy columns stay zero
-  for (int i = tid; i < (kWgXTileBytes + kWgDyTileBytes) / 16; i += 512)
+  for (int i = tid; i < 2 * (kWgXTileBytes + kWgDyTileBytes) / 16; i += 512)
     reinterpret_cast<u32x4*>(smem)[i] = (u32x4){0u, 0u, 0u, 0u};
 
   const int tr_pos = (g >> 1) * kTileW + 4 * (g & 1) + qr;   // A: row pair 0, tap (0,0), first read
@@ -317,8 +319,8 @@ __global__ __launch_bounds__(512, 2) void conv5x5_wgrad(
       ar_r = *reinterpret_cast<const u32x2*>(arg + off);
     }
   };
-  auto stage = [&]() {
-    if (has_x && !(DTF_ABLATE & 32)) *reinterpret_cast<u32x4*>(xt + x_tp * 16 + x_ch * 8) = xr;
+  auto stage = [&](int boff) {
+    if (has_x && !(DTF_ABLATE & 32)) *reinterpret_cast<u32x4*>(xt + boff + x_tp * 16 + x_ch * 8) = xr;
     if (has_dy && !(DTF_ABLATE & 128)) {
       const int r = d_pp / 7, w = d_pp % 7;
       bf16x8 o[4];
@@ -333,52 +335,85 @@ __global__ __launch_bounds__(512, 2) void conv5x5_wgrad(
       for (int q = 0; q < 4; ++q) {
         int kk = (q >> 1) * 16 + 2 * w + (q & 1);
         int slot = (((d_c8 >> 1) ^ ((kk >> 2) & 1)) << 1) | (d_c8 & 1);
-        *reinterpret_cast<bf16x8*>(dyt + (r * 32 + kk) * 32 + slot * 8) = o[q];
+        *reinterpret_cast<bf16x8*>(dyt + boff + (r * 32 + kk) * 32 + slot * 8) = o[q];
       }
     }
   };
 
   if (b_begin < b_end) prefetch(b_begin);
+  __syncthreads();  // zero fill done
+  if (b_begin < b_end) stage(0);
+  if (b_begin + 1 < b_end) prefetch(b_begin + 1);
   for (int b = b_begin; b < b_end; ++b) {
-    __syncthreads();  // previous image fully consumed (and the zero fill done)
-    stage();
+    const int boff = ((b - b_begin) & 1) * kBufElems;
+    // image b is staged in buffer boff; every wave is done reading the other buffer (image b-1),
+    // which this iteration refills with image b+1 after its own k-loop
     __syncthreads();
-    if (b + 1 < b_end) prefetch(b + 1);
-#pragma unroll 1
-    for (int r = (kh + b) & 1; r < ((DTF_ABLATE & 256) ? 0 : 7); r += 2) {
-      bf16x8 bfrag[2];
+    // k-loop over this wave's row pairs, software-pipelined: the 18 transposed reads of step r+2
+    // are in flight while the 14 MFMAs of step r issue (two fragment sets, loop unrolled by two)
+    const bf16* a_img = a_lane + boff;
+    const bf16* b_img = dyt + boff + kkrow * 32 + pc * 4;
+    auto load_frags = [&](int r, bf16x8 (&af)[7], bf16x8 (&bf)[2]) {
 #pragma unroll
       for (int j = 0; j < 2; ++j) {
-        const bf16* p0 = dyt + (r * 32 + kkrow) * 32 + ((j ^ bsw) << 4) + pc * 4;
+        const bf16* p0 = b_img + r * 32 * 32 + ((j ^ bsw) << 4);
         s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)p0);
         s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(p0 + 8 * 32));
         s16x8 v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
-        bfrag[j] = __builtin_bit_cast(bf16x8, v);
+        bf[j] = __builtin_bit_cast(bf16x8, v);
       }
+#pragma unroll
+      for (int t = 0; t < 7; ++t) {
+        const bf16* p0 = a_img + 2 * r * kTileW * 16 + tap_off[t];
+        s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)p0);
+        s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(p0 + 8 * 16));
+        s16x8 av = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+        af[t] = __builtin_bit_cast(bf16x8, av);
+      }
+    };
+    auto mma_frags = [&](const bf16x8 (&af)[7], const bf16x8 (&bf)[2]) {
       if (do_bias) {
 #pragma unroll
         for (int j = 0; j < 2; ++j)
 #pragma unroll
-          for (int e = 0; e < 8; ++e) bsum[j] += (float)bfrag[j][e];
-      }
-      bf16x8 afrag[7];
-#pragma unroll
-      for (int t = 0; t < 7; ++t) {
-        const bf16* p0 = a_lane + 2 * r * kTileW * 16 + tap_off[t];
-        s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)p0);
-        s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(p0 + 8 * 16));
-        s16x8 av = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
-        afrag[t] = __builtin_bit_cast(bf16x8, av);
+          for (int e = 0; e < 8; ++e) bsum[j] += (float)bf[j][e];
       }
 #pragma unroll
       for (int t = 0; t < 7; ++t) {
         if (DTF_ABLATE & 64) {
-          asm volatile("" ::"v"(afrag[t]), "v"(bfrag[0]), "v"(bfrag[1]));
+          asm volatile("" ::"v"(af[t]), "v"(bf[0]), "v"(bf[1]));
         } else {
-          acc[t][0] = mfma16(afrag[t], bfrag[0], acc[t][0]);
-          acc[t][1] = mfma16(afrag[t], bfrag[1], acc[t][1]);
+          acc[t][0] = mfma16(af[t], bf[0], acc[t][0]);
+          acc[t][1] = mfma16(af[t], bf[1], acc[t][1]);
         }
       }
+    };
+    if (!(DTF_ABLATE & 256)) {
+      // 4 (r = 0,2,4,6) or 3 (r = 1,3,5) steps, straight-line so every wait count is exact
+      bf16x8 af0[7], bf0[2], af1[7], bf1[2];
+      const int r = (kh + b) & 1;
+      load_frags(r, af0, bf0);
+      load_frags(r + 2, af1, bf1);
+      __builtin_amdgcn_sched_barrier(0);
+      mma_frags(af0, bf0);
+      __builtin_amdgcn_sched_barrier(0);
+      load_frags(r + 4, af0, bf0);
+      __builtin_amdgcn_sched_barrier(0);
+      mma_frags(af1, bf1);
+      __builtin_amdgcn_sched_barrier(0);
+      if (r == 0) {
+        load_frags(6, af1, bf1);
+        __builtin_amdgcn_sched_barrier(0);
+        mma_frags(af0, bf0);
+        __builtin_amdgcn_sched_barrier(0);
+        mma_frags(af1, bf1);
+      } else {
+        mma_frags(af0, bf0);
+      }
+    }
+    if (b + 1 < b_end) {
+      stage(kBufElems - boff);
+      if (b + 2 < b_end) prefetch(b + 2);
     }
   }
 

@@ -57,20 +57,66 @@ __device__ __forceinline__ void xcd_tile(int gx, int gy, int& tx, int& ty) {
   ty = band * BH + rem % h;
 }
 
-template <int BM, int BN, int EPI>
-__global__ __launch_bounds__(256) void gemm_nt_bf16(const bf16* __restrict__ A, const bf16* __restrict__ Bm,
-                                                    bf16* __restrict__ C, const float* __restrict__ bias,
-                                                    int M, int N, int K, int lda, int ldb, int ldc,
-                                                    DropoutArgs drop) {
-  constexpr int BK = 64;
-  constexpr int WM = BM / 2, WN = BN / 2;
+// ---------------------------------------------------------------------------------------------
+// Shared software pipeline.  One K tile (BK = 64) per phase, double-buffered LDS, two register
+// sets: the global loads of tile t+2 are issued at the head of phase t and written to LDS at the
+// end of phase t+1, so they have two compute phases to land.
+//
+// What makes this work on the compiler we have (each point measured, see docs/ARCHITECTURE.md):
+//  * loads are raw buffer loads (V# + per-thread byte offset computed once + scalar K offset):
+//    unconditional, branch-free, and out-of-range rows read as zero.  A guarded `cond ? *p : 0`
+//    load becomes a branch, the waitcnt pass then cannot count, and every wait in the loop
+//    degrades to vmcnt(0) -- the full memory latency exposed in every phase;
+//  * buffer loads are not sunk to their use the way loads through const __restrict__ pointers
+//    are, and the sched_barrier after each issue keeps them at the head of the phase;
+//  * no per-load address VGPRs, so no write-after-write waits against loads still in flight.
+// 128x128 tiles run 8 waves (2 per SIMD): while one wave waits on LDS or at the barrier the other
+// issues MFMAs.  A 4-wave tile measured ~1350 cycles per phase for 512 cycles of MFMA.
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void* p, size_t bytes) {
+  const uint32_t n = bytes > 0xfffffff0ull ? 0xfffffff0u : (uint32_t)bytes;
+  return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), 0, (int)n, 0x00020000);
+}
+__device__ __forceinline__ u32x4 buf_load16(__amdgpu_buffer_rsrc_t r, uint32_t voff, uint32_t soff) {
+  return __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(r, (int)voff, (int)soff, 0));
+}
+
+template <int A_CH, int B_CH, class GL, class SW, class CP>
+__device__ __forceinline__ void gemm_pipeline(int T, GL&& gload, SW&& swrite, CP&& compute) {
+  u32x4 ra0[A_CH], rb0[B_CH], ra1[A_CH], rb1[B_CH];
+  gload(ra0, rb0, 0);
+  gload(ra1, rb1, 1);
+  swrite(ra0, rb0, 0);
+  __syncthreads();
+  for (int t = 0; t < T; t += 2) {
+    gload(ra0, rb0, t + 2);  // past the end: in-range garbage or zeros, written to LDS but never multiplied
+    __builtin_amdgcn_sched_barrier(0);
+    compute(0);
+    swrite(ra1, rb1, 1);
+    __syncthreads();
+    if (t + 1 >= T) break;
+    gload(ra1, rb1, t + 3);
+    __builtin_amdgcn_sched_barrier(0);
+    compute(1);
+    swrite(ra0, rb0, 0);
+    __syncthreads();
+  }
+}
+
+template <int BM, int BN, int NW, int EPI>
+__global__ __launch_bounds__(NW * 64) void gemm_nt_bf16(const bf16* A, const bf16* Bm, bf16* __restrict__ C,
+                                                        const float* __restrict__ bias, int M, int N, int K,
+                                                        int lda, int ldb, int ldc, DropoutArgs drop) {
+  constexpr int BK = 64, NT = NW * 64;
+  constexpr int WAVES_N = NW / 2;
+  constexpr int WM = BM / 2, WN = BN / WAVES_N;
   constexpr int MT = WM / 16, NTL = WN / 16;
-  constexpr int A_CH = BM * 8 / 256, B_CH = BN * 8 / 256;  // 16-byte chunks per thread
+  constexpr int A_CH = BM * 8 / NT, B_CH = BN * 8 / NT;  // 16-byte chunks per thread
   __shared__ __attribute__((aligned(16))) bf16 sA[2][BM * BK];
   __shared__ __attribute__((aligned(16))) bf16 sB[2][BN * BK];
 
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int wm = wave >> 1, wn = wave & 1;
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave / WAVES_N, wn = wave % WAVES_N;
   int tile_x, tile_y;
   xcd_tile(gridDim.x, gridDim.y, tile_x, tile_y);
   const int m0 = tile_y * BM, n0 = tile_x * BN;
@@ -82,75 +128,61 @@ __global__ __launch_bounds__(256) void gemm_nt_bf16(const bf16* __restrict__ A, 
 #pragma unroll
     for (int j = 0; j < NTL; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-  // Software pipeline: two register sets + two LDS buffers.  The global loads of tile t+2 are
-  // issued before the MFMAs of tile t and only written to LDS a full phase later, so their
-  // latency hides under two compute phases; one barrier per K tile.
-  u32x4 ra0[A_CH], rb0[B_CH], ra1[A_CH], rb1[B_CH];
-  auto gload = [&](u32x4 (&ra)[A_CH], u32x4 (&rb)[B_CH], int k0) {
+  const __amdgpu_buffer_rsrc_t rA = make_rsrc(A, (size_t)M * lda * 2), rB = make_rsrc(Bm, (size_t)N * ldb * 2);
+  uint32_t va[A_CH], vb[B_CH];
 #pragma unroll
-    for (int i = 0; i < A_CH; ++i) {
-      int c = tid + i * 256, row = c >> 3, slot = c & 7;
-      int gm = m0 + row, gk = k0 + slot * 8;
-      ra[i] = (gm < M && gk < K) ? *reinterpret_cast<const u32x4*>(A + (size_t)gm * lda + gk)
-                                 : (u32x4){0u, 0u, 0u, 0u};
-    }
+  for (int i = 0; i < A_CH; ++i) {
+    int c = tid + i * NT, row = c >> 3, slot = c & 7;
+    va[i] = (uint32_t)(m0 + row) * (uint32_t)(lda * 2) + slot * 16;
+  }
 #pragma unroll
-    for (int i = 0; i < B_CH; ++i) {
-      int c = tid + i * 256, row = c >> 3, slot = c & 7;
-      int gn = n0 + row, gk = k0 + slot * 8;
-      rb[i] = (gn < N && gk < K) ? *reinterpret_cast<const u32x4*>(Bm + (size_t)gn * ldb + gk)
-                                 : (u32x4){0u, 0u, 0u, 0u};
-    }
+  for (int i = 0; i < B_CH; ++i) {
+    int c = tid + i * NT, row = c >> 3, slot = c & 7;
+    vb[i] = (uint32_t)(n0 + row) * (uint32_t)(ldb * 2) + slot * 16;
+  }
+  auto gload = [&](u32x4 (&ra)[A_CH], u32x4 (&rb)[B_CH], int t) {
+    const uint32_t so = (uint32_t)t * (BK * 2);
+#pragma unroll
+    for (int i = 0; i < A_CH; ++i) ra[i] = buf_load16(rA, va[i], so);
+#pragma unroll
+    for (int i = 0; i < B_CH; ++i) rb[i] = buf_load16(rB, vb[i], so);
   };
   auto swrite = [&](const u32x4 (&ra)[A_CH], const u32x4 (&rb)[B_CH], int buf) {
 #pragma unroll
     for (int i = 0; i < A_CH; ++i) {
-      int c = tid + i * 256, row = c >> 3, slot = c & 7;
+      int c = tid + i * NT, row = c >> 3, slot = c & 7;
       *reinterpret_cast<u32x4*>(sA[buf] + row * BK + ((slot ^ (row & 7)) << 3)) = ra[i];
     }
 #pragma unroll
     for (int i = 0; i < B_CH; ++i) {
-      int c = tid + i * 256, row = c >> 3, slot = c & 7;
+      int c = tid + i * NT, row = c >> 3, slot = c & 7;
       *reinterpret_cast<u32x4*>(sB[buf] + row * BK + ((slot ^ (row & 7)) << 3)) = rb[i];
     }
   };
   auto compute = [&](int buf) {
+    bf16x8 af[2][MT], bfv[2][NTL];
 #pragma unroll
     for (int kk = 0; kk < 2; ++kk) {
-      bf16x8 af[MT], bfv[NTL];
 #pragma unroll
       for (int i = 0; i < MT; ++i) {
         int row = wm * WM + i * 16 + i16;
-        af[i] = *reinterpret_cast<const bf16x8*>(sA[buf] + row * BK + (((kk * 4 + g) ^ (row & 7)) << 3));
+        af[kk][i] = *reinterpret_cast<const bf16x8*>(sA[buf] + row * BK + (((kk * 4 + g) ^ (row & 7)) << 3));
       }
 #pragma unroll
       for (int j = 0; j < NTL; ++j) {
         int row = wn * WN + j * 16 + i16;
-        bfv[j] = *reinterpret_cast<const bf16x8*>(sB[buf] + row * BK + (((kk * 4 + g) ^ (row & 7)) << 3));
+        bfv[kk][j] = *reinterpret_cast<const bf16x8*>(sB[buf] + row * BK + (((kk * 4 + g) ^ (row & 7)) << 3));
       }
+    }
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk)
 #pragma unroll
       for (int i = 0; i < MT; ++i)
 #pragma unroll
-        for (int j = 0; j < NTL; ++j) acc[i][j] = mfma16(af[i], bfv[j], acc[i][j]);
-    }
+        for (int j = 0; j < NTL; ++j) acc[i][j] = mfma16(af[kk][i], bfv[kk][j], acc[i][j]);
   };
 
-  const int T = (K + BK - 1) / BK;
-  gload(ra0, rb0, 0);
-  if (T > 1) gload(ra1, rb1, BK);
-  swrite(ra0, rb0, 0);
-  __syncthreads();
-  for (int t = 0; t < T; t += 2) {
-    if (t + 2 < T) gload(ra0, rb0, (t + 2) * BK);
-    compute(0);
-    if (t + 1 < T) swrite(ra1, rb1, 1);
-    __syncthreads();
-    if (t + 1 >= T) break;
-    if (t + 3 < T) gload(ra1, rb1, (t + 3) * BK);
-    compute(1);
-    if (t + 2 < T) swrite(ra0, rb0, 0);
-    __syncthreads();
-  }
+  gemm_pipeline<A_CH, B_CH>(K / BK, gload, swrite, compute);
 
   uint64_t drop_off = 0;
   const bool do_drop = (EPI == EPI_BIAS_RELU_DROPOUT) && drop.keep_prob < 1.0f;
@@ -179,20 +211,20 @@ __global__ __launch_bounds__(256) void gemm_nt_bf16(const bf16* __restrict__ A, 
 }
 
 // C[M,N] (fp32) = sum_k A[k][m] * B[k][n];  A: [K][lda], B: [K][ldb]
-template <int BM, int BN>
-__global__ __launch_bounds__(256) void gemm_tn_bf16(const bf16* __restrict__ A, const bf16* __restrict__ Bm,
-                                                    float* __restrict__ C, int M, int N, int K, int lda,
-                                                    int ldb, int ldc) {
-  constexpr int BK = 64;
+template <int BM, int BN, int NW>
+__global__ __launch_bounds__(NW * 64) void gemm_tn_bf16(const bf16* A, const bf16* Bm, float* __restrict__ C,
+                                                        int M, int N, int K, int lda, int ldb, int ldc) {
+  constexpr int BK = 64, NT = NW * 64;
   constexpr int PA = BM + 16, PB = BN + 16;  // row pitch in elements (+32 B)
-  constexpr int WM = BM / 2, WN = BN / 2;
+  constexpr int WAVES_N = NW / 2;
+  constexpr int WM = BM / 2, WN = BN / WAVES_N;
   constexpr int MT = WM / 16, NTL = WN / 16;
-  constexpr int A_CH = BK * (BM / 8) / 256, B_CH = BK * (BN / 8) / 256;
+  constexpr int A_CH = BK * (BM / 8) / NT, B_CH = BK * (BN / 8) / NT;
   __shared__ __attribute__((aligned(16))) bf16 sA[2][BK * PA];
   __shared__ __attribute__((aligned(16))) bf16 sB[2][BK * PB];
 
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int wm = wave >> 1, wn = wave & 1;
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave / WAVES_N, wn = wave % WAVES_N;
   int tile_x, tile_y;
   xcd_tile(gridDim.x, gridDim.y, tile_x, tile_y);
   const int m0 = tile_y * BM, n0 = tile_x * BN;
@@ -205,32 +237,36 @@ __global__ __launch_bounds__(256) void gemm_tn_bf16(const bf16* __restrict__ A, 
 #pragma unroll
     for (int j = 0; j < NTL; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-  u32x4 ra0[A_CH], rb0[B_CH], ra1[A_CH], rb1[B_CH];
-  auto gload = [&](u32x4 (&ra)[A_CH], u32x4 (&rb)[B_CH], int k0) {
+  // rows past K read as zero (beyond the descriptor); columns past M/N wrap into the next row and
+  // only feed output rows/columns that are never stored
+  const __amdgpu_buffer_rsrc_t rA = make_rsrc(A, (size_t)K * lda * 2), rB = make_rsrc(Bm, (size_t)K * ldb * 2);
+  uint32_t va[A_CH], vb[B_CH];
 #pragma unroll
-    for (int i = 0; i < A_CH; ++i) {
-      int c = tid + i * 256, row = c / (BM / 8), slot = c % (BM / 8);
-      int gk = k0 + row, gm = m0 + slot * 8;
-      ra[i] = (gk < K && gm < M) ? *reinterpret_cast<const u32x4*>(A + (size_t)gk * lda + gm)
-                                 : (u32x4){0u, 0u, 0u, 0u};
-    }
+  for (int i = 0; i < A_CH; ++i) {
+    int c = tid + i * NT, row = c / (BM / 8), slot = c % (BM / 8);
+    va[i] = (uint32_t)row * (uint32_t)(lda * 2) + (uint32_t)(m0 + slot * 8) * 2;
+  }
 #pragma unroll
-    for (int i = 0; i < B_CH; ++i) {
-      int c = tid + i * 256, row = c / (BN / 8), slot = c % (BN / 8);
-      int gk = k0 + row, gn = n0 + slot * 8;
-      rb[i] = (gk < K && gn < N) ? *reinterpret_cast<const u32x4*>(Bm + (size_t)gk * ldb + gn)
-                                 : (u32x4){0u, 0u, 0u, 0u};
-    }
+  for (int i = 0; i < B_CH; ++i) {
+    int c = tid + i * NT, row = c / (BN / 8), slot = c % (BN / 8);
+    vb[i] = (uint32_t)row * (uint32_t)(ldb * 2) + (uint32_t)(n0 + slot * 8) * 2;
+  }
+  const uint32_t stepA = (uint32_t)lda * (BK * 2), stepB = (uint32_t)ldb * (BK * 2);
+  auto gload = [&](u32x4 (&ra)[A_CH], u32x4 (&rb)[B_CH], int t) {
+#pragma unroll
+    for (int i = 0; i < A_CH; ++i) ra[i] = buf_load16(rA, va[i], (uint32_t)t * stepA);
+#pragma unroll
+    for (int i = 0; i < B_CH; ++i) rb[i] = buf_load16(rB, vb[i], (uint32_t)t * stepB);
   };
   auto swrite = [&](const u32x4 (&ra)[A_CH], const u32x4 (&rb)[B_CH], int buf) {
 #pragma unroll
     for (int i = 0; i < A_CH; ++i) {
-      int c = tid + i * 256, row = c / (BM / 8), slot = c % (BM / 8);
+      int c = tid + i * NT, row = c / (BM / 8), slot = c % (BM / 8);
       *reinterpret_cast<u32x4*>(sA[buf] + row * PA + slot * 8) = ra[i];
     }
 #pragma unroll
     for (int i = 0; i < B_CH; ++i) {
-      int c = tid + i * 256, row = c / (BN / 8), slot = c % (BN / 8);
+      int c = tid + i * NT, row = c / (BN / 8), slot = c % (BN / 8);
       *reinterpret_cast<u32x4*>(sB[buf] + row * PB + slot * 8) = rb[i];
     }
   };
@@ -245,36 +281,24 @@ __global__ __launch_bounds__(256) void gemm_tn_bf16(const bf16* __restrict__ A, 
     return __builtin_bit_cast(bf16x8, v);
   };
   auto compute = [&](int buf) {
+    bf16x8 af[2][MT], bfv[2][NTL];
 #pragma unroll
     for (int kk = 0; kk < 2; ++kk) {
-      bf16x8 af[MT], bfv[NTL];
 #pragma unroll
-      for (int i = 0; i < MT; ++i) af[i] = tr_frag(sA[buf], PA, kk, wm * WM + i * 16);
+      for (int i = 0; i < MT; ++i) af[kk][i] = tr_frag(sA[buf], PA, kk, wm * WM + i * 16);
 #pragma unroll
-      for (int j = 0; j < NTL; ++j) bfv[j] = tr_frag(sB[buf], PB, kk, wn * WN + j * 16);
+      for (int j = 0; j < NTL; ++j) bfv[kk][j] = tr_frag(sB[buf], PB, kk, wn * WN + j * 16);
+    }
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk)
 #pragma unroll
       for (int i = 0; i < MT; ++i)
 #pragma unroll
-        for (int j = 0; j < NTL; ++j) acc[i][j] = mfma16(af[i], bfv[j], acc[i][j]);
-    }
+        for (int j = 0; j < NTL; ++j) acc[i][j] = mfma16(af[kk][i], bfv[kk][j], acc[i][j]);
   };
 
-  const int T = (K + BK - 1) / BK;
-  gload(ra0, rb0, 0);
-  if (T > 1) gload(ra1, rb1, BK);
-  swrite(ra0, rb0, 0);
-  __syncthreads();
-  for (int t = 0; t < T; t += 2) {
-    if (t + 2 < T) gload(ra0, rb0, (t + 2) * BK);
-    compute(0);
-    if (t + 1 < T) swrite(ra1, rb1, 1);
-    __syncthreads();
-    if (t + 1 >= T) break;
-    if (t + 3 < T) gload(ra1, rb1, (t + 3) * BK);
-    compute(1);
-    if (t + 2 < T) swrite(ra0, rb0, 0);
-    __syncthreads();
-  }
+  gemm_pipeline<A_CH, B_CH>((K + BK - 1) / BK, gload, swrite, compute);
+
 #pragma unroll
   for (int j = 0; j < NTL; ++j) {
     const int n = n0 + wn * WN + j * 16 + i16;
@@ -296,21 +320,22 @@ __global__ __launch_bounds__(256) void gemm_tn_bf16(const bf16* __restrict__ A, 
 // gemm_nt.  B fragments: ds_read_b64_tr_b16 with rows 8g+q / 8g+4+q so that element j of lane
 // group g is k = 8g + j on BOTH operands; the two 128-byte halves of every row with bit 3 set are
 // swapped, which makes these transposed reads bank-conflict free (rows r and r+8 would collide).
-template <int BM, int BN>
-__global__ __launch_bounds__(256) void gemm_nn_splitk_bf16(const bf16* __restrict__ A, const bf16* __restrict__ Bm,
-                                                           float* __restrict__ Cp, int M, int N, int K, int lda,
-                                                           int ldb, int tiles_per_split) {
+template <int BM, int BN, int NW>
+__global__ __launch_bounds__(NW * 64) void gemm_nn_splitk_bf16(const bf16* A, const bf16* Bm,
+                                                               float* __restrict__ Cp, int M, int N, int K,
+                                                               int lda, int ldb, int tiles_per_split) {
   static_assert(BN == 128, "the half-swap swizzle below assumes 256-byte B rows");
-  constexpr int BK = 64;
+  constexpr int BK = 64, NT = NW * 64;
   constexpr int PB = BN + 16;
-  constexpr int WM = BM / 2, WN = BN / 2;
+  constexpr int WAVES_N = NW / 2;
+  constexpr int WM = BM / 2, WN = BN / WAVES_N;
   constexpr int MT = WM / 16, NTL = WN / 16;
-  constexpr int A_CH = BM * 8 / 256, B_CH = BK * (BN / 8) / 256;
+  constexpr int A_CH = BM * 8 / NT, B_CH = BK * (BN / 8) / NT;
   __shared__ __attribute__((aligned(16))) bf16 sA[2][BM * BK];
   __shared__ __attribute__((aligned(16))) bf16 sB[2][BK * PB];
 
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int wm = wave >> 1, wn = wave & 1;
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave / WAVES_N, wn = wave % WAVES_N;
   int tile_x, tile_y;
   xcd_tile(gridDim.x, gridDim.y, tile_x, tile_y);
   const int m0 = tile_y * BM, n0 = tile_x * BN;
@@ -319,7 +344,6 @@ __global__ __launch_bounds__(256) void gemm_nn_splitk_bf16(const bf16* __restric
   const int T_all = (K + BK - 1) / BK;
   const int t_begin = blockIdx.z * tiles_per_split;
   const int T = min(T_all, t_begin + tiles_per_split) - t_begin;
-  const int kbase = t_begin * BK;
 
   f32x4 acc[MT][NTL];
 #pragma unroll
@@ -327,32 +351,35 @@ __global__ __launch_bounds__(256) void gemm_nn_splitk_bf16(const bf16* __restric
 #pragma unroll
     for (int j = 0; j < NTL; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-  u32x4 ra0[A_CH], rb0[B_CH], ra1[A_CH], rb1[B_CH];
-  auto gload = [&](u32x4 (&ra)[A_CH], u32x4 (&rb)[B_CH], int k0) {
+  // A columns past K wrap into the next row, but meet B rows past K, which read as zero
+  const __amdgpu_buffer_rsrc_t rA = make_rsrc(A, (size_t)M * lda * 2), rB = make_rsrc(Bm, (size_t)K * ldb * 2);
+  uint32_t va[A_CH], vb[B_CH];
 #pragma unroll
-    for (int i = 0; i < A_CH; ++i) {
-      int c = tid + i * 256, row = c >> 3, slot = c & 7;
-      int gm = m0 + row, gk = k0 + slot * 8;
-      ra[i] = (gm < M && gk < K) ? *reinterpret_cast<const u32x4*>(A + (size_t)gm * lda + gk)
-                                 : (u32x4){0u, 0u, 0u, 0u};
-    }
+  for (int i = 0; i < A_CH; ++i) {
+    int c = tid + i * NT, row = c >> 3, slot = c & 7;
+    va[i] = (uint32_t)(m0 + row) * (uint32_t)(lda * 2) + slot * 16 + (uint32_t)t_begin * (BK * 2);
+  }
 #pragma unroll
-    for (int i = 0; i < B_CH; ++i) {
-      int c = tid + i * 256, row = c / (BN / 8), slot = c % (BN / 8);
-      int gk = k0 + row, gn = n0 + slot * 8;
-      rb[i] = (gk < K && gn < N) ? *reinterpret_cast<const u32x4*>(Bm + (size_t)gk * ldb + gn)
-                                 : (u32x4){0u, 0u, 0u, 0u};
-    }
+  for (int i = 0; i < B_CH; ++i) {
+    int c = tid + i * NT, row = c / (BN / 8), slot = c % (BN / 8);
+    vb[i] = (uint32_t)(t_begin * BK + row) * (uint32_t)(ldb * 2) + (uint32_t)(n0 + slot * 8) * 2;
+  }
+  const uint32_t stepB = (uint32_t)ldb * (BK * 2);
+  auto gload = [&](u32x4 (&ra)[A_CH], u32x4 (&rb)[B_CH], int t) {
+#pragma unroll
+    for (int i = 0; i < A_CH; ++i) ra[i] = buf_load16(rA, va[i], (uint32_t)t * (BK * 2));
+#pragma unroll
+    for (int i = 0; i < B_CH; ++i) rb[i] = buf_load16(rB, vb[i], (uint32_t)t * stepB);
   };
   auto swrite = [&](const u32x4 (&ra)[A_CH], const u32x4 (&rb)[B_CH], int buf) {
 #pragma unroll
     for (int i = 0; i < A_CH; ++i) {
-      int c = tid + i * 256, row = c >> 3, slot = c & 7;
+      int c = tid + i * NT, row = c >> 3, slot = c & 7;
       *reinterpret_cast<u32x4*>(sA[buf] + row * BK + ((slot ^ (row & 7)) << 3)) = ra[i];
     }
 #pragma unroll
     for (int i = 0; i < B_CH; ++i) {
-      int c = tid + i * 256, row = c / (BN / 8), slot = c % (BN / 8);
+      int c = tid + i * NT, row = c / (BN / 8), slot = c % (BN / 8);
       int col = (slot * 8) ^ (((row >> 3) & 1) << 6);   // swap the 64-element halves on rows with bit 3
       *reinterpret_cast<u32x4*>(sB[buf] + row * PB + col) = rb[i];
     }
@@ -360,13 +387,13 @@ __global__ __launch_bounds__(256) void gemm_nn_splitk_bf16(const bf16* __restric
   typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
   typedef __attribute__((ext_vector_type(8))) short s16x8;
   auto compute = [&](int buf) {
+    bf16x8 af[2][MT], bfv[2][NTL];
 #pragma unroll
     for (int kk = 0; kk < 2; ++kk) {
-      bf16x8 af[MT], bfv[NTL];
 #pragma unroll
       for (int i = 0; i < MT; ++i) {
         int row = wm * WM + i * 16 + i16;
-        af[i] = *reinterpret_cast<const bf16x8*>(sA[buf] + row * BK + (((kk * 4 + g) ^ (row & 7)) << 3));
+        af[kk][i] = *reinterpret_cast<const bf16x8*>(sA[buf] + row * BK + (((kk * 4 + g) ^ (row & 7)) << 3));
       }
 #pragma unroll
       for (int j = 0; j < NTL; ++j) {
@@ -377,32 +404,19 @@ __global__ __launch_bounds__(256) void gemm_nn_splitk_bf16(const bf16* __restric
         s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)p0);
         s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(p0 + 4 * PB));
         s16x8 v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
-        bfv[j] = __builtin_bit_cast(bf16x8, v);
+        bfv[kk][j] = __builtin_bit_cast(bf16x8, v);
       }
+    }
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk)
 #pragma unroll
       for (int i = 0; i < MT; ++i)
 #pragma unroll
-        for (int j = 0; j < NTL; ++j) acc[i][j] = mfma16(af[i], bfv[j], acc[i][j]);
-    }
+        for (int j = 0; j < NTL; ++j) acc[i][j] = mfma16(af[kk][i], bfv[kk][j], acc[i][j]);
   };
 
-  if (T > 0) {
-    gload(ra0, rb0, kbase);
-    if (T > 1) gload(ra1, rb1, kbase + BK);
-    swrite(ra0, rb0, 0);
-    __syncthreads();
-    for (int t = 0; t < T; t += 2) {
-      if (t + 2 < T) gload(ra0, rb0, kbase + (t + 2) * BK);
-      compute(0);
-      if (t + 1 < T) swrite(ra1, rb1, 1);
-      __syncthreads();
-      if (t + 1 >= T) break;
-      if (t + 3 < T) gload(ra1, rb1, kbase + (t + 3) * BK);
-      compute(1);
-      if (t + 2 < T) swrite(ra0, rb0, 0);
-      __syncthreads();
-    }
-  }
+  if (T > 0) gemm_pipeline<A_CH, B_CH>(T, gload, swrite, compute);
+
   float* C = Cp + (size_t)blockIdx.z * M * N;
 #pragma unroll
   for (int j = 0; j < NTL; ++j) {
@@ -471,13 +485,13 @@ extern "C" {
 int dtf_gemm_nt(const void* A, const void* B, void* C, const void* bias, int M, int N, int K, int lda,
                 int ldb, int ldc, int epi, float keep_prob, uint64_t seed, const void* state, int tile,
                 hipStream_t s) {
-  if ((K & 7) || (lda & 7) || (ldb & 7)) return -3;
+  if ((K & 63) || (lda & 7) || (ldb & 7)) return -3;  // the unguarded loader needs whole K tiles
   DropoutArgs d{keep_prob, seed, (const int64_t*)state};
   if (tile == 0) tile = ((long)((M + 127) / 128) * ((N + 127) / 128) >= 192) ? 128 : 64;
 #define NT_CASE(BMN, E)                                                                               \
-  hipLaunchKernelGGL((gemm_nt_bf16<BMN, BMN, E>), dim3((N + BMN - 1) / BMN, (M + BMN - 1) / BMN),     \
-                     dim3(256), 0, s, (const bf16*)A, (const bf16*)B, (bf16*)C, (const float*)bias, M, \
-                     N, K, lda, ldb, ldc, d)
+  hipLaunchKernelGGL((gemm_nt_bf16<BMN, BMN, BMN / 16, E>),                                           \
+                     dim3((N + BMN - 1) / BMN, (M + BMN - 1) / BMN), dim3(BMN * 4), 0, s, (const bf16*)A, \
+                     (const bf16*)B, (bf16*)C, (const float*)bias, M, N, K, lda, ldb, ldc, d)
   if (tile == 128 && epi == 0) NT_CASE(128, EPI_STORE);
   else if (tile == 128 && epi == 1) NT_CASE(128, EPI_BIAS_RELU_DROPOUT);
   else if (tile == 64 && epi == 0) NT_CASE(64, EPI_STORE);
@@ -495,10 +509,10 @@ int dtf_gemm_tn(const void* A, const void* B, void* C, int M, int N, int K, int 
   if ((lda & 7) || (ldb & 7) || (M & 7) || (N & 7)) return -3;
   if (tile == 0) tile = ((long)((M + 127) / 128) * ((N + 127) / 128) >= 192) ? 128 : 64;
   if (tile == 128)
-    hipLaunchKernelGGL((gemm_tn_bf16<128, 128>), dim3((N + 127) / 128, (M + 127) / 128), dim3(256), 0, s,
+    hipLaunchKernelGGL((gemm_tn_bf16<128, 128, 8>), dim3((N + 127) / 128, (M + 127) / 128), dim3(512), 0, s,
                        (const bf16*)A, (const bf16*)B, (float*)C, M, N, K, lda, ldb, ldc);
   else if (tile == 64)
-    hipLaunchKernelGGL((gemm_tn_bf16<64, 64>), dim3((N + 63) / 64, (M + 63) / 64), dim3(256), 0, s,
+    hipLaunchKernelGGL((gemm_tn_bf16<64, 64, 4>), dim3((N + 63) / 64, (M + 63) / 64), dim3(256), 0, s,
                        (const bf16*)A, (const bf16*)B, (float*)C, M, N, K, lda, ldb, ldc);
   else
     return -1;
@@ -519,7 +533,7 @@ int dtf_gemm_nn_fwd(const void* A, const void* B, void* part, void* out, const v
   if (S > T) S = T;
   const int tps = (T + S - 1) / S;
   S = (T + tps - 1) / tps;
-  hipLaunchKernelGGL((gemm_nn_splitk_bf16<128, 128>), dim3((N + 127) / 128, (M + 127) / 128, S), dim3(256), 0, s,
+  hipLaunchKernelGGL((gemm_nn_splitk_bf16<128, 128, 8>), dim3((N + 127) / 128, (M + 127) / 128, S), dim3(512), 0, s,
                      (const bf16*)A, (const bf16*)B, (float*)part, M, N, K, lda, ldb, tps);
   DropoutArgs d{keep_prob, seed, (const int64_t*)state};
   const long MN = (long)M * N;
