@@ -102,18 +102,27 @@ __global__ __launch_bounds__(IMGS * 2 * NW * 64, MINW) void conv5x5_igemm(
   for (int kc0 = 0; kc0 < KTOT; kc0 += KC) {
   __syncthreads();  // zero fill done / previous chunk fully consumed
   if (MODE == MODE_FWD) {
+    // all loads of a thread are issued before the first LDS write (one memory latency per
+    // block, not one per chunk); indices past the end are clamped and their write is skipped
     constexpr int NCHUNK = IMGS * 196 * CH8;
-    for (int c = tid; c < NCHUNK; c += NTHREADS) {
-      int ch = c % CH8;
-      int pos = (c / CH8) % 196;
-      int im = c / (CH8 * 196);
-      int b = img0 + im;
-      if (b < B && !(DTF_ABLATE & 8)) {
-        u32x4 v = *reinterpret_cast<const u32x4*>(in + ((size_t)b * 196 + pos) * KTOT + kc0 + ch * 8);
-        int y = pos / 14, x = pos % 14;
-        int tp = (y + 2) * kTileW + (x + 2);
-        *reinterpret_cast<u32x4*>(tile + ((size_t)im * kTilePos + tp) * KP + ch * 8) = v;
-      }
+    constexpr int ROUNDS = (NCHUNK + NTHREADS - 1) / NTHREADS;
+    u32x4 v[ROUNDS];
+#pragma unroll
+    for (int r = 0; r < ROUNDS; ++r) {
+      int c = min(tid + r * NTHREADS, NCHUNK - 1);
+      int ch = c % CH8, pos = (c / CH8) % 196, im = c / (CH8 * 196);
+      int b = min(img0 + im, B - 1);
+      v[r] = (DTF_ABLATE & 8) ? (u32x4){0u, 0u, 0u, 0u}
+                              : *reinterpret_cast<const u32x4*>(in + ((size_t)b * 196 + pos) * KTOT + kc0 + ch * 8);
+    }
+#pragma unroll
+    for (int r = 0; r < ROUNDS; ++r) {
+      int c = tid + r * NTHREADS;
+      int ch = c % CH8, pos = (c / CH8) % 196, im = c / (CH8 * 196);
+      int y = pos / 14, x = pos % 14;
+      int tp = (y + 2) * kTileW + (x + 2);
+      if (c < NCHUNK && img0 + im < B)
+        *reinterpret_cast<u32x4*>(tile + ((size_t)im * kTilePos + tp) * KP + ch * 8) = v[r];
     }
   } else {
     // max-pool / ReLU gradient: route g to the saved argmax position.
@@ -159,11 +168,8 @@ __global__ __launch_bounds__(IMGS * 2 * NW * 64, MINW) void conv5x5_igemm(
     for (int j = 0; j < NT; ++j)
       dst[j] = *reinterpret_cast<const bf16x8*>(b_base + ((size_t)wtap * NC + j * 16) * KTOT + ks * 32);
   };
-  load_b(bcur, 0);
   constexpr int NSTEPS = 25 * KSTEPS;
-#pragma unroll 1
-  for (int step = 0; step < NSTEPS; ++step) {
-    if (!(DTF_ABLATE & 1) && step + 1 < NSTEPS) load_b(bnxt, step + 1);
+  auto do_step = [&](int step, const bf16x8 (&bf)[NT]) {
     const int tap = step / KSTEPS, ks = step % KSTEPS;
     const int ky = tap / 5, kx = tap % 5;
     const bf16* ap = a_base + (ky * kTileW + kx) * KP + ks * 32;
@@ -175,13 +181,22 @@ __global__ __launch_bounds__(IMGS * 2 * NW * 64, MINW) void conv5x5_igemm(
     for (int i = 0; i < 7; ++i)
 #pragma unroll
       for (int j = 0; j < NT; ++j) {
-        if (DTF_ABLATE & 4) { asm volatile("" ::"v"(a[i]), "v"(bcur[j])); }
-        else acc[i][j] = mfma16(a[i], bcur[j], acc[i][j]);
+        if (DTF_ABLATE & 4) { asm volatile("" ::"v"(a[i]), "v"(bf[j])); }
+        else acc[i][j] = mfma16(a[i], bf[j], acc[i][j]);
       }
-    if (!(DTF_ABLATE & 1)) {
-#pragma unroll
-      for (int j = 0; j < NT; ++j) bcur[j] = bnxt[j];
-    }
+  };
+  // B fragments of step s+1 are loaded (unconditionally: the last step re-loads itself, so every
+  // wait is an exact count) before the MFMAs of step s; two register sets, loop unrolled by two
+  load_b(bcur, 0);
+#pragma unroll 1
+  for (int step = 0; step < NSTEPS; step += 2) {
+    if (!(DTF_ABLATE & 1)) load_b(bnxt, min(step + 1, NSTEPS - 1));
+    __builtin_amdgcn_sched_barrier(0);
+    do_step(step, bcur);
+    if (step + 1 >= NSTEPS) break;
+    if (!(DTF_ABLATE & 1)) load_b(bcur, min(step + 2, NSTEPS - 1));
+    __builtin_amdgcn_sched_barrier(0);
+    do_step(step + 1, (DTF_ABLATE & 1) ? bcur : bnxt);
   }
   }  // K chunks
 
