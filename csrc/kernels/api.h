@@ -6,6 +6,9 @@
 extern "C" {
 int dtf_conv1_fwd(const void* images, const void* idx, const void* w, const void* bias, void* pooled, void* arg,
                   int B, int cout, int grid, hipStream_t s);
+int dtf_conv1_fwd_sampled(const void* images, void* idx_out, const void* state, unsigned n, unsigned hb,
+                          unsigned seed, int shuffle, const void* w, const void* bias, void* pooled, void* arg,
+                          int B, int cout, int grid, hipStream_t s);
 int dtf_conv1_wgrad(const void* images, const void* idx, const void* gpool, const void* arg, const void* pooled,
                     void* part, int B, int cout, int grid, hipStream_t s);
 int dtf_conv2_fwd(const void* x, const void* wT, const void* bias, void* pooled, void* arg, int B, int cin, int cout,
@@ -33,6 +36,10 @@ int dtf_adam_update(void* w, const void* g, void* m, void* v, void* shadow, cons
 int dtf_cast_bf16(const void* w, void* shadow, long n, hipStream_t s);
 int dtf_reduce_segments(int count, const void** part, void** out, const int* G, const int* n, const long* stride,
                         hipStream_t s);
+int dtf_fused_reduce_sgd(int count, const void** part, const int* G, const int* n, const long* stride,
+                         const long* seg_off, void* w, void* g, void* shadow, const void* hyper, long dense_lo,
+                         long dense_hi, void* wc2T, long wc2_off, int c1, int c2, void* state, long cursor_inc,
+                         long step_inc, long drop_inc, hipStream_t s);
 int dtf_sample_indices(const void* state, void* idx, int B, unsigned n, unsigned hb, unsigned seed, int shuffle,
                        hipStream_t s);
 }

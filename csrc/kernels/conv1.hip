@@ -29,9 +29,20 @@ namespace dtf {
 // grid-stride over images; 4 waves split the 14 row pairs.  w: fp32 HWIO [25][C] (rounded to bf16).
 constexpr int kC1Pitch = 96;   // pixels per padded LDS row (48 dwords: rows of lane groups g, g+1 never share a bank)
 
+// Fused batch sampler (state != nullptr): the block derives the dataset row of image b from the
+// device-resident sample cursor itself -- the stateless Feistel epoch shuffle of data.hip's
+// sample_indices, bit for bit -- and publishes it in idx_out[b] for the later consumers of the
+// batch (head labels, conv1 wgrad).  This removes the sampler launch from the head of every step.
+struct SampleArgs {
+  const int64_t* state;   // nullptr: rows come from idx (or are 0..B-1)
+  int* idx_out;
+  uint32_t n, hb, seed;
+  int shuffle;
+};
+
 template <int C>
 __global__ __launch_bounds__(256) void conv1_pool_fwd(const bf16* __restrict__ images,
-                                                      const int* __restrict__ idx,
+                                                      const int* __restrict__ idx, SampleArgs smp,
                                                       const float* __restrict__ w,
                                                       const float* __restrict__ bias,
                                                       bf16* __restrict__ pooled,
@@ -60,9 +71,25 @@ __global__ __launch_bounds__(256) void conv1_pool_fwd(const bf16* __restrict__ i
 
   for (int i = tid; i < 32 * kC1Pitch / 8; i += 256) reinterpret_cast<u4*>(img)[i] = (u4){0u, 0u, 0u, 0u};
 
+  uint32_t s_epoch = 0, s_pos = 0;
+  if (smp.state) {   // one 64-bit division per thread, once; everything after is 32-bit
+    const uint64_t c = (uint64_t)smp.state[0];
+    s_epoch = (uint32_t)(c / smp.n);
+    s_pos = (uint32_t)(c % smp.n);
+  }
+
   for (int b = blockIdx.x; b < B; b += gridDim.x) {
     __syncthreads();   // previous image consumed / zero fill done
-    const size_t row = idx ? (size_t)idx[b] : (size_t)b;
+    size_t row;
+    if (smp.state) {
+      const uint32_t at = s_pos + (uint32_t)b;        // batches may span epochs (B can exceed n)
+      const uint32_t epoch = s_epoch + at / smp.n, pos = at % smp.n;
+      const uint32_t r = smp.shuffle ? feistel_permute(pos, smp.n, smp.hb, mix32(smp.seed + epoch * 0x9E3779B9u)) : pos;
+      if (tid == 0 && blockIdx.y == 0) smp.idx_out[b] = (int)r;
+      row = r;
+    } else {
+      row = idx ? (size_t)idx[b] : (size_t)b;
+    }
     const unsigned* src = reinterpret_cast<const unsigned*>(images + row * 784);
     for (int i = tid; i < 392; i += 256) {   // 2 pixels (one dword) per thread-iteration
       int y = i / 14, x2 = i % 14;
@@ -279,18 +306,33 @@ using namespace dtf;
 
 extern "C" {
 
-int dtf_conv1_fwd(const void* images, const void* idx, const void* w, const void* bias, void* pooled,
-                  void* arg, int B, int cout, int grid, hipStream_t s) {
+static int conv1_fwd_launch(const void* images, const void* idx, SampleArgs smp, const void* w, const void* bias,
+                            void* pooled, void* arg, int B, int cout, int grid, hipStream_t s) {
   if (grid <= 0) grid = B < 1024 ? B : 1024;
   if (cout == 32)
     hipLaunchKernelGGL((conv1_pool_fwd<32>), dim3(grid, 1), dim3(256), 0, s, (const bf16*)images,
-                       (const int*)idx, (const float*)w, (const float*)bias, (bf16*)pooled, (uint8_t*)arg, B);
+                       (const int*)idx, smp, (const float*)w, (const float*)bias, (bf16*)pooled, (uint8_t*)arg, B);
   else if (cout == 128)
     hipLaunchKernelGGL((conv1_pool_fwd<128>), dim3(grid, 4), dim3(256), 0, s, (const bf16*)images,
-                       (const int*)idx, (const float*)w, (const float*)bias, (bf16*)pooled, (uint8_t*)arg, B);
+                       (const int*)idx, smp, (const float*)w, (const float*)bias, (bf16*)pooled, (uint8_t*)arg, B);
   else
     return -1;
   return (int)hipGetLastError();
+}
+
+int dtf_conv1_fwd(const void* images, const void* idx, const void* w, const void* bias, void* pooled,
+                  void* arg, int B, int cout, int grid, hipStream_t s) {
+  return conv1_fwd_launch(images, idx, SampleArgs{nullptr, nullptr, 0, 0, 0, 0}, w, bias, pooled, arg, B, cout, grid, s);
+}
+
+// conv1 forward on the next training batch of the resident dataset: rows are drawn from the
+// device sample cursor state[0] inside the kernel and written to idx_out[B]
+int dtf_conv1_fwd_sampled(const void* images, void* idx_out, const void* state, unsigned n, unsigned hb,
+                          unsigned seed, int shuffle, const void* w, const void* bias, void* pooled, void* arg,
+                          int B, int cout, int grid, hipStream_t s) {
+  if (!state || !idx_out || n == 0 || (1ull << (2 * hb)) < n) return -3;
+  return conv1_fwd_launch(images, nullptr, SampleArgs{(const int64_t*)state, (int*)idx_out, n, hb, seed, shuffle}, w,
+                          bias, pooled, arg, B, cout, grid, s);
 }
 
 // part must hold grid * 26 * cout floats

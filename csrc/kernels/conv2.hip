@@ -33,6 +33,14 @@
 #ifndef DTF_ABLATE
 #define DTF_ABLATE 0
 #endif
+// Tile configuration of the 32->64 layer: KTOT, KC, NC, IMGS, NW, MODE, min waves/SIMD
+// (overridable so tools/conv_ablate.py can sweep it)
+#ifndef DTF_FWD_CFG
+#define DTF_FWD_CFG 32, 32, 64, 2, 2, MODE_FWD, 4
+#endif
+#ifndef DTF_DGRAD_CFG
+#define DTF_DGRAD_CFG 64, 32, 32, 2, 1, MODE_DGRAD, 4
+#endif
 
 namespace dtf {
 
@@ -132,7 +140,7 @@ __global__ __launch_bounds__(IMGS * 2 * NW * 64, MINW) void conv5x5_igemm(
       int pp = (c / CH8) % 49;
       int im = c / (CH8 * 49);
       int b = img0 + im;
-      if (b < B) {
+      if (b < B && !(DTF_ABLATE & 8)) {
         size_t off = ((size_t)b * 49 + pp) * KTOT + kc0 + ch * 8;
         bf16x8 gq = *reinterpret_cast<const bf16x8*>(in + off);
         bf16x8 p = *reinterpret_cast<const bf16x8*>(in_pooled + off);
@@ -200,45 +208,65 @@ __global__ __launch_bounds__(IMGS * 2 * NW * 64, MINW) void conv5x5_igemm(
   }
   }  // K chunks
 
-  // ---- epilogue ----
-  const int b = img0 + w_img;
-  if (b >= B) return;
+  // ---- epilogue: results go through LDS (the tile is dead by now) so that global memory sees
+  // linear 16-byte stores; straight from the C/D layout they would be 2-byte (1-byte for argmax)
+  // stores scattered over positions ----
   // C/D map: lane holds rows 4*(lane>>4)+r -> window (lane>>4), q = r; col = lane&15
   const int ewin = 4 * w_h + g;  // window index along x (0..7; 7 is the dummy window)
-  if (ewin >= 7) return;
+  __syncthreads();
   if (MODE == MODE_FWD) {
+    bf16* ot = reinterpret_cast<bf16*>(smem);                      // [IMGS][49][NC]
+    uint8_t* oa = reinterpret_cast<uint8_t*>(smem) + IMGS * 49 * NC * 2;  // [IMGS][49][NC]
+    if (ewin < 7) {
 #pragma unroll
-    for (int j = 0; j < NT; ++j) {
-      const int n = w_n * NT * 16 + j * 16 + m;
-      const float bv = bias[n];
+      for (int j = 0; j < NT; ++j) {
+        const int n = w_n * NT * 16 + j * 16 + m;
+        const float bv = bias[n];
 #pragma unroll
-      for (int i = 0; i < 7; ++i) {
-        f32x4 v = acc[i][j];
-        float best = v[0];
-        int bi = 0;
-        if (v[1] > best) { best = v[1]; bi = 1; }
-        if (v[2] > best) { best = v[2]; bi = 2; }
-        if (v[3] > best) { best = v[3]; bi = 3; }
-        float o = fmaxf(best + bv, 0.f);
-        size_t off = (((size_t)b * 7 + i) * 7 + ewin) * NC + n;
-        if ((DTF_ABLATE & 16) && o != -1.f) continue;
-        out[off] = (bf16)o;
-        out_arg[off] = (uint8_t)bi;
-      }
-    }
-  } else {
-#pragma unroll
-    for (int j = 0; j < NT; ++j) {
-      const int n = w_n * NT * 16 + j * 16 + m;
-#pragma unroll
-      for (int i = 0; i < 7; ++i) {
-        f32x4 v = acc[i][j];
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          int y = 2 * i + (r >> 1), x = 2 * ewin + (r & 1);
-          out[(((size_t)b * 14 + y) * 14 + x) * NC + n] = (bf16)v[r];
+        for (int i = 0; i < 7; ++i) {
+          f32x4 v = acc[i][j];
+          float best = v[0];
+          int bi = 0;
+          if (v[1] > best) { best = v[1]; bi = 1; }
+          if (v[2] > best) { best = v[2]; bi = 2; }
+          if (v[3] > best) { best = v[3]; bi = 3; }
+          float o = fmaxf(best + bv, 0.f);
+          const int off = ((w_img * 7 + i) * 7 + ewin) * NC + n;
+          ot[off] = (bf16)o;
+          oa[off] = (uint8_t)bi;
         }
       }
+    }
+    __syncthreads();
+    if (!(DTF_ABLATE & 16)) {
+      const int nimg = min(IMGS, B - img0);
+      u32x4* gp = reinterpret_cast<u32x4*>(out + (size_t)img0 * 49 * NC);
+      for (int c = tid; c < nimg * 49 * NC / 8; c += NTHREADS) gp[c] = reinterpret_cast<const u32x4*>(ot)[c];
+      u32x4* ga = reinterpret_cast<u32x4*>(out_arg + (size_t)img0 * 49 * NC);
+      for (int c = tid; c < nimg * 49 * NC / 16; c += NTHREADS) ga[c] = reinterpret_cast<const u32x4*>(oa)[c];
+    }
+  } else {
+    bf16* ot = reinterpret_cast<bf16*>(smem);  // [IMGS][196][NC]
+    if (ewin < 7) {
+#pragma unroll
+      for (int j = 0; j < NT; ++j) {
+        const int n = w_n * NT * 16 + j * 16 + m;
+#pragma unroll
+        for (int i = 0; i < 7; ++i) {
+          f32x4 v = acc[i][j];
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            int y = 2 * i + (r >> 1), x = 2 * ewin + (r & 1);
+            ot[((w_img * 14 + y) * 14 + x) * NC + n] = (bf16)v[r];
+          }
+        }
+      }
+    }
+    __syncthreads();
+    if (!(DTF_ABLATE & 16)) {
+      const int nimg = min(IMGS, B - img0);
+      u32x4* gp = reinterpret_cast<u32x4*>(out + (size_t)img0 * 196 * NC);
+      for (int c = tid; c < nimg * 196 * NC / 8; c += NTHREADS) gp[c] = reinterpret_cast<const u32x4*>(ot)[c];
     }
   }
 }
@@ -509,7 +537,7 @@ extern "C" {
 int dtf_conv2_fwd(const void* x, const void* wT, const void* bias, void* pooled, void* arg, int B,
                   int cin, int cout, hipStream_t s) {
   if (cin == 32 && cout == 64)
-    return launch_igemm<32, 32, 64, 1, 2, MODE_FWD, 4>(x, nullptr, nullptr, wT, bias, pooled, arg, B, s);
+    return launch_igemm<DTF_FWD_CFG>(x, nullptr, nullptr, wT, bias, pooled, arg, B, s);
   if (cin == 128 && cout == 256)
     return launch_igemm<128, 128, 256, 1, 4, MODE_FWD>(x, nullptr, nullptr, wT, bias, pooled, arg, B, s);
   return -1;
@@ -519,7 +547,7 @@ int dtf_conv2_fwd(const void* x, const void* wT, const void* bias, void* pooled,
 int dtf_conv2_dgrad(const void* gpool, const void* arg, const void* pooled, const void* w, void* dx,
                     int B, int cin, int cout, hipStream_t s) {
   if (cin == 32 && cout == 64)
-    return launch_igemm<64, 32, 32, 1, 2, MODE_DGRAD, 4>(gpool, arg, pooled, w, nullptr, dx, nullptr, B, s);
+    return launch_igemm<DTF_DGRAD_CFG>(gpool, arg, pooled, w, nullptr, dx, nullptr, B, s);
   if (cin == 128 && cout == 256)
     return launch_igemm<256, 128, 128, 1, 2, MODE_DGRAD>(gpool, arg, pooled, w, nullptr, dx, nullptr, B, s);
   return -1;

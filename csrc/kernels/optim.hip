@@ -142,6 +142,96 @@ __global__ __launch_bounds__(256) void reduce_segments(ReduceSegs segs) {
   }
 }
 
+// ---------------------------------------------------------------------------------------------
+// Single-GPU SGD step tail in ONE launch: slab reduction + parameter update + bf16 shadow + the
+// K-contiguous conv2 weight copy (+ step-state advance).  Replaces reduce_segments (x2), sgd_update
+// and transpose_bf16: on this chip every dependent launch costs ~2 us before it does any work and
+// the three small kernels were latency chains of 5-6 us each.
+// Blocks [0, reduce_blocks) own 16 float4 columns of a slab-backed segment (head | conv2 | conv1):
+// they sum the slabs in the fixed order of reduce_segments (bitwise identical gradients), store the
+// reduced gradient (so the gradient arena stays inspectable) and apply the update to exactly those
+// elements.  The remaining blocks stream the dense range whose gradient is already final (wd1).
+// ---------------------------------------------------------------------------------------------
+struct FusedSeg {
+  const float* part;  // [G][stride]
+  int G, n;
+  long stride;
+  long arena_off;     // float offset of the segment in the parameter / gradient arenas
+};
+struct FusedSgdArgs {
+  FusedSeg s[3];
+  int blocks_end[3];
+  int count, reduce_blocks;
+  float* w;
+  float* g;
+  bf16* shadow;
+  const float* hyper;
+  long dense_lo4, dense_hi4;   // dense range in float4 units
+  bf16* wc2T;                  // [25][c2][c1] copy of the wc2 shadow (nullptr: none)
+  long wc2_off;
+  int c1, c2;
+  StepAdvance adv;
+};
+
+__global__ __launch_bounds__(256) void fused_reduce_sgd(FusedSgdArgs a) {
+  __shared__ f32x4 red[16][17];
+  const float lr = a.hyper[0] * a.hyper[4];
+  if ((int)blockIdx.x < a.reduce_blocks) {
+    int k = 0, blk = blockIdx.x;
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+      if (k == t && t + 1 < a.count && (int)blockIdx.x >= a.blocks_end[t]) { k = t + 1; blk = blockIdx.x - a.blocks_end[t]; }
+    const FusedSeg sg = a.s[k];
+    const int col = threadIdx.x & 15, grp = threadIdx.x >> 4;
+    const long i4 = (long)blk * 16 + col;
+    f32x4 a0 = {0.f, 0.f, 0.f, 0.f}, a1 = a0;
+    if (i4 * 4 < sg.n) {
+      const float* p = sg.part + i4 * 4;
+      int gI = grp;
+      for (; gI + 16 < sg.G; gI += 32) {
+        f32x4 v0 = *reinterpret_cast<const f32x4*>(p + (size_t)gI * sg.stride);
+        f32x4 v1 = *reinterpret_cast<const f32x4*>(p + (size_t)(gI + 16) * sg.stride);
+        a0 += v0;
+        a1 += v1;
+      }
+      if (gI < sg.G) a0 += *reinterpret_cast<const f32x4*>(p + (size_t)gI * sg.stride);
+    }
+    red[grp][col] = a0 + a1;
+    __syncthreads();
+    if (grp == 0 && i4 * 4 < sg.n) {
+      f32x4 gs = red[0][col];
+#pragma unroll
+      for (int t = 1; t < 16; ++t) gs += red[t][col];
+      const long e0 = sg.arena_off + i4 * 4;
+      *reinterpret_cast<f32x4*>(a.g + e0) = gs;
+      f32x4 wv = *reinterpret_cast<const f32x4*>(a.w + e0);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) wv[e] = fmaf(-lr, gs[e], wv[e]);
+      *reinterpret_cast<f32x4*>(a.w + e0) = wv;
+      store_bf16x4(a.shadow + e0, wv[0], wv[1], wv[2], wv[3]);
+      const long r = e0 - a.wc2_off;
+      if (a.wc2T && r >= 0 && r < 25L * a.c1 * a.c2) {
+        // HWIO element (tap, ci, co..co+3) -> [tap][co][ci]
+        const int tap = (int)(r / (a.c1 * a.c2)), rem = (int)(r % (a.c1 * a.c2));
+        const int ci = rem / a.c2, co = rem % a.c2;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) a.wc2T[((long)tap * a.c2 + co + e) * a.c1 + ci] = (bf16)wv[e];
+      }
+    }
+  } else {
+    const long nb = gridDim.x - a.reduce_blocks;
+    for (long i = a.dense_lo4 + (long)(blockIdx.x - a.reduce_blocks) * 256 + threadIdx.x; i < a.dense_hi4; i += nb * 256) {
+      f32x4 wv = reinterpret_cast<const f32x4*>(a.w)[i];
+      f32x4 gv = reinterpret_cast<const f32x4*>(a.g)[i];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) wv[e] = fmaf(-lr, gv[e], wv[e]);
+      reinterpret_cast<f32x4*>(a.w)[i] = wv;
+      store_bf16x4(a.shadow + 4 * i, wv[0], wv[1], wv[2], wv[3]);
+    }
+  }
+  advance_state(a.adv);
+}
+
 }  // namespace dtf
 
 using namespace dtf;
@@ -208,6 +298,44 @@ int dtf_reduce_segments(int count, const void** part, void** out, const int* G, 
   }
   segs.count = count;
   hipLaunchKernelGGL(reduce_segments, dim3(blocks), dim3(256), 0, s, segs);
+  return (int)hipGetLastError();
+}
+
+// Fused single-GPU SGD tail (see fused_reduce_sgd).  Segments: part[k] is [G[k]][stride[k]] and
+// lands at arena float offset seg_off[k] (n[k] floats); [dense_lo, dense_hi) is the float range whose
+// gradient is already final.  wc2T may be NULL.
+int dtf_fused_reduce_sgd(int count, const void** part, const int* G, const int* n, const long* stride,
+                         const long* seg_off, void* w, void* g, void* shadow, const void* hyper, long dense_lo,
+                         long dense_hi, void* wc2T, long wc2_off, int c1, int c2, void* state, long cursor_inc,
+                         long step_inc, long drop_inc, hipStream_t s) {
+  if (count < 1 || count > 3 || (dense_lo & 3) || (dense_hi & 3) || (wc2_off & 3) || (c2 & 3)) return -3;
+  FusedSgdArgs a;
+  int blocks = 0;
+  for (int k = 0; k < 3; ++k) {
+    if (k < count) {
+      if ((n[k] & 3) || (stride[k] & 3) || (seg_off[k] & 3) || ((uintptr_t)part[k] & 15)) return -3;
+      a.s[k] = FusedSeg{(const float*)part[k], G[k], n[k], stride[k], seg_off[k]};
+      blocks += (n[k] / 4 + 15) / 16;
+    } else {
+      a.s[k] = FusedSeg{nullptr, 0, 0, 0, 0};
+    }
+    a.blocks_end[k] = blocks;
+  }
+  a.count = count;
+  a.reduce_blocks = blocks;
+  a.w = (float*)w;
+  a.g = (float*)g;
+  a.shadow = (bf16*)shadow;
+  a.hyper = (const float*)hyper;
+  a.dense_lo4 = dense_lo / 4;
+  a.dense_hi4 = dense_hi / 4;
+  a.wc2T = (bf16*)wc2T;
+  a.wc2_off = wc2_off;
+  a.c1 = c1;
+  a.c2 = c2;
+  a.adv = StepAdvance{(int64_t*)state, cursor_inc, step_inc, drop_inc, -1};
+  const int dense_blocks = grid_for((dense_hi - dense_lo) / 4);
+  hipLaunchKernelGGL(fused_reduce_sgd, dim3(blocks + dense_blocks), dim3(256), 0, s, a);
   return (int)hipGetLastError();
 }
 

@@ -85,22 +85,26 @@ int dtf_engine_forward_dense(const DtfEngineDesc* e, const void* labels, const v
                           1.0f / keep, backward, s);
 }
 
-// head wgrad + slab reduce + fc1 wgrad: finalises the (head | wd1) prefix of the gradient arena
-int dtf_engine_backward_dense(const DtfEngineDesc* e, hipStream_t s) {
+// head wgrad + slab reduce + fc1 wgrad: finalises the (head | wd1) prefix of the gradient arena.
+// reduce == 0 leaves the head slabs unreduced (the fused single-GPU SGD tail sums them itself).
+static int backward_dense_impl(const DtfEngineDesc* e, int reduce, hipStream_t s) {
   DTF_TRY(dtf_head_wgrad(e->h1, e->dlogits, e->da, e->head_part, e->B, e->hidden, e->head_ks, s));
-  const void* part[1] = {e->head_part};
-  void* out[1] = {f32at(e->grads, e->off_out_w)};
-  int G[1] = {e->head_ks}, n[1] = {(int)e->head_stride};
-  long st[1] = {e->head_stride};
-  DTF_TRY(dtf_reduce_segments(1, part, out, G, n, st, s));
+  if (reduce) {
+    const void* part[1] = {e->head_part};
+    void* out[1] = {f32at(e->grads, e->off_out_w)};
+    int G[1] = {e->head_ks}, n[1] = {(int)e->head_stride};
+    long st[1] = {e->head_stride};
+    DTF_TRY(dtf_reduce_segments(1, part, out, G, n, st, s));
+  }
   return dtf_gemm_tn(e->p2, e->da, f32at(e->grads, e->off_wd1), e->flat, e->hidden, e->B, e->flat, e->hidden,
                      e->hidden, 0, s);
 }
+int dtf_engine_backward_dense(const DtfEngineDesc* e, hipStream_t s) { return backward_dense_impl(e, 1, s); }
 
 // fc1 dgrad -> {conv2 dgrad -> conv1 wgrad} || conv2 wgrad (side stream) -> slab reduce.
 // record_dgrad != 0: e->ev_dgrad is recorded right after fc1 dgrad (the last reader of bf16 wd1).
-int dtf_engine_backward_conv(const DtfEngineDesc* e, const void* images, const void* idx, int record_dgrad,
-                             hipStream_t s) {
+static int backward_conv_impl(const DtfEngineDesc* e, const void* images, const void* idx, int record_dgrad,
+                              int reduce, hipStream_t s) {
   DTF_TRY(dtf_gemm_nt(e->da, bf16at(e->shadow, e->off_wd1), e->dflat, nullptr, e->B, e->flat, e->hidden, e->hidden,
                       e->hidden, e->flat, 0, 1.0f, 0, nullptr, 0, s));
   if (record_dgrad) HIP_TRY(hipEventRecord(e->ev_dgrad, s));
@@ -115,25 +119,33 @@ int dtf_engine_backward_conv(const DtfEngineDesc* e, const void* images, const v
   DTF_TRY(dtf_conv2_dgrad(e->dflat, e->arg2, e->p2, bf16at(e->shadow, e->off_wc2), e->dp1, e->B, e->c1, e->c2, s));
   DTF_TRY(dtf_conv1_wgrad(images, idx, e->dp1, e->arg1, e->p1, e->c1_part, e->B, e->c1, e->c1_g, s));
   if (e->multi_stream) HIP_TRY(hipStreamWaitEvent(s, e->ev_join2, 0));
+  if (!reduce) return 0;
   const void* part[2] = {e->c2_part, e->c1_part};
   void* out[2] = {f32at(e->grads, e->off_wc2), f32at(e->grads, e->off_wc1)};
   int G[2] = {e->c2_g, e->c1_g}, n[2] = {(int)e->c2_stride, (int)e->c1_stride};
   long st[2] = {e->c2_stride, e->c1_stride};
   return dtf_reduce_segments(2, part, out, G, n, st, s);
 }
+int dtf_engine_backward_conv(const DtfEngineDesc* e, const void* images, const void* idx, int record_dgrad,
+                             hipStream_t s) {
+  return backward_conv_impl(e, images, idx, record_dgrad, 1, s);
+}
 
 // whole backward; the dense-layer weight gradients run on side1 next to the conv chain
-int dtf_engine_backward(const DtfEngineDesc* e, const void* images, const void* idx, hipStream_t s) {
+static int backward_impl(const DtfEngineDesc* e, const void* images, const void* idx, int reduce, hipStream_t s) {
   if (!e->multi_stream) {
-    DTF_TRY(dtf_engine_backward_dense(e, s));
-    return dtf_engine_backward_conv(e, images, idx, 0, s);
+    DTF_TRY(backward_dense_impl(e, reduce, s));
+    return backward_conv_impl(e, images, idx, 0, reduce, s);
   }
   HIP_TRY(hipEventRecord(e->ev_head, s));
   HIP_TRY(hipStreamWaitEvent(e->side1, e->ev_head, 0));
-  DTF_TRY(dtf_engine_backward_dense(e, e->side1));
+  DTF_TRY(backward_dense_impl(e, reduce, e->side1));
   HIP_TRY(hipEventRecord(e->ev_join1, e->side1));
-  DTF_TRY(dtf_engine_backward_conv(e, images, idx, 0, s));
+  DTF_TRY(backward_conv_impl(e, images, idx, 0, reduce, s));
   return (int)hipStreamWaitEvent(s, e->ev_join1, 0);
+}
+int dtf_engine_backward(const DtfEngineDesc* e, const void* images, const void* idx, hipStream_t s) {
+  return backward_impl(e, images, idx, 1, s);
 }
 
 int dtf_engine_update_range(const DtfEngineDesc* e, long lo, long hi, int advance, int advance_cursor, long step_inc,
@@ -154,14 +166,27 @@ int dtf_engine_transposes(const DtfEngineDesc* e, int wc2, hipStream_t s) {
   return 0;
 }
 
-// one full optimisation step on the resident dataset
+// one full optimisation step on the resident dataset.  SGD (the reference optimizer) ends in the
+// fused tail: slab reductions + update + bf16 shadow + K-contiguous wc2 copy in one launch.
 int dtf_engine_train_step(const DtfEngineDesc* e, long step_inc, hipStream_t s) {
-  DTF_TRY(dtf_engine_sample(e, s));
-  DTF_TRY(dtf_engine_forward_conv(e, e->ds_images, e->idx, e->B, s));
+  // the batch sampler runs inside conv1 forward (rows from the device cursor, published in e->idx)
+  DTF_TRY(dtf_conv1_fwd_sampled(e->ds_images, e->idx, e->state, e->ds_n, e->ds_hb, e->sample_seed, e->shuffle,
+                                f32at(e->params, e->off_wc1), f32at(e->params, e->off_bc1), e->p1, e->arg1, e->B,
+                                e->c1, 0, s));
+  DTF_TRY(dtf_conv2_fwd(e->p1, e->wc2T, f32at(e->params, e->off_bc2), e->p2, e->arg2, e->B, e->c1, e->c2, s));
   DTF_TRY(dtf_engine_forward_dense(e, e->ds_labels, e->idx, 1, e->B, 1, s));
-  DTF_TRY(dtf_engine_backward(e, e->ds_images, e->idx, s));
-  DTF_TRY(dtf_engine_update_range(e, 0, e->n_total, 1, 1, step_inc, 3, s));
-  return dtf_engine_transposes(e, 1, s);
+  if (e->optimizer != 0) {
+    DTF_TRY(backward_impl(e, e->ds_images, e->idx, 1, s));
+    DTF_TRY(dtf_engine_update_range(e, 0, e->n_total, 1, 1, step_inc, 3, s));
+    return dtf_engine_transposes(e, 1, s);
+  }
+  DTF_TRY(backward_impl(e, e->ds_images, e->idx, 0, s));
+  const void* part[3] = {e->head_part, e->c2_part, e->c1_part};
+  int G[3] = {e->head_ks, e->c2_g, e->c1_g}, n[3] = {(int)e->head_stride, (int)e->c2_stride, (int)e->c1_stride};
+  long st[3] = {e->head_stride, e->c2_stride, e->c1_stride};
+  long off[3] = {e->off_out_w, e->off_wc2, e->off_wc1};
+  return dtf_fused_reduce_sgd(3, part, G, n, st, off, e->params, e->grads, e->shadow, e->hyper, e->off_wd1, e->off_wc2,
+                              e->wc2T, e->off_wc2, e->c1, e->c2, e->state, e->B, step_inc, 1, s);
 }
 
 }  // extern "C"

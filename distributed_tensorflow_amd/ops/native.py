@@ -27,6 +27,8 @@ class NativeLibraryMissing(RuntimeError):
 _SIGS = {
     # name: argtypes
     "dtf_conv1_fwd": [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p],
+    "dtf_conv1_fwd_sampled": [c_void_p, c_void_p, c_void_p, c_uint, c_uint, c_uint, c_int, c_void_p, c_void_p, c_void_p,
+                              c_void_p, c_int, c_int, c_int, c_void_p],
     "dtf_conv1_wgrad": [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p],
     "dtf_conv2_fwd": [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p],
     "dtf_conv2_dgrad": [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p],
@@ -47,6 +49,9 @@ _SIGS = {
     "dtf_cast_bf16": [c_void_p, c_void_p, c_long, c_void_p],
     "dtf_reduce_segments": [c_int, ctypes.POINTER(c_void_p), ctypes.POINTER(c_void_p), ctypes.POINTER(c_int),
                             ctypes.POINTER(c_int), ctypes.POINTER(c_long), c_void_p],
+    "dtf_fused_reduce_sgd": [c_int, ctypes.POINTER(c_void_p), ctypes.POINTER(c_int), ctypes.POINTER(c_int),
+                             ctypes.POINTER(c_long), ctypes.POINTER(c_long), c_void_p, c_void_p, c_void_p, c_void_p,
+                             c_long, c_long, c_void_p, c_long, c_int, c_int, c_void_p, c_long, c_long, c_long, c_void_p],
     "dtf_sample_indices": [c_void_p, c_void_p, c_int, c_uint, c_uint, c_uint, c_int, c_void_p],
     "dtf_gen_synthetic": [c_void_p, c_void_p, c_long, c_uint, c_void_p],
     "dtf_init_truncated_normal": [c_void_p, c_long, c_float, c_uint64, c_uint64, c_void_p],

@@ -96,6 +96,30 @@ def test_conv1_fwd(gpu_lib, B, C):
     assert agree > 0.995, agree
 
 
+def test_conv1_fwd_fused_sampler(gpu_lib):
+    """conv1 forward drawing its own batch from the device cursor == sample_indices + gathered conv1 forward."""
+    from distributed_tensorflow_amd.data import half_bits
+    g = torch.Generator(device="cpu").manual_seed(11)
+    N, B, C, seed = 500, 96, 32, 5
+    images = bf(torch.rand(N, 784, generator=g)).to(DEV)
+    w = (torch.randn(5, 5, 1, C, generator=g) * 0.1).to(DEV)
+    b = (torch.randn(C, generator=g) * 0.1).to(DEV)
+    state = torch.zeros(8, dtype=torch.int64, device=DEV)
+    for cursor in (0, 450, 7 * N + 123):   # the middle one spans an epoch boundary
+        state[0] = cursor
+        idx = torch.zeros(B, dtype=torch.int32, device=DEV)
+        check(gpu_lib.dtf_sample_indices(ptr(state), ptr(idx), B, N, half_bits(N), seed, 1, stream()), "sample")
+        p0 = torch.empty(B, 14, 14, C, dtype=torch.bfloat16, device=DEV)
+        a0 = torch.empty(B, 14, 14, C, dtype=torch.uint8, device=DEV)
+        check(gpu_lib.dtf_conv1_fwd(ptr(images), ptr(idx), ptr(w), ptr(b), ptr(p0), ptr(a0), B, C, 0, stream()), "c1")
+        idx1 = torch.full((B,), -1, dtype=torch.int32, device=DEV)
+        p1, a1 = torch.empty_like(p0), torch.empty_like(a0)
+        check(gpu_lib.dtf_conv1_fwd_sampled(ptr(images), ptr(idx1), ptr(state), N, half_bits(N), seed, 1, ptr(w), ptr(b),
+                                            ptr(p1), ptr(a1), B, C, 0, stream()), "c1 sampled")
+        assert torch.equal(idx, idx1)
+        assert torch.equal(p0, p1) and torch.equal(a0, a1)
+
+
 @pytest.mark.parametrize("B,C", [(33, 32), (6, 128)])
 def test_conv1_wgrad(gpu_lib, B, C):
     g = torch.Generator(device="cpu").manual_seed(2)
@@ -305,6 +329,41 @@ def test_reduce_segments(gpu_lib):
     assert torch.allclose(out[:1000], a.sum(0), atol=1e-5)
     assert torch.allclose(out[1000:1076], b.sum(0), atol=1e-5)
     assert float(out[1076:].abs().max()) == 0.0
+
+
+def test_fused_reduce_sgd(gpu_lib):
+    """One launch == reduce_segments + sgd_update + wc2 transpose, bitwise."""
+    c1, c2 = 8, 12
+    n_head, n_dense, n_c2, n_c1 = 76, 1000, 25 * c1 * c2 + c2, 40
+    offs = [0, n_head, n_head + n_dense, n_head + n_dense + n_c2]
+    total = offs[3] + n_c1
+    g = torch.Generator(device="cpu").manual_seed(3)
+    w0 = torch.randn(total, generator=g).to(DEV)
+    grads = torch.randn(total, generator=g).to(DEV)
+    parts = [torch.randn(G, n, generator=g).to(DEV) for G, n in ((5, n_head), (33, n_c2), (7, n_c1))]
+    hyper = torch.tensor([0.1, 0.9, 0.999, 1e-8, 0.5, 0.0, 0.0, 0.0], device=DEV)
+    # reference path
+    w_ref, g_ref = w0.clone(), grads.clone()
+    for k, (o, p) in enumerate(zip((offs[0], offs[2], offs[3]), parts)):
+        pa = (ctypes.c_void_p * 1)(p.data_ptr()); oa = (ctypes.c_void_p * 1)(g_ref.data_ptr() + 4 * o)
+        check(gpu_lib.dtf_reduce_segments(1, pa, oa, (ctypes.c_int * 1)(p.shape[0]), (ctypes.c_int * 1)(p.shape[1]),
+                                          (ctypes.c_long * 1)(p.shape[1]), stream()), "reduce")
+    sh_ref = torch.zeros(total, dtype=torch.bfloat16, device=DEV)
+    check(gpu_lib.dtf_sgd_update(ptr(w_ref), ptr(g_ref), ptr(sh_ref), ptr(hyper), total, None, 0, 0, 0, stream()), "sgd")
+    # fused path
+    w1, g1 = w0.clone(), grads.clone()
+    sh1 = torch.zeros(total, dtype=torch.bfloat16, device=DEV)
+    wT = torch.zeros(25, c2, c1, dtype=torch.bfloat16, device=DEV)
+    state = torch.zeros(8, dtype=torch.int64, device=DEV)
+    pa = (ctypes.c_void_p * 3)(*[p.data_ptr() for p in parts])
+    check(gpu_lib.dtf_fused_reduce_sgd(3, pa, (ctypes.c_int * 3)(5, 33, 7), (ctypes.c_int * 3)(n_head, n_c2, n_c1),
+                                       (ctypes.c_long * 3)(n_head, n_c2, n_c1), (ctypes.c_long * 3)(offs[0], offs[2], offs[3]),
+                                       ptr(w1), ptr(g1), ptr(sh1), ptr(hyper), offs[1], offs[2], ptr(wT), offs[2], c1, c2,
+                                       ptr(state), 100, 1, 1, stream()), "fused")
+    assert torch.equal(g1, g_ref) and torch.equal(w1, w_ref) and torch.equal(sh1, sh_ref)
+    want_T = sh_ref[offs[2]:offs[2] + 25 * c1 * c2].reshape(25, c1, c2).transpose(1, 2).contiguous()
+    assert torch.equal(wT, want_T)
+    assert state.tolist()[:3] == [100, 1, 1]
 
 
 def test_sgd_and_adam(gpu_lib):
