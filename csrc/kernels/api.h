@@ -11,6 +11,7 @@ int dtf_conv1_fwd_sampled(const void* images, void* idx_out, const void* state, 
                           int B, int cout, int grid, hipStream_t s);
 int dtf_conv1_wgrad(const void* images, const void* idx, const void* gpool, const void* arg, const void* pooled,
                     void* part, int B, int cout, int grid, hipStream_t s);
+int dtf_conv2_pack_weights(const void* w, void* packed, int cin, int cout, hipStream_t s);
 int dtf_conv2_fwd(const void* x, const void* wT, const void* bias, void* pooled, void* arg, int B, int cin, int cout,
                   hipStream_t s);
 int dtf_conv2_dgrad(const void* gpool, const void* arg, const void* pooled, const void* w, void* dx, int B, int cin,

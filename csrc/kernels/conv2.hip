@@ -39,7 +39,7 @@
 #define DTF_FWD_CFG 32, 32, 64, 2, 2, MODE_FWD, 4
 #endif
 #ifndef DTF_DGRAD_CFG
-#define DTF_DGRAD_CFG 64, 32, 32, 2, 1, MODE_DGRAD, 4
+#define DTF_DGRAD_CFG 64, 32, 32, 2, 1, MODE_DGRAD, 3
 #endif
 
 namespace dtf {
@@ -54,13 +54,19 @@ enum { MODE_FWD = 0, MODE_DGRAD = 1 };
 //   in   MODE_FWD  : x    [B,14,14,KC] bf16
 //        MODE_DGRAD: gpool[B,7,7,KC] bf16 (gradient wrt the pooled output),
 //                    arg  [B,7,7,KC] u8, pooled [B,7,7,KC] bf16 (fwd output)
-//   wk   [25][NC][KC] bf16  (K contiguous; fwd: transposed shadow of HWIO,
-//                            dgrad: the HWIO tensor itself, taps read flipped)
+//   wk   fragment-ordered ("packed") weights, see pack_conv2_weights: one contiguous 1 KiB block
+//        per (tap, 32-wide k block, 16-wide n tile), lane l's 8 k-values at l*16 bytes, so a B
+//        fragment load is one fully coalesced 1 KiB read.  (From a plain [n][k] matrix the same
+//        load touches 16 rows x 4 quarter-lines; the texture path handles it line by line and
+//        those loads alone cost dgrad 11 of 34 us -- tools/conv_ablate.py.)
 //   out  MODE_FWD  : pooled [B,7,7,NC] bf16 + argmax [B,7,7,NC] u8
 //        MODE_DGRAD: dx [B,14,14,NC] bf16
 // ----------------------------------------------------------------------------
 // KTOT = reduction channels of the layer, KC = channels resident in LDS at a time (KTOT is
 // walked in KC chunks when the full tile would not fit the 160 KiB LDS).
+constexpr int igemm_tile_w(int kc) { return kc == 32 ? 20 : kTileW; }
+constexpr int igemm_tile_pos(int kc) { return kc == 32 ? 18 * 20 : kTilePos; }
+
 template <int KTOT, int KC, int NC, int IMGS, int NW, int MODE, int MINW>
 __global__ __launch_bounds__(IMGS * 2 * NW * 64, MINW) void conv5x5_igemm(
     const bf16* __restrict__ in, const uint8_t* __restrict__ in_arg,
@@ -72,11 +78,17 @@ __global__ __launch_bounds__(IMGS * 2 * NW * 64, MINW) void conv5x5_igemm(
   constexpr int KSTEPS = KC / 32;      // k-steps per tap
   constexpr int CH8 = KC / 8;          // 16-byte chunks per position
   constexpr int KP = (KC % 64 == 0) ? KC + 8 : KC;  // LDS position pitch: +16 B turns the 4-way b128 conflict of 128-B pitches into 2-way
+  // KC == 32 (64-byte positions): rows of 20 positions and the 16-byte chunk index XORed with
+  // (pos >> 1) & 3 make every ds_read_b128 A-fragment read bank-conflict free for all 25 taps
+  // (18-wide rows without the swizzle are 2-way conflicted on every read; tools/lds_bank_search.py).
+  // 20 is a multiple of 4, so the swizzle of a lane is the same for all 7 row pairs of a step.
+  constexpr bool SWZ = (KC == 32);
+  constexpr int TW = igemm_tile_w(KC), TPOS = igemm_tile_pos(KC);
   static_assert(NC % (16 * NW) == 0, "NC must split evenly over NW waves");
   static_assert(KC % 32 == 0 && KTOT % KC == 0, "KC must be a multiple of 32 dividing KTOT");
 
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  bf16* tile = reinterpret_cast<bf16*>(smem);  // [IMGS][kTilePos][KP]
+  bf16* tile = reinterpret_cast<bf16*>(smem);  // [IMGS][TPOS][KP]
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -90,15 +102,15 @@ __global__ __launch_bounds__(IMGS * 2 * NW * 64, MINW) void conv5x5_igemm(
   {
     u32x4 z = {0u, 0u, 0u, 0u};
     u32x4* t4 = reinterpret_cast<u32x4*>(smem);
-    constexpr int N16 = IMGS * kTilePos * KP * 2 / 16;
+    constexpr int N16 = IMGS * TPOS * KP * 2 / 16;
     for (int i = tid; i < N16; i += NTHREADS) t4[i] = z;
   }
   // lane -> (row m of the 16-row tile, k-group g)
   const int m = lane & 15, g = lane >> 4;
   const int wl = m >> 2, q = m & 3;
   // position of this lane's A row for m-tile 0 (row pair 0), tap (0,0), in tile coordinates
-  const int a_pos = (q >> 1) * kTileW + 2 * (4 * w_h + wl) + (q & 1);
-  const bf16* a_base = tile + ((size_t)w_img * kTilePos + a_pos) * KP + g * 8;
+  const int a_pos = (q >> 1) * TW + 2 * (4 * w_h + wl) + (q & 1);
+  const bf16* a_base = tile + ((size_t)w_img * TPOS + a_pos) * KP + (SWZ ? 0 : g * 8);
 
   f32x4 acc[7][NT];
 #pragma unroll
@@ -128,9 +140,9 @@ __global__ __launch_bounds__(IMGS * 2 * NW * 64, MINW) void conv5x5_igemm(
       int c = tid + r * NTHREADS;
       int ch = c % CH8, pos = (c / CH8) % 196, im = c / (CH8 * 196);
       int y = pos / 14, x = pos % 14;
-      int tp = (y + 2) * kTileW + (x + 2);
+      int tp = (y + 2) * TW + (x + 2);
       if (c < NCHUNK && img0 + im < B)
-        *reinterpret_cast<u32x4*>(tile + ((size_t)im * kTilePos + tp) * KP + ch * 8) = v[r];
+        *reinterpret_cast<u32x4*>(tile + ((size_t)im * TPOS + tp) * KP + (SWZ ? (ch ^ ((tp >> 1) & 3)) : ch) * 8) = v[r];
     }
   } else {
     // max-pool / ReLU gradient: route g to the saved argmax position.
@@ -156,8 +168,8 @@ __global__ __launch_bounds__(IMGS * 2 * NW * 64, MINW) void conv5x5_igemm(
         }
 #pragma unroll
         for (int qq = 0; qq < 4; ++qq) {
-          int tp = (2 * py + (qq >> 1) + 2) * kTileW + (2 * px + (qq & 1) + 2);
-          *reinterpret_cast<bf16x8*>(tile + ((size_t)im * kTilePos + tp) * KP + ch * 8) = o[qq];
+          int tp = (2 * py + (qq >> 1) + 2) * TW + (2 * px + (qq & 1) + 2);
+          *reinterpret_cast<bf16x8*>(tile + ((size_t)im * TPOS + tp) * KP + (SWZ ? (ch ^ ((tp >> 1) & 3)) : ch) * 8) = o[qq];
         }
       }
     }
@@ -166,7 +178,7 @@ __global__ __launch_bounds__(IMGS * 2 * NW * 64, MINW) void conv5x5_igemm(
 
   // ---- main loop over this chunk ----
   // B fragment: column n = lane&15 of n-tile nt, k = kc0 + 8g..8g+7
-  const bf16* b_base = wk + ((size_t)(w_n * NT * 16 + m)) * KTOT + kc0 + g * 8;
+  const bf16* b_base = wk + ((size_t)(kc0 / 32) * (NC / 16) + w_n * NT) * 512 + lane * 8;
 
   bf16x8 bcur[NT], bnxt[NT];
   auto load_b = [&](bf16x8 (&dst)[NT], int step) {
@@ -174,17 +186,18 @@ __global__ __launch_bounds__(IMGS * 2 * NW * 64, MINW) void conv5x5_igemm(
     int wtap = (MODE == MODE_DGRAD) ? (24 - tap) : tap;
 #pragma unroll
     for (int j = 0; j < NT; ++j)
-      dst[j] = *reinterpret_cast<const bf16x8*>(b_base + ((size_t)wtap * NC + j * 16) * KTOT + ks * 32);
+      dst[j] = *reinterpret_cast<const bf16x8*>(b_base + (((size_t)wtap * (KTOT / 32) + ks) * (NC / 16) + j) * 512);
   };
   constexpr int NSTEPS = 25 * KSTEPS;
   auto do_step = [&](int step, const bf16x8 (&bf)[NT]) {
     const int tap = step / KSTEPS, ks = step % KSTEPS;
     const int ky = tap / 5, kx = tap % 5;
-    const bf16* ap = a_base + (ky * kTileW + kx) * KP + ks * 32;
+    const bf16* ap = a_base + (ky * TW + kx) * KP + ks * 32;
+    if (SWZ) ap += (g ^ (((a_pos + ky * TW + kx) >> 1) & 3)) * 8;
     bf16x8 a[7];
 #pragma unroll
     for (int i = 0; i < 7; ++i)
-      a[i] = *reinterpret_cast<const bf16x8*>((DTF_ABLATE & 2) ? a_base + i * 8 : ap + i * (2 * kTileW * KP));
+      a[i] = *reinterpret_cast<const bf16x8*>((DTF_ABLATE & 2) ? a_base + i * 8 : ap + i * (2 * TW * KP));
 #pragma unroll
     for (int i = 0; i < 7; ++i)
 #pragma unroll
@@ -193,18 +206,35 @@ __global__ __launch_bounds__(IMGS * 2 * NW * 64, MINW) void conv5x5_igemm(
         else acc[i][j] = mfma16(a[i], bf[j], acc[i][j]);
       }
   };
-  // B fragments of step s+1 are loaded (unconditionally: the last step re-loads itself, so every
-  // wait is an exact count) before the MFMAs of step s; two register sets, loop unrolled by two
-  load_b(bcur, 0);
+  if constexpr (NSTEPS <= 50) {
+    // Fully unrolled with a ring of D fragment sets: the B fragments of step s+D-1 are requested
+    // before the MFMAs of step s.  One step is only ~250 cycles of MFMA, an L2 hit costs more, and a
+    // distance-1 prefetch left ~10 us of exposed load latency in dgrad (tools/conv_ablate.py).
+    // Loads are unconditional (past the end they re-load the last step): exact vmcnt waits.
+    constexpr int D = 4;
+    bf16x8 ring[D][NT];
+#pragma unroll
+    for (int p = 0; p < D - 1; ++p) load_b(ring[p], p < NSTEPS ? p : NSTEPS - 1);
+#pragma unroll
+    for (int step = 0; step < NSTEPS; ++step) {
+      if (!(DTF_ABLATE & 1)) load_b(ring[(step + D - 1) % D], step + D - 1 < NSTEPS ? step + D - 1 : NSTEPS - 1);
+      __builtin_amdgcn_sched_barrier(0);
+      do_step(step, ring[(DTF_ABLATE & 1) ? 0 : step % D]);
+    }
+  } else {
+    // B fragments of step s+1 are loaded (unconditionally: the last step re-loads itself, so every
+    // wait is an exact count) before the MFMAs of step s; two register sets, loop unrolled by two
+    load_b(bcur, 0);
 #pragma unroll 1
-  for (int step = 0; step < NSTEPS; step += 2) {
-    if (!(DTF_ABLATE & 1)) load_b(bnxt, min(step + 1, NSTEPS - 1));
-    __builtin_amdgcn_sched_barrier(0);
-    do_step(step, bcur);
-    if (step + 1 >= NSTEPS) break;
-    if (!(DTF_ABLATE & 1)) load_b(bcur, min(step + 2, NSTEPS - 1));
-    __builtin_amdgcn_sched_barrier(0);
-    do_step(step + 1, (DTF_ABLATE & 1) ? bcur : bnxt);
+    for (int step = 0; step < NSTEPS; step += 2) {
+      if (!(DTF_ABLATE & 1)) load_b(bnxt, min(step + 1, NSTEPS - 1));
+      __builtin_amdgcn_sched_barrier(0);
+      do_step(step, bcur);
+      if (step + 1 >= NSTEPS) break;
+      if (!(DTF_ABLATE & 1)) load_b(bcur, min(step + 2, NSTEPS - 1));
+      __builtin_amdgcn_sched_barrier(0);
+      do_step(step + 1, (DTF_ABLATE & 1) ? bcur : bnxt);
+    }
   }
   }  // K chunks
 
@@ -268,6 +298,32 @@ __global__ __launch_bounds__(IMGS * 2 * NW * 64, MINW) void conv5x5_igemm(
       u32x4* gp = reinterpret_cast<u32x4*>(out + (size_t)img0 * 196 * NC);
       for (int c = tid; c < nimg * 196 * NC / 8; c += NTHREADS) gp[c] = reinterpret_cast<const u32x4*>(ot)[c];
     }
+  }
+}
+
+// ----------------------------------------------------------------------------
+// Weight packing for conv5x5_igemm.  w: bf16 HWIO [25][cin][cout] (the shadow arena).
+//   fwd  pack (k = ci, n = co): F[((tap*(cin/32)  + ci/32)*(cout/16) + co/16)*512 + (((ci%32)/8)*16 + co%16)*8 + ci%8]
+//   dgrad pack (k = co, n = ci): D[((tap*(cout/32) + co/32)*(cin/16)  + ci/16)*512 + (((co%32)/8)*16 + ci%16)*8 + co%8]
+// packed = [F | D], 25*cin*cout elements each.  The fused SGD tail (optim.hip) writes the same
+// layout directly; this kernel serves init / restore / the multi-GPU and Adam paths.
+// ----------------------------------------------------------------------------
+__host__ __device__ __forceinline__ long conv2_pack_fwd_index(int tap, int ci, int co, int cin, int cout) {
+  return (((long)tap * (cin / 32) + ci / 32) * (cout / 16) + co / 16) * 512 + (((ci % 32) / 8) * 16 + co % 16) * 8 + ci % 8;
+}
+__host__ __device__ __forceinline__ long conv2_pack_dgrad_index(int tap, int ci, int co, int cin, int cout) {
+  return (((long)tap * (cout / 32) + co / 32) * (cin / 16) + ci / 16) * 512 + (((co % 32) / 8) * 16 + ci % 16) * 8 + co % 8;
+}
+
+__global__ __launch_bounds__(256) void pack_conv2_weights(const bf16* __restrict__ w, bf16* __restrict__ packed,
+                                                          int cin, int cout) {
+  const long n = 25L * cin * cout;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+    const int tap = (int)(i / (cin * cout)), rem = (int)(i % (cin * cout));
+    const int ci = rem / cout, co = rem % cout;
+    const bf16 v = w[i];
+    packed[conv2_pack_fwd_index(tap, ci, co, cin, cout)] = v;
+    packed[n + conv2_pack_dgrad_index(tap, ci, co, cin, cout)] = v;
   }
 }
 
@@ -517,7 +573,7 @@ static int launch_igemm(const void* in, const void* in_arg, const void* in_poole
                         const void* bias, void* out, void* out_arg, int B, hipStream_t s) {
   constexpr int threads = IMGS * 2 * NW * 64;
   constexpr int KP = (KC % 64 == 0) ? KC + 8 : KC;
-  constexpr size_t lds = (size_t)IMGS * kTilePos * KP * 2;
+  constexpr size_t lds = (size_t)IMGS * igemm_tile_pos(KC) * KP * 2;
   auto kern = conv5x5_igemm<KTOT, KC, NC, IMGS, NW, MODE, MINW>;
   static bool attr_set = false;
   if (!attr_set) {
@@ -533,7 +589,15 @@ static int launch_igemm(const void* in, const void* in_arg, const void* in_poole
 
 extern "C" {
 
-// Forward: x[B,14,14,cin] -> pooled[B,7,7,cout], arg[B,7,7,cout]; wT [25][cout][cin]
+// packed (2 * 25*cin*cout bf16) = [fwd pack | dgrad pack] of the bf16 HWIO weights w
+int dtf_conv2_pack_weights(const void* w, void* packed, int cin, int cout, hipStream_t s) {
+  if ((cin % 32) || (cout % 32)) return -3;
+  hipLaunchKernelGGL(pack_conv2_weights, dim3((25 * cin * cout + 255) / 256), dim3(256), 0, s, (const bf16*)w,
+                     (bf16*)packed, cin, cout);
+  return DTF_LAUNCH_CHECK();
+}
+
+// Forward: x[B,14,14,cin] -> pooled[B,7,7,cout], arg[B,7,7,cout]; wT = fwd pack (dtf_conv2_pack_weights)
 int dtf_conv2_fwd(const void* x, const void* wT, const void* bias, void* pooled, void* arg, int B,
                   int cin, int cout, hipStream_t s) {
   if (cin == 32 && cout == 64)
@@ -543,7 +607,7 @@ int dtf_conv2_fwd(const void* x, const void* wT, const void* bias, void* pooled,
   return -1;
 }
 
-// dgrad: gpool[B,7,7,cout] (+arg, pooled) -> dx[B,14,14,cin]; w is HWIO [25][cin][cout]
+// dgrad: gpool[B,7,7,cout] (+arg, pooled) -> dx[B,14,14,cin]; w = dgrad pack (second half of dtf_conv2_pack_weights)
 int dtf_conv2_dgrad(const void* gpool, const void* arg, const void* pooled, const void* w, void* dx,
                     int B, int cin, int cout, hipStream_t s) {
   if (cin == 32 && cout == 64)

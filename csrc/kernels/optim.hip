@@ -167,7 +167,7 @@ struct FusedSgdArgs {
   bf16* shadow;
   const float* hyper;
   long dense_lo4, dense_hi4;   // dense range in float4 units
-  bf16* wc2T;                  // [25][c2][c1] copy of the wc2 shadow (nullptr: none)
+  bf16* wc2T;                  // [fwd pack | dgrad pack] of the wc2 shadow (nullptr: none)
   long wc2_off;
   int c1, c2;
   StepAdvance adv;
@@ -210,12 +210,17 @@ __global__ __launch_bounds__(256) void fused_reduce_sgd(FusedSgdArgs a) {
       *reinterpret_cast<f32x4*>(a.w + e0) = wv;
       store_bf16x4(a.shadow + e0, wv[0], wv[1], wv[2], wv[3]);
       const long r = e0 - a.wc2_off;
-      if (a.wc2T && r >= 0 && r < 25L * a.c1 * a.c2) {
-        // HWIO element (tap, ci, co..co+3) -> [tap][co][ci]
+      const long nw = 25L * a.c1 * a.c2;
+      if (a.wc2T && r >= 0 && r < nw) {
+        // HWIO element (tap, ci, co..co+3) -> the two fragment-ordered packs of conv2.hip
+        // (pack_conv2_weights): [fwd pack | dgrad pack]
         const int tap = (int)(r / (a.c1 * a.c2)), rem = (int)(r % (a.c1 * a.c2));
         const int ci = rem / a.c2, co = rem % a.c2;
+        const long f0 = (((long)tap * (a.c1 / 32) + ci / 32) * (a.c2 / 16) + co / 16) * 512 + (((ci % 32) / 8) * 16 + co % 16) * 8 + ci % 8;
 #pragma unroll
-        for (int e = 0; e < 4; ++e) a.wc2T[((long)tap * a.c2 + co + e) * a.c1 + ci] = (bf16)wv[e];
+        for (int e = 0; e < 4; ++e) a.wc2T[f0 + 8 * e] = (bf16)wv[e];   // co+e -> next lane slot (co % 16 + e <= 15)
+        const long d0 = (((long)tap * (a.c2 / 32) + co / 32) * (a.c1 / 16) + ci / 16) * 512 + (((co % 32) / 8) * 16 + ci % 16) * 8 + co % 8;
+        store_bf16x4(a.wc2T + nw + d0, wv[0], wv[1], wv[2], wv[3]);       // 4 consecutive k of one lane slot
       }
     }
   } else {
@@ -308,7 +313,8 @@ int dtf_fused_reduce_sgd(int count, const void** part, const int* G, const int* 
                          const long* seg_off, void* w, void* g, void* shadow, const void* hyper, long dense_lo,
                          long dense_hi, void* wc2T, long wc2_off, int c1, int c2, void* state, long cursor_inc,
                          long step_inc, long drop_inc, hipStream_t s) {
-  if (count < 1 || count > 3 || (dense_lo & 3) || (dense_hi & 3) || (wc2_off & 3) || (c2 & 3)) return -3;
+  if (count < 1 || count > 3 || (dense_lo & 3) || (dense_hi & 3) || (wc2_off & 3)) return -3;
+  if (wc2T && ((c1 % 32) || (c2 % 32))) return -3;
   FusedSgdArgs a;
   int blocks = 0;
   for (int k = 0; k < 3; ++k) {

@@ -116,7 +116,7 @@ static int backward_conv_impl(const DtfEngineDesc* e, const void* images, const 
   }
   DTF_TRY(dtf_conv2_wgrad(e->p1, e->dflat, e->arg2, e->p2, e->c2_part, e->B, e->c1, e->c2, e->c2_g, s2));
   if (e->multi_stream) HIP_TRY(hipEventRecord(e->ev_join2, s2));
-  DTF_TRY(dtf_conv2_dgrad(e->dflat, e->arg2, e->p2, bf16at(e->shadow, e->off_wc2), e->dp1, e->B, e->c1, e->c2, s));
+  DTF_TRY(dtf_conv2_dgrad(e->dflat, e->arg2, e->p2, bf16at(e->wc2T, 25L * e->c1 * e->c2), e->dp1, e->B, e->c1, e->c2, s));
   DTF_TRY(dtf_conv1_wgrad(images, idx, e->dp1, e->arg1, e->p1, e->c1_part, e->B, e->c1, e->c1_g, s));
   if (e->multi_stream) HIP_TRY(hipStreamWaitEvent(s, e->ev_join2, 0));
   if (!reduce) return 0;
@@ -160,9 +160,10 @@ int dtf_engine_update_range(const DtfEngineDesc* e, long lo, long hi, int advanc
                          bf16at(e->shadow, lo), e->hyper, n, e->state, adam_slot, st, cinc, step_inc, 1, s);
 }
 
-// only wc2 still needs a K-contiguous copy (100 KB); wd1 is used in place by both fc1 GEMMs
+// only wc2 needs a derived copy: its two fragment-ordered packs (2 x 100 KB, conv2.hip); wd1 is
+// used in place by both fc1 GEMMs
 int dtf_engine_transposes(const DtfEngineDesc* e, int wc2, hipStream_t s) {
-  if (wc2) DTF_TRY(dtf_transpose_bf16(bf16at(e->shadow, e->off_wc2), e->wc2T, 25, e->c1, e->c2, s));
+  if (wc2) DTF_TRY(dtf_conv2_pack_weights(bf16at(e->shadow, e->off_wc2), e->wc2T, e->c1, e->c2, s));
   return 0;
 }
 

@@ -104,7 +104,7 @@ class HipEngine:
         self.params = torch.zeros(n, **f32)
         self.grads = torch.zeros(n, **f32)
         self.shadow = torch.zeros(n, **bf)
-        self.wc2T = torch.zeros((25, C2, C1), **bf)
+        self.wc2T = torch.zeros((2, 25 * C1 * C2), **bf)   # [fwd pack | dgrad pack] of wc2 (csrc/kernels/conv2.hip)
         if optimizer == "adam":
             self.adam_m = torch.zeros(n, **f32)
             self.adam_v = torch.zeros(n, **f32)

@@ -75,3 +75,13 @@ def pool_argmax(x_nhwc: torch.Tensor):
     # torch.max returns the first maximal index on CPU; enforce it explicitly for ties
     first = (win == pooled.unsqueeze(-1)).float().argmax(dim=-1)
     return pooled, first.to(torch.uint8)
+
+
+def conv2_pack_reference(w):
+    """Fragment-ordered packs of a [25, cin, cout] (HWIO) conv2 weight, as csrc/kernels/conv2.hip
+    (pack_conv2_weights) lays them out: returns (fwd_pack, dgrad_pack), each flat with 25*cin*cout
+    elements.  fwd: [tap][ci/32][co/16][(ci%32)/8][co%16][ci%8]; dgrad: [tap][co/32][ci/16][(co%32)/8][ci%16][co%8]."""
+    t, cin, cout = w.shape
+    f = w.reshape(t, cin // 32, 4, 8, cout // 16, 16).permute(0, 1, 4, 2, 5, 3).contiguous().reshape(-1)
+    d = w.reshape(t, cin // 16, 16, cout // 32, 4, 8).permute(0, 3, 1, 4, 2, 5).contiguous().reshape(-1)
+    return f, d

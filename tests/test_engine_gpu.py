@@ -57,7 +57,9 @@ def test_step_matches_oracle(gpu_lib, dataset, B):
     # bf16 shadows/transposes follow the master weights
     assert torch.equal(eng.shadow, eng.params.to(torch.bfloat16))
     wc2 = eng.pview("wc2").reshape(25, spec.c1, spec.c2)
-    assert torch.equal(eng.wc2T, wc2.to(torch.bfloat16).transpose(1, 2).contiguous())
+    from distributed_tensorflow_amd.ops.reference import conv2_pack_reference
+    f_ref, d_ref = conv2_pack_reference(wc2.to(torch.bfloat16))
+    assert torch.equal(eng.wc2T[0], f_ref) and torch.equal(eng.wc2T[1], d_ref)
 
 
 def test_training_converges_and_graph_replay(gpu_lib, dataset):

@@ -152,7 +152,11 @@ def _conv2_inputs(B, C1, C2, seed):
 @pytest.mark.parametrize("B,C1,C2", [(1, 32, 64), (5, 32, 64), (64, 32, 64), (3, 128, 256)])
 def test_conv2_fwd(gpu_lib, B, C1, C2):
     g, x, w, b = _conv2_inputs(B, C1, C2, 3)
-    wT = w.reshape(25, C1, C2).transpose(1, 2).contiguous()
+    packed = torch.empty(2, 25 * C1 * C2, dtype=torch.bfloat16, device=DEV)
+    check(gpu_lib.dtf_conv2_pack_weights(ptr(w), ptr(packed), C1, C2, stream()), "pack")
+    f_ref, d_ref = R.conv2_pack_reference(w.reshape(25, C1, C2))
+    assert torch.equal(packed[0], f_ref) and torch.equal(packed[1], d_ref)
+    wT = packed[0]
     pooled = torch.empty(B, 7, 7, C2, dtype=torch.bfloat16, device=DEV)
     arg = torch.empty(B, 7, 7, C2, dtype=torch.uint8, device=DEV)
     check(gpu_lib.dtf_conv2_fwd(ptr(x), ptr(wT), ptr(b), ptr(pooled), ptr(arg), B, C1, C2, stream()), "conv2_fwd")
@@ -177,7 +181,9 @@ def test_conv2_backward(gpu_lib, B, C1, C2):
     arg = arg.contiguous()
     # dgrad
     dx = torch.empty(B, 14, 14, C1, dtype=torch.bfloat16, device=DEV)
-    check(gpu_lib.dtf_conv2_dgrad(ptr(gp), ptr(arg), ptr(pooled_bf), ptr(w), ptr(dx), B, C1, C2, stream()),
+    packed = torch.empty(2, 25 * C1 * C2, dtype=torch.bfloat16, device=DEV)
+    check(gpu_lib.dtf_conv2_pack_weights(ptr(w), ptr(packed), C1, C2, stream()), "pack")
+    check(gpu_lib.dtf_conv2_dgrad(ptr(gp), ptr(arg), ptr(pooled_bf), ptr(packed[1]), ptr(dx), B, C1, C2, stream()),
           "conv2_dgrad")
     assert rel_err(dx, xf.grad) < 8e-3
     # wgrad
@@ -333,7 +339,7 @@ def test_reduce_segments(gpu_lib):
 
 def test_fused_reduce_sgd(gpu_lib):
     """One launch == reduce_segments + sgd_update + wc2 transpose, bitwise."""
-    c1, c2 = 8, 12
+    c1, c2 = 32, 64
     n_head, n_dense, n_c2, n_c1 = 76, 1000, 25 * c1 * c2 + c2, 40
     offs = [0, n_head, n_head + n_dense, n_head + n_dense + n_c2]
     total = offs[3] + n_c1
@@ -353,7 +359,7 @@ def test_fused_reduce_sgd(gpu_lib):
     # fused path
     w1, g1 = w0.clone(), grads.clone()
     sh1 = torch.zeros(total, dtype=torch.bfloat16, device=DEV)
-    wT = torch.zeros(25, c2, c1, dtype=torch.bfloat16, device=DEV)
+    wT = torch.zeros(2, 25 * c1 * c2, dtype=torch.bfloat16, device=DEV)
     state = torch.zeros(8, dtype=torch.int64, device=DEV)
     pa = (ctypes.c_void_p * 3)(*[p.data_ptr() for p in parts])
     check(gpu_lib.dtf_fused_reduce_sgd(3, pa, (ctypes.c_int * 3)(5, 33, 7), (ctypes.c_int * 3)(n_head, n_c2, n_c1),
@@ -361,8 +367,8 @@ def test_fused_reduce_sgd(gpu_lib):
                                        ptr(w1), ptr(g1), ptr(sh1), ptr(hyper), offs[1], offs[2], ptr(wT), offs[2], c1, c2,
                                        ptr(state), 100, 1, 1, stream()), "fused")
     assert torch.equal(g1, g_ref) and torch.equal(w1, w_ref) and torch.equal(sh1, sh_ref)
-    want_T = sh_ref[offs[2]:offs[2] + 25 * c1 * c2].reshape(25, c1, c2).transpose(1, 2).contiguous()
-    assert torch.equal(wT, want_T)
+    f_ref, d_ref = R.conv2_pack_reference(sh_ref[offs[2]:offs[2] + 25 * c1 * c2].reshape(25, c1, c2))
+    assert torch.equal(wT[0], f_ref) and torch.equal(wT[1], d_ref)
     assert state.tolist()[:3] == [100, 1, 1]
 
 
