@@ -9,14 +9,14 @@ int dtf_conv1_fwd(const void* images, const void* idx, const void* w, const void
 int dtf_conv1_fwd_sampled(const void* images, void* idx_out, const void* state, unsigned n, unsigned hb,
                           unsigned seed, int shuffle, const void* w, const void* bias, void* pooled, void* arg,
                           int B, int cout, int grid, hipStream_t s);
-int dtf_conv1_wgrad(const void* images, const void* idx, const void* gpool, const void* arg, const void* pooled,
+int dtf_conv1_wgrad(const void* images, const void* idx, const void* gpool, const void* arg,
                     void* part, int B, int cout, int grid, hipStream_t s);
 int dtf_conv2_pack_weights(const void* w, void* packed, int cin, int cout, hipStream_t s);
 int dtf_conv2_fwd(const void* x, const void* wT, const void* bias, void* pooled, void* arg, int B, int cin, int cout,
                   hipStream_t s);
-int dtf_conv2_dgrad(const void* gpool, const void* arg, const void* pooled, const void* w, void* dx, int B, int cin,
+int dtf_conv2_dgrad(const void* gpool, const void* arg, const void* w, void* dx, int B, int cin,
                     int cout, hipStream_t s);
-int dtf_conv2_wgrad(const void* x, const void* gpool, const void* arg, const void* pooled, void* part, int B, int cin,
+int dtf_conv2_wgrad(const void* x, const void* gpool, const void* arg, void* part, int B, int cin,
                     int cout, int G, hipStream_t s);
 int dtf_gemm_nt(const void* A, const void* B, void* C, const void* bias, int M, int N, int K, int lda, int ldb,
                 int ldc, int epi, float keep_prob, uint64_t seed, const void* state, int tile, hipStream_t s);

@@ -89,6 +89,28 @@ __host__ __device__ __forceinline__ uint32_t feistel_permute(uint32_t i, uint32_
   return i;
 }
 
+// ---------------------------------------------------------------------------
+// Max-pool + ReLU gradient routing.  The forward kernels store, per pooled element, the 2x2
+// argmax q in 0..3 -- or kPoolDead when the pooled activation is not positive -- so backward
+// needs the u8 code only (no re-read of the pooled tensor).  expand_pool_grad turns 8 pooled
+// gradients (4 dwords of bf16 pairs) + 8 codes into the 4 window positions: o[q] = g where
+// code == q, else 0.  Pure 32-bit integer ops on packed pairs.
+// ---------------------------------------------------------------------------
+constexpr unsigned kPoolDead = 4;
+
+__device__ __forceinline__ void expand_pool_grad(const u32x4& g, const u32x2& a, u32x4 (&o)[4]) {
+#pragma unroll
+  for (int d = 0; d < 4; ++d) {
+    const unsigned ab = (d < 2 ? a[0] : a[1]) >> ((d & 1) * 16);
+    const unsigned a0 = ab & 0xffu, a1 = (ab >> 8) & 0xffu;
+#pragma unroll
+    for (unsigned q = 0; q < 4; ++q) {
+      const unsigned m = (a0 == q ? 0x0000ffffu : 0u) | (a1 == q ? 0xffff0000u : 0u);
+      o[q][d] = g[d] & m;
+    }
+  }
+}
+
 // Wave-level sum across all 64 lanes.
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll

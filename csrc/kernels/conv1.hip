@@ -135,8 +135,9 @@ __global__ __launch_bounds__(256) void conv1_pool_fwd(const bf16* __restrict__ i
           if (v2 > best) { best = v2; bi = 2; }
           if (v3 > best) { best = v3; bi = 3; }
           const int px = 4 * g + r;
-          orow[wave][px * 32 + nt * 16 + i16] = (bf16)fmaxf(best + bv[nt], 0.f);
-          arow[wave][px * 32 + nt * 16 + i16] = (uint8_t)bi;
+          const float o = fmaxf(best + bv[nt], 0.f);
+          orow[wave][px * 32 + nt * 16 + i16] = (bf16)o;
+          arow[wave][px * 32 + nt * 16 + i16] = (uint8_t)(o > 0.f ? bi : (int)kPoolDead);
         }
       __builtin_amdgcn_wave_barrier();
       // 14 px x 32 ch: 896 B of bf16 = 56 x 16 B, 448 B of argmax = 28 x 16 B
@@ -183,7 +184,6 @@ __global__ __launch_bounds__(256) void conv1_wgrad(const bf16* __restrict__ imag
                                                    const int* __restrict__ idx,
                                                    const bf16* __restrict__ gpool,
                                                    const uint8_t* __restrict__ arg,
-                                                   const bf16* __restrict__ pooled,
                                                    float* __restrict__ part, int B) {
   typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
   typedef __attribute__((ext_vector_type(8))) short s16x8;
@@ -230,22 +230,15 @@ __global__ __launch_bounds__(256) void conv1_wgrad(const bf16* __restrict__ imag
       int c8 = c & 3, pp = c >> 2;
       int py = pp / 14, px = pp % 14;
       size_t off = ((size_t)b * 196 + pp) * C + cchunk * 32 + c8 * 8;
-      bf16x8 gv = *reinterpret_cast<const bf16x8*>(gpool + off);
-      bf16x8 pv = *reinterpret_cast<const bf16x8*>(pooled + off);
+      u32x4 gv = *reinterpret_cast<const u32x4*>(gpool + off);
       u32x2 a2 = *reinterpret_cast<const u32x2*>(arg + off);
-      bf16x8 o[4];
-#pragma unroll
-      for (int e = 0; e < 8; ++e) {
-        unsigned a = ((e < 4 ? a2[0] : a2[1]) >> ((e & 3) * 8)) & 0xffu;
-        bool live = (float)pv[e] > 0.f;
-#pragma unroll
-        for (int q = 0; q < 4; ++q) o[q][e] = (live && a == (unsigned)q) ? gv[e] : (bf16)0.f;
-      }
+      u32x4 o[4];
+      expand_pool_grad(gv, a2, o);
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
         int y = 2 * py + (q >> 1), x = 2 * px + (q & 1);
         int slot = (((c8 >> 1) ^ ((x >> 3) & 1)) << 1) | (c8 & 1);
-        *reinterpret_cast<bf16x8*>(dyt + (y * 32 + x) * 32 + slot * 8) = o[q];
+        *reinterpret_cast<u32x4*>(dyt + (y * 32 + x) * 32 + slot * 8) = o[q];
       }
     }
     __syncthreads();
@@ -336,8 +329,7 @@ int dtf_conv1_fwd_sampled(const void* images, void* idx_out, const void* state, 
 }
 
 // part must hold grid * 26 * cout floats
-int dtf_conv1_wgrad(const void* images, const void* idx, const void* gpool, const void* arg,
-                    const void* pooled, void* part, int B, int cout, int grid, hipStream_t s) {
+int dtf_conv1_wgrad(const void* images, const void* idx, const void* gpool, const void* arg, void* part, int B, int cout, int grid, hipStream_t s) {
   if (grid <= 0) return -2;
   constexpr int lds = kCpBytes + kDy1Bytes;
   static bool attr_set = false;
@@ -348,10 +340,10 @@ int dtf_conv1_wgrad(const void* images, const void* idx, const void* gpool, cons
   }
   if (cout == 32)
     hipLaunchKernelGGL((conv1_wgrad<32>), dim3(grid, 1), dim3(256), lds, s, (const bf16*)images, (const int*)idx,
-                       (const bf16*)gpool, (const uint8_t*)arg, (const bf16*)pooled, (float*)part, B);
+                       (const bf16*)gpool, (const uint8_t*)arg, (float*)part, B);
   else if (cout == 128)
     hipLaunchKernelGGL((conv1_wgrad<128>), dim3(grid, 4), dim3(256), lds, s, (const bf16*)images, (const int*)idx,
-                       (const bf16*)gpool, (const uint8_t*)arg, (const bf16*)pooled, (float*)part, B);
+                       (const bf16*)gpool, (const uint8_t*)arg, (float*)part, B);
   else
     return -1;
   return (int)hipGetLastError();

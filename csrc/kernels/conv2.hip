@@ -53,7 +53,7 @@ enum { MODE_FWD = 0, MODE_DGRAD = 1 };
 // Forward / dgrad
 //   in   MODE_FWD  : x    [B,14,14,KC] bf16
 //        MODE_DGRAD: gpool[B,7,7,KC] bf16 (gradient wrt the pooled output),
-//                    arg  [B,7,7,KC] u8, pooled [B,7,7,KC] bf16 (fwd output)
+//                    arg  [B,7,7,KC] u8 argmax code (kPoolDead where the pooled activation is 0)
 //   wk   fragment-ordered ("packed") weights, see pack_conv2_weights: one contiguous 1 KiB block
 //        per (tap, 32-wide k block, 16-wide n tile), lane l's 8 k-values at l*16 bytes, so a B
 //        fragment load is one fully coalesced 1 KiB read.  (From a plain [n][k] matrix the same
@@ -69,8 +69,7 @@ constexpr int igemm_tile_pos(int kc) { return kc == 32 ? 18 * 20 : kTilePos; }
 
 template <int KTOT, int KC, int NC, int IMGS, int NW, int MODE, int MINW>
 __global__ __launch_bounds__(IMGS * 2 * NW * 64, MINW) void conv5x5_igemm(
-    const bf16* __restrict__ in, const uint8_t* __restrict__ in_arg,
-    const bf16* __restrict__ in_pooled, const bf16* __restrict__ wk,
+    const bf16* __restrict__ in, const uint8_t* __restrict__ in_arg, const bf16* __restrict__ wk,
     const float* __restrict__ bias, bf16* __restrict__ out, uint8_t* __restrict__ out_arg,
     int B) {
   constexpr int NTHREADS = IMGS * 2 * NW * 64;
@@ -154,22 +153,15 @@ __global__ __launch_bounds__(IMGS * 2 * NW * 64, MINW) void conv5x5_igemm(
       int b = img0 + im;
       if (b < B && !(DTF_ABLATE & 8)) {
         size_t off = ((size_t)b * 49 + pp) * KTOT + kc0 + ch * 8;
-        bf16x8 gq = *reinterpret_cast<const bf16x8*>(in + off);
-        bf16x8 p = *reinterpret_cast<const bf16x8*>(in_pooled + off);
+        u32x4 gq = *reinterpret_cast<const u32x4*>(in + off);
         u32x2 a2 = *reinterpret_cast<const u32x2*>(in_arg + off);
         int py = pp / 7, px = pp % 7;
-        bf16x8 o[4];
-#pragma unroll
-        for (int e = 0; e < 8; ++e) {
-          unsigned a = ((e < 4 ? a2[0] : a2[1]) >> ((e & 3) * 8)) & 0xffu;
-          bool live = (float)p[e] > 0.f;
-#pragma unroll
-          for (int qq = 0; qq < 4; ++qq) o[qq][e] = (live && a == (unsigned)qq) ? gq[e] : (bf16)0.f;
-        }
+        u32x4 o[4];
+        expand_pool_grad(gq, a2, o);
 #pragma unroll
         for (int qq = 0; qq < 4; ++qq) {
           int tp = (2 * py + (qq >> 1) + 2) * TW + (2 * px + (qq & 1) + 2);
-          *reinterpret_cast<bf16x8*>(tile + ((size_t)im * TPOS + tp) * KP + (SWZ ? (ch ^ ((tp >> 1) & 3)) : ch) * 8) = o[qq];
+          *reinterpret_cast<u32x4*>(tile + ((size_t)im * TPOS + tp) * KP + (SWZ ? (ch ^ ((tp >> 1) & 3)) : ch) * 8) = o[qq];
         }
       }
     }
@@ -263,7 +255,7 @@ __global__ __launch_bounds__(IMGS * 2 * NW * 64, MINW) void conv5x5_igemm(
           float o = fmaxf(best + bv, 0.f);
           const int off = ((w_img * 7 + i) * 7 + ewin) * NC + n;
           ot[off] = (bf16)o;
-          oa[off] = (uint8_t)bi;
+          oa[off] = (uint8_t)(o > 0.f ? bi : (int)kPoolDead);
         }
       }
     }
@@ -331,8 +323,7 @@ __global__ __launch_bounds__(256) void pack_conv2_weights(const bf16* __restrict
 // wgrad.  grid = (G image chunks, (C_IN/16) * (C_OUT/32) output tiles)
 //   x      [B,14,14,C_IN] bf16   layer input
 //   gpool  [B,7,7,C_OUT]  bf16   gradient wrt pooled output
-//   arg    [B,7,7,C_OUT]  u8     saved argmax
-//   pooled [B,7,7,C_OUT]  bf16   forward pooled output (ReLU mask = pooled > 0)
+//   arg    [B,7,7,C_OUT]  u8     saved argmax code (kPoolDead where the pooled activation is 0)
 //   part   [G][25*C_IN*C_OUT + C_OUT] fp32 partial slabs (HWIO order, then bias)
 // A block owns ALL 25 taps of a 16(ci) x 32(co) output tile, so the two LDS images it stages per
 // image -- the halo-padded input [pos][16 ci] and the max-pool/ReLU-expanded output gradient
@@ -354,8 +345,7 @@ constexpr int kWgRedBytes = 4 * 58 * 64 * 4;       // 59392: end-of-kernel reduc
 template <int C_IN, int C_OUT>
 __global__ __launch_bounds__(512, 2) void conv5x5_wgrad(
     const bf16* __restrict__ x, const bf16* __restrict__ gpool,
-    const uint8_t* __restrict__ arg, const bf16* __restrict__ pooled,
-    float* __restrict__ part, int B, int imgs_per_block) {
+    const uint8_t* __restrict__ arg, float* __restrict__ part, int B, int imgs_per_block) {
   constexpr int CI_T = C_IN / 16;
   typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
   typedef __attribute__((ext_vector_type(8))) short s16x8;
@@ -406,15 +396,14 @@ __global__ __launch_bounds__(512, 2) void conv5x5_wgrad(
   const int x_tp = (x_pos / 14 + 2) * kTileW + (x_pos % 14 + 2);
   const int d_c8 = tid & 3, d_pp = tid >> 2;
   u32x4 xr = {0u, 0u, 0u, 0u};
-  bf16x8 gv_r, pv_r;
+  u32x4 gv_r = {0u, 0u, 0u, 0u};
   u32x2 ar_r = {0u, 0u};
   auto prefetch = [&](int b) {
     if (has_x && !(DTF_ABLATE & 32))
       xr = *reinterpret_cast<const u32x4*>(x + ((size_t)b * 196 + x_pos) * C_IN + ci_t * 16 + x_ch * 8);
     if (has_dy && !(DTF_ABLATE & 128)) {
       size_t off = ((size_t)b * 49 + d_pp) * C_OUT + co_t * 32 + d_c8 * 8;
-      gv_r = *reinterpret_cast<const bf16x8*>(gpool + off);
-      pv_r = *reinterpret_cast<const bf16x8*>(pooled + off);
+      gv_r = *reinterpret_cast<const u32x4*>(gpool + off);
       ar_r = *reinterpret_cast<const u32x2*>(arg + off);
     }
   };
@@ -422,19 +411,13 @@ __global__ __launch_bounds__(512, 2) void conv5x5_wgrad(
     if (has_x && !(DTF_ABLATE & 32)) *reinterpret_cast<u32x4*>(xt + boff + x_tp * 16 + x_ch * 8) = xr;
     if (has_dy && !(DTF_ABLATE & 128)) {
       const int r = d_pp / 7, w = d_pp % 7;
-      bf16x8 o[4];
-#pragma unroll
-      for (int e = 0; e < 8; ++e) {
-        unsigned a = ((e < 4 ? ar_r[0] : ar_r[1]) >> ((e & 3) * 8)) & 0xffu;
-        bool live = (float)pv_r[e] > 0.f;
-#pragma unroll
-        for (int q = 0; q < 4; ++q) o[q][e] = (live && a == (unsigned)q) ? gv_r[e] : (bf16)0.f;
-      }
+      u32x4 o[4];
+      expand_pool_grad(gv_r, ar_r, o);
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
         int kk = (q >> 1) * 16 + 2 * w + (q & 1);
         int slot = (((d_c8 >> 1) ^ ((kk >> 2) & 1)) << 1) | (d_c8 & 1);
-        *reinterpret_cast<bf16x8*>(dyt + boff + (r * 32 + kk) * 32 + slot * 8) = o[q];
+        *reinterpret_cast<u32x4*>(dyt + boff + (r * 32 + kk) * 32 + slot * 8) = o[q];
       }
     }
   };
@@ -569,7 +552,7 @@ using namespace dtf;
 #define DTF_LAUNCH_CHECK() (int)hipGetLastError()
 
 template <int KTOT, int KC, int NC, int IMGS, int NW, int MODE, int MINW = 1>
-static int launch_igemm(const void* in, const void* in_arg, const void* in_pooled, const void* wk,
+static int launch_igemm(const void* in, const void* in_arg, const void* wk,
                         const void* bias, void* out, void* out_arg, int B, hipStream_t s) {
   constexpr int threads = IMGS * 2 * NW * 64;
   constexpr int KP = (KC % 64 == 0) ? KC + 8 : KC;
@@ -582,7 +565,7 @@ static int launch_igemm(const void* in, const void* in_arg, const void* in_poole
   }
   int grid = (B + IMGS - 1) / IMGS;
   hipLaunchKernelGGL(kern, dim3(grid), dim3(threads), lds, s, (const bf16*)in, (const uint8_t*)in_arg,
-                     (const bf16*)in_pooled, (const bf16*)wk, (const float*)bias, (bf16*)out,
+                     (const bf16*)wk, (const float*)bias, (bf16*)out,
                      (uint8_t*)out_arg, B);
   return DTF_LAUNCH_CHECK();
 }
@@ -601,35 +584,35 @@ int dtf_conv2_pack_weights(const void* w, void* packed, int cin, int cout, hipSt
 int dtf_conv2_fwd(const void* x, const void* wT, const void* bias, void* pooled, void* arg, int B,
                   int cin, int cout, hipStream_t s) {
   if (cin == 32 && cout == 64)
-    return launch_igemm<DTF_FWD_CFG>(x, nullptr, nullptr, wT, bias, pooled, arg, B, s);
+    return launch_igemm<DTF_FWD_CFG>(x, nullptr, wT, bias, pooled, arg, B, s);
   if (cin == 128 && cout == 256)
-    return launch_igemm<128, 128, 256, 1, 4, MODE_FWD>(x, nullptr, nullptr, wT, bias, pooled, arg, B, s);
+    return launch_igemm<128, 128, 256, 1, 4, MODE_FWD>(x, nullptr, wT, bias, pooled, arg, B, s);
   return -1;
 }
 
-// dgrad: gpool[B,7,7,cout] (+arg, pooled) -> dx[B,14,14,cin]; w = dgrad pack (second half of dtf_conv2_pack_weights)
-int dtf_conv2_dgrad(const void* gpool, const void* arg, const void* pooled, const void* w, void* dx,
+// dgrad: gpool[B,7,7,cout] (+arg code) -> dx[B,14,14,cin]; w = dgrad pack (second half of dtf_conv2_pack_weights)
+int dtf_conv2_dgrad(const void* gpool, const void* arg, const void* w, void* dx,
                     int B, int cin, int cout, hipStream_t s) {
   if (cin == 32 && cout == 64)
-    return launch_igemm<DTF_DGRAD_CFG>(gpool, arg, pooled, w, nullptr, dx, nullptr, B, s);
+    return launch_igemm<DTF_DGRAD_CFG>(gpool, arg, w, nullptr, dx, nullptr, B, s);
   if (cin == 128 && cout == 256)
-    return launch_igemm<256, 128, 128, 1, 2, MODE_DGRAD>(gpool, arg, pooled, w, nullptr, dx, nullptr, B, s);
+    return launch_igemm<256, 128, 128, 1, 2, MODE_DGRAD>(gpool, arg, w, nullptr, dx, nullptr, B, s);
   return -1;
 }
 
 // wgrad partial slabs: part [G][25*cin*cout + cout]
-int dtf_conv2_wgrad(const void* x, const void* gpool, const void* arg, const void* pooled, void* part,
+int dtf_conv2_wgrad(const void* x, const void* gpool, const void* arg, void* part,
                     int B, int cin, int cout, int G, hipStream_t s) {
   if (G <= 0) return -2;
   int ipb = (B + G - 1) / G;
   if (cin == 32 && cout == 64) {
     hipLaunchKernelGGL((conv5x5_wgrad<32, 64>), dim3(G, 4), dim3(512), 0, s, (const bf16*)x,
-                       (const bf16*)gpool, (const uint8_t*)arg, (const bf16*)pooled, (float*)part, B, ipb);
+                       (const bf16*)gpool, (const uint8_t*)arg, (float*)part, B, ipb);
     return DTF_LAUNCH_CHECK();
   }
   if (cin == 128 && cout == 256) {
     hipLaunchKernelGGL((conv5x5_wgrad<128, 256>), dim3(G, 64), dim3(512), 0, s, (const bf16*)x,
-                       (const bf16*)gpool, (const uint8_t*)arg, (const bf16*)pooled, (float*)part, B, ipb);
+                       (const bf16*)gpool, (const uint8_t*)arg, (float*)part, B, ipb);
     return DTF_LAUNCH_CHECK();
   }
   return -1;

@@ -114,10 +114,10 @@ static int backward_conv_impl(const DtfEngineDesc* e, const void* images, const 
     HIP_TRY(hipStreamWaitEvent(e->side2, e->ev_fork, 0));
     s2 = e->side2;
   }
-  DTF_TRY(dtf_conv2_wgrad(e->p1, e->dflat, e->arg2, e->p2, e->c2_part, e->B, e->c1, e->c2, e->c2_g, s2));
+  DTF_TRY(dtf_conv2_wgrad(e->p1, e->dflat, e->arg2, e->c2_part, e->B, e->c1, e->c2, e->c2_g, s2));
   if (e->multi_stream) HIP_TRY(hipEventRecord(e->ev_join2, s2));
-  DTF_TRY(dtf_conv2_dgrad(e->dflat, e->arg2, e->p2, bf16at(e->wc2T, 25L * e->c1 * e->c2), e->dp1, e->B, e->c1, e->c2, s));
-  DTF_TRY(dtf_conv1_wgrad(images, idx, e->dp1, e->arg1, e->p1, e->c1_part, e->B, e->c1, e->c1_g, s));
+  DTF_TRY(dtf_conv2_dgrad(e->dflat, e->arg2, bf16at(e->wc2T, 25L * e->c1 * e->c2), e->dp1, e->B, e->c1, e->c2, s));
+  DTF_TRY(dtf_conv1_wgrad(images, idx, e->dp1, e->arg1, e->c1_part, e->B, e->c1, e->c1_g, s));
   if (e->multi_stream) HIP_TRY(hipStreamWaitEvent(s, e->ev_join2, 0));
   if (!reduce) return 0;
   const void* part[2] = {e->c2_part, e->c1_part};

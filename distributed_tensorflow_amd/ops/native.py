@@ -29,11 +29,11 @@ _SIGS = {
     "dtf_conv1_fwd": [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p],
     "dtf_conv1_fwd_sampled": [c_void_p, c_void_p, c_void_p, c_uint, c_uint, c_uint, c_int, c_void_p, c_void_p, c_void_p,
                               c_void_p, c_int, c_int, c_int, c_void_p],
-    "dtf_conv1_wgrad": [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p],
+    "dtf_conv1_wgrad": [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p],
     "dtf_conv2_pack_weights": [c_void_p, c_void_p, c_int, c_int, c_void_p],
     "dtf_conv2_fwd": [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p],
-    "dtf_conv2_dgrad": [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p],
-    "dtf_conv2_wgrad": [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p],
+    "dtf_conv2_dgrad": [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p],
+    "dtf_conv2_wgrad": [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p],
     "dtf_gemm_nt": [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_int,
                     c_float, c_uint64, c_void_p, c_int, c_void_p],
     "dtf_gemm_tn": [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p],

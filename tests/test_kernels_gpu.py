@@ -38,6 +38,11 @@ def conv_block_ref(x_nhwc, w_hwio, b):
 
 
 # ------------------------------------------------------------------ data path
+def dead_code(arg, pooled):
+    """argmax code as the forward kernels store it: 4 (kPoolDead) where the pooled activation is not positive."""
+    return torch.where(bf(pooled) > 0, arg, torch.full_like(arg, 4)).contiguous()
+
+
 def test_sample_indices_match_host(gpu_lib):
     n, B, seed = 55000, 300, 77
     state = torch.zeros(8, dtype=torch.int64, device=DEV)
@@ -94,6 +99,7 @@ def test_conv1_fwd(gpu_lib, B, C):
     live = ref > 1e-3
     agree = (arg == ref_arg)[live].float().mean()
     assert agree > 0.995, agree
+    assert bool(((arg == 4) == (pooled.float() <= 0)).all())   # ReLU-dead windows carry the dead code
 
 
 def test_conv1_fwd_fused_sampler(gpu_lib):
@@ -133,8 +139,8 @@ def test_conv1_wgrad(gpu_lib, B, C):
     pooled, arg = conv_block_ref(x, w.detach(), b.detach())
     G = 7
     part = torch.empty(G, 26 * C, device=DEV)
-    check(gpu_lib.dtf_conv1_wgrad(ptr(images), None, ptr(gp), ptr(arg.contiguous()), ptr(bf(pooled).contiguous()),
-                                  ptr(part), B, C, G, stream()), "conv1_wgrad")
+    code = dead_code(arg, pooled)
+    check(gpu_lib.dtf_conv1_wgrad(ptr(images), None, ptr(gp), ptr(code), ptr(part), B, C, G, stream()), "conv1_wgrad")
     got = part.sum(0)
     assert rel_err(got[:25 * C].reshape(5, 5, 1, C), w.grad) < 2e-3
     assert rel_err(got[25 * C:], b.grad) < 2e-3
@@ -165,6 +171,7 @@ def test_conv2_fwd(gpu_lib, B, C1, C2):
     live = ref > 1e-2
     agree = (arg == ref_arg)[live].float().mean()
     assert agree > 0.99, agree
+    assert bool(((arg == 4) == (pooled.float() <= 0)).all())
 
 
 @pytest.mark.parametrize("B,C1,C2", [(1, 32, 64), (5, 32, 64), (32, 32, 64), (3, 128, 256)])
@@ -177,20 +184,19 @@ def test_conv2_backward(gpu_lib, B, C1, C2):
     gp = bf(torch.randn(y.shape, generator=g)).to(DEV)
     y.backward(gp.float())
     pooled, arg = conv_block_ref(x, w, b)
-    pooled_bf = bf(pooled).contiguous()
-    arg = arg.contiguous()
+    arg = dead_code(arg, pooled)
     # dgrad
     dx = torch.empty(B, 14, 14, C1, dtype=torch.bfloat16, device=DEV)
     packed = torch.empty(2, 25 * C1 * C2, dtype=torch.bfloat16, device=DEV)
     check(gpu_lib.dtf_conv2_pack_weights(ptr(w), ptr(packed), C1, C2, stream()), "pack")
-    check(gpu_lib.dtf_conv2_dgrad(ptr(gp), ptr(arg), ptr(pooled_bf), ptr(packed[1]), ptr(dx), B, C1, C2, stream()),
+    check(gpu_lib.dtf_conv2_dgrad(ptr(gp), ptr(arg), ptr(packed[1]), ptr(dx), B, C1, C2, stream()),
           "conv2_dgrad")
     assert rel_err(dx, xf.grad) < 8e-3
     # wgrad
     G = 3
     stride = 25 * C1 * C2 + C2
     part = torch.zeros(G, stride, device=DEV)
-    check(gpu_lib.dtf_conv2_wgrad(ptr(x), ptr(gp), ptr(arg), ptr(pooled_bf), ptr(part), B, C1, C2, G, stream()),
+    check(gpu_lib.dtf_conv2_wgrad(ptr(x), ptr(gp), ptr(arg), ptr(part), B, C1, C2, G, stream()),
           "conv2_wgrad")
     got = part.sum(0)
     assert rel_err(got[:25 * C1 * C2].reshape(5, 5, C1, C2), wf.grad) < 3e-3
