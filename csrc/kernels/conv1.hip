@@ -216,32 +216,73 @@ __global__ __launch_bounds__(256) void conv1_wgrad(const bf16* __restrict__ imag
   for (int i = tid; i < (kCpBytes + kDy1Bytes) / 16; i += 256)
     reinterpret_cast<u32x4*>(smem)[i] = (u32x4){0u, 0u, 0u, 0u};
 
-  for (int b = blockIdx.x; b < B; b += gridDim.x) {
-    __syncthreads();
+  // Staging.  Every global load of image b+1 (2 pixel pairs of the input, 4 x (8 gradients + 8
+  // argmax codes) of the pooled gradient per thread) is issued before the k-loop of image b and
+  // only consumed after it: the loop never waits on memory.  The five shifted input copies are
+  // written from the pixel pairs directly (an even shift keeps the pair dword-aligned, an odd one
+  // splits it into two 2-byte stores), not gathered pixel by pixel from global memory.
+  constexpr int DY_ROUNDS = (196 * 4 + 255) / 256;   // 4
+  unsigned px_r[2] = {0u, 0u};
+  u32x4 gv_r[DY_ROUNDS];
+  u32x2 ar_r[DY_ROUNDS];
+  auto prefetch = [&](int b) {
     const size_t row = idx ? (size_t)idx[b] : (size_t)b;
-    const bf16* src = images + row * 784;
-    for (int e = tid; e < 5 * 1024; e += 256) {
-      int s = e >> 10, r = (e >> 5) & 31, c = e & 31;
-      int y = r - 2, x = c + s - 2;
-      bf16 v = (y >= 0 && y < 28 && x >= 0 && x < 28) ? src[y * 28 + x] : (bf16)0.f;
-      cp[s * kCpStride + r * kCpPitch + c] = v;
-    }
-    for (int c = tid; c < 196 * 4; c += 256) {
-      int c8 = c & 3, pp = c >> 2;
-      int py = pp / 14, px = pp % 14;
-      size_t off = ((size_t)b * 196 + pp) * C + cchunk * 32 + c8 * 8;
-      u32x4 gv = *reinterpret_cast<const u32x4*>(gpool + off);
-      u32x2 a2 = *reinterpret_cast<const u32x2*>(arg + off);
-      u32x4 o[4];
-      expand_pool_grad(gv, a2, o);
+    const unsigned* src = reinterpret_cast<const unsigned*>(images + row * 784);
 #pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        int y = 2 * py + (q >> 1), x = 2 * px + (q & 1);
-        int slot = (((c8 >> 1) ^ ((x >> 3) & 1)) << 1) | (c8 & 1);
-        *reinterpret_cast<u32x4*>(dyt + (y * 32 + x) * 32 + slot * 8) = o[q];
+    for (int r = 0; r < 2; ++r) px_r[r] = src[min(tid + r * 256, 391)];
+#pragma unroll
+    for (int r = 0; r < DY_ROUNDS; ++r) {
+      const int c = min(tid + r * 256, 196 * 4 - 1);
+      const size_t off = ((size_t)b * 196 + (c >> 2)) * C + cchunk * 32 + (c & 3) * 8;
+      gv_r[r] = *reinterpret_cast<const u32x4*>(gpool + off);
+      ar_r[r] = *reinterpret_cast<const u32x2*>(arg + off);
+    }
+  };
+  auto stage = [&]() {
+#pragma unroll
+    for (int r = 0; r < 2; ++r) {
+      const int i = tid + r * 256;   // pixel pair (y, 2*x2), (y, 2*x2 + 1)
+      if (i < 392) {
+        const int y = i / 14, x = 2 * (i % 14);
+        const unsigned v = px_r[r];
+        bf16* rowp = cp + (y + 2) * kCpPitch;
+#pragma unroll
+        for (int sft = 0; sft < 5; ++sft) {
+          const int c = x - sft + 2;   // column of pixel x in copy sft (copy holds x = c + sft - 2)
+          bf16* dst = rowp + sft * kCpStride + c;
+          if ((sft & 1) == 0) {
+            if (c >= 0 && c < 31) *reinterpret_cast<unsigned*>(dst) = v;
+          } else {
+            if (c >= 0) reinterpret_cast<unsigned short*>(dst)[0] = (unsigned short)(v & 0xffffu);
+            if (c + 1 >= 0 && c + 1 < 32) reinterpret_cast<unsigned short*>(dst)[1] = (unsigned short)(v >> 16);
+          }
+        }
       }
     }
+#pragma unroll
+    for (int r = 0; r < DY_ROUNDS; ++r) {
+      const int c = tid + r * 256;
+      if (c < 196 * 4) {
+        const int c8 = c & 3, pp = c >> 2;
+        const int py = pp / 14, px = pp % 14;
+        u32x4 o[4];
+        expand_pool_grad(gv_r[r], ar_r[r], o);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          int y = 2 * py + (q >> 1), x = 2 * px + (q & 1);
+          int slot = (((c8 >> 1) ^ ((x >> 3) & 1)) << 1) | (c8 & 1);
+          *reinterpret_cast<u32x4*>(dyt + (y * 32 + x) * 32 + slot * 8) = o[q];
+        }
+      }
+    }
+  };
+
+  if ((int)blockIdx.x < B) prefetch(blockIdx.x);
+  for (int b = blockIdx.x; b < B; b += gridDim.x) {
+    __syncthreads();   // previous image consumed / zero fill done
+    stage();
     __syncthreads();
+    if (b + (int)gridDim.x < B) prefetch(b + gridDim.x);
     for (int kb = wave; kb < 28; kb += 4) {
       const int yrow = 2 * (kb >> 1) + (g >> 1);
       const int xb = (kb & 1) * 16 + 8 * (g & 1);
