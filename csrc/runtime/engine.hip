@@ -28,6 +28,7 @@ struct DtfEngineDesc {
   // native-owned handles (filled by dtf_engine_init)
   hipStream_t side1, side2;
   hipEvent_t ev_head, ev_fork, ev_join1, ev_join2, ev_dgrad;
+  hipEvent_t ev_dense_ready, ev_dense_updated, ev_tail_ready, ev_tail_reduced;  // data-parallel step
 };
 
 #define DTF_TRY(x)            \
@@ -47,13 +48,15 @@ static inline char* bf16at(void* base, long off) { return (char*)base + 2 * off;
 int dtf_engine_init(DtfEngineDesc* e) {
   HIP_TRY(hipStreamCreateWithFlags(&e->side1, hipStreamNonBlocking));
   HIP_TRY(hipStreamCreateWithFlags(&e->side2, hipStreamNonBlocking));
-  hipEvent_t* evs[5] = {&e->ev_head, &e->ev_fork, &e->ev_join1, &e->ev_join2, &e->ev_dgrad};
+  hipEvent_t* evs[9] = {&e->ev_head,        &e->ev_fork,          &e->ev_join1,      &e->ev_join2,       &e->ev_dgrad,
+                        &e->ev_dense_ready, &e->ev_dense_updated, &e->ev_tail_ready, &e->ev_tail_reduced};
   for (auto ev : evs) HIP_TRY(hipEventCreateWithFlags(ev, hipEventDisableTiming));
   return 0;
 }
 
 int dtf_engine_destroy(DtfEngineDesc* e) {
-  hipEvent_t evs[5] = {e->ev_head, e->ev_fork, e->ev_join1, e->ev_join2, e->ev_dgrad};
+  hipEvent_t evs[9] = {e->ev_head,        e->ev_fork,          e->ev_join1,      e->ev_join2,       e->ev_dgrad,
+                       e->ev_dense_ready, e->ev_dense_updated, e->ev_tail_ready, e->ev_tail_reduced};
   for (auto ev : evs)
     if (ev) (void)hipEventDestroy(ev);
   if (e->side1) (void)hipStreamDestroy(e->side1);
@@ -188,6 +191,67 @@ int dtf_engine_train_step(const DtfEngineDesc* e, long step_inc, hipStream_t s) 
   long off[3] = {e->off_out_w, e->off_wc2, e->off_wc1};
   return dtf_fused_reduce_sgd(3, part, G, n, st, off, e->params, e->grads, e->shadow, e->hyper, e->off_wd1, e->off_wc2,
                               e->wc2T, e->off_wc2, e->c1, e->c2, e->state, e->B, step_inc, 1, s);
+}
+
+// ---------------------------------------------------------------------------------------------
+// Data-parallel step choreography (parallel/sync_dp.py).  The step is three native calls around
+// the two collectives that Python issues through torch.distributed (RCCL): every kernel launch,
+// stream wait and event record of the overlap schedule happens here, so the host cost of a step is
+// 3 foreign calls + 2 all-reduce enqueues.  s = compute stream, comm = dense all-reduce + dense
+// update stream, tail = conv-tail all-reduce stream (may equal comm).
+//   phase1: sampler+conv forward | wait(dense params of the previous step) | dense forward, head,
+//           dense wgrads -> ev_dense_ready ; comm waits for it.         [Python: all-reduce dense on comm]
+//   phase2: fc1 dgrad (-> ev_dgrad), conv backward -> ev_tail_ready ; comm: wait ev_dgrad, update
+//           dense range -> ev_dense_updated ; tail waits ev_tail_ready.  [Python: all-reduce tail on tail]
+//   phase3: tail -> ev_tail_reduced ; s waits, updates the conv tail (+ state advance), repacks wc2.
+// ---------------------------------------------------------------------------------------------
+int dtf_engine_dp_phase1(const DtfEngineDesc* e, int wait_dense_updated, hipStream_t s, hipStream_t comm) {
+  DTF_TRY(dtf_conv1_fwd_sampled(e->ds_images, e->idx, e->state, e->ds_n, e->ds_hb, e->sample_seed, e->shuffle,
+                                f32at(e->params, e->off_wc1), f32at(e->params, e->off_bc1), e->p1, e->arg1, e->B,
+                                e->c1, 0, s));
+  DTF_TRY(dtf_conv2_fwd(e->p1, e->wc2T, f32at(e->params, e->off_bc2), e->p2, e->arg2, e->B, e->c1, e->c2, s));
+  if (wait_dense_updated) HIP_TRY(hipStreamWaitEvent(s, e->ev_dense_updated, 0));
+  DTF_TRY(dtf_engine_forward_dense(e, e->ds_labels, e->idx, 1, e->B, 1, s));
+  DTF_TRY(backward_dense_impl(e, 1, s));
+  HIP_TRY(hipEventRecord(e->ev_dense_ready, s));
+  return (int)hipStreamWaitEvent(comm, e->ev_dense_ready, 0);
+}
+
+int dtf_engine_dp_phase2(const DtfEngineDesc* e, long dense_hi, int dense_adam_slot, hipStream_t s, hipStream_t comm,
+                         hipStream_t tail) {
+  DTF_TRY(backward_conv_impl(e, e->ds_images, e->idx, 1, 1, s));
+  HIP_TRY(hipEventRecord(e->ev_tail_ready, s));
+  // the dense update overwrites the bf16 wd1 that fc1 dgrad reads: order it after that kernel
+  HIP_TRY(hipStreamWaitEvent(comm, e->ev_dgrad, 0));
+  DTF_TRY(dtf_engine_update_range(e, 0, dense_hi, 0, 0, 0, dense_adam_slot, comm));
+  HIP_TRY(hipEventRecord(e->ev_dense_updated, comm));
+  return (int)hipStreamWaitEvent(tail, e->ev_tail_ready, 0);
+}
+
+int dtf_engine_dp_phase3(const DtfEngineDesc* e, long dense_hi, int tail_adam_slot, long step_inc, int wait_dense,
+                         hipStream_t s, hipStream_t tail) {
+  HIP_TRY(hipEventRecord(e->ev_tail_reduced, tail));
+  HIP_TRY(hipStreamWaitEvent(s, e->ev_tail_reduced, 0));
+  if (e->optimizer == 0 && dense_hi == e->off_wc2) {
+    // SGD: update + bf16 shadow + wc2 repack of the (already all-reduced) conv tail in one launch --
+    // the fused tail kernel with the gradient arena itself as a single "slab" per segment
+    const void* part[2] = {f32at(e->grads, e->off_wc2), f32at(e->grads, e->off_wc1)};
+    int G[2] = {1, 1}, n[2] = {(int)e->c2_stride, (int)e->c1_stride};
+    long st[2] = {e->c2_stride, e->c1_stride};
+    long off[2] = {e->off_wc2, e->off_wc1};
+    DTF_TRY(dtf_fused_reduce_sgd(2, part, G, n, st, off, e->params, e->grads, e->shadow, e->hyper, e->off_wc2,
+                                 e->off_wc2, e->wc2T, e->off_wc2, e->c1, e->c2, e->state, e->B, step_inc, 1, s));
+  } else {
+    DTF_TRY(dtf_engine_update_range(e, dense_hi, e->n_total, 1, 1, step_inc, tail_adam_slot, s));
+    DTF_TRY(dtf_engine_transposes(e, 1, s));
+  }
+  if (wait_dense) HIP_TRY(hipStreamWaitEvent(s, e->ev_dense_updated, 0));
+  return 0;
+}
+
+// make the deferred dense update of the last step visible to s
+int dtf_engine_dp_flush(const DtfEngineDesc* e, hipStream_t s) {
+  return (int)hipStreamWaitEvent(s, e->ev_dense_updated, 0);
 }
 
 }  // extern "C"

@@ -75,7 +75,8 @@ class EngineDesc(ctypes.Structure):
                                    "idx", "p1", "arg1", "p2", "arg2", "h1", "logits", "loss_rows", "correct_rows",
                                    "dlogits", "da", "dflat", "dp1", "head_part", "c2_part", "c1_part", "ds_images",
                                    "ds_labels")]
-        + [(n, c_void_p) for n in ("side1", "side2", "ev_head", "ev_fork", "ev_join1", "ev_join2", "ev_dgrad")]
+        + [(n, c_void_p) for n in ("side1", "side2", "ev_head", "ev_fork", "ev_join1", "ev_join2", "ev_dgrad",
+                                   "ev_dense_ready", "ev_dense_updated", "ev_tail_ready", "ev_tail_reduced")]
     )
 
 
@@ -94,6 +95,10 @@ _ENGINE_SIGS = {
     "dtf_engine_update_range": [_EP, c_long, c_long, c_int, c_int, c_long, c_int, c_void_p],
     "dtf_engine_transposes": [_EP, c_int, c_void_p],
     "dtf_engine_train_step": [_EP, c_long, c_void_p],
+    "dtf_engine_dp_phase1": [_EP, c_int, c_void_p, c_void_p],
+    "dtf_engine_dp_phase2": [_EP, c_long, c_int, c_void_p, c_void_p, c_void_p],
+    "dtf_engine_dp_phase3": [_EP, c_long, c_int, c_long, c_int, c_void_p, c_void_p],
+    "dtf_engine_dp_flush": [_EP, c_void_p],
 }
 
 
