@@ -22,6 +22,8 @@ int dtf_gemm_nt(const void* A, const void* B, void* C, const void* bias, int M, 
                 int ldc, int epi, float keep_prob, uint64_t seed, const void* state, int tile, hipStream_t s);
 int dtf_gemm_tn(const void* A, const void* B, void* C, int M, int N, int K, int lda, int ldb, int ldc, int tile,
                 hipStream_t s);
+int dtf_gemm_tn_sgd(const void* A, const void* B, void* W, void* shadow, const void* hyper, int M, int N, int K,
+                    int lda, int ldb, int ldw, hipStream_t s);
 int dtf_gemm_nn_fwd(const void* A, const void* B, void* part, void* out, const void* bias, int M, int N, int K,
                     int lda, int ldb, int S, float keep_prob, uint64_t seed, const void* state, hipStream_t s);
 int dtf_transpose_bf16(const void* in, void* out, int batch, int R, int C, hipStream_t s);

@@ -211,9 +211,15 @@ __global__ __launch_bounds__(NW * 64) void gemm_nt_bf16(const bf16* A, const bf1
 }
 
 // C[M,N] (fp32) = sum_k A[k][m] * B[k][n];  A: [K][lda], B: [K][ldb]
-template <int BM, int BN, int NW>
+// SGD = true: C is the fp32 MASTER WEIGHT and the product is its gradient; the epilogue applies
+// w -= lr * g in place and writes the bf16 compute copy -- the fc1 weight gradient (98 % of the
+// model's gradient bytes) then never goes through memory.  Single-GPU SGD only: with data
+// parallelism the gradient has to exist for the all-reduce.
+template <int BM, int BN, int NW, bool SGD = false>
 __global__ __launch_bounds__(NW * 64) void gemm_tn_bf16(const bf16* A, const bf16* Bm, float* __restrict__ C,
-                                                        int M, int N, int K, int lda, int ldb, int ldc) {
+                                                        int M, int N, int K, int lda, int ldb, int ldc,
+                                                        bf16* __restrict__ shadow = nullptr,
+                                                        const float* __restrict__ hyper = nullptr) {
   constexpr int BK = 64, NT = NW * 64;
   constexpr int PA = BM + 16, PB = BN + 16;  // row pitch in elements (+32 B)
   constexpr int WAVES_N = NW / 2;
@@ -299,17 +305,52 @@ __global__ __launch_bounds__(NW * 64) void gemm_tn_bf16(const bf16* A, const bf1
 
   gemm_pipeline<A_CH, B_CH>((K + BK - 1) / BK, gload, swrite, compute);
 
-#pragma unroll
-  for (int j = 0; j < NTL; ++j) {
-    const int n = n0 + wn * WN + j * 16 + i16;
-    if (n >= N) continue;
+  if constexpr (SGD) {
+    // Read-modify-write of the master weight straight from the C/D layout would be 4-byte accesses
+    // scattered over rows (measured: +8 us).  The gradient tile goes through LDS instead (the
+    // pipeline buffers are dead: rows 0..63 into sA, rows 64..127 into sB, pitch 132 floats so the
+    // four row groups of a store land on different banks) and every thread then updates float4s.
+    static_assert(BM == 128 && BN == 128 && NW == 8, "SGD epilogue is written for the 128x128x8-wave tile");
+    constexpr int GP = BN + 4;
+    static_assert(64 * GP * 4 <= BK * PA * 2 * 2, "gradient half-tile must fit an operand's LDS buffers");
+    float* gt = reinterpret_cast<float*>(wm == 0 ? &sA[0][0] : &sB[0][0]);
 #pragma unroll
     for (int i = 0; i < MT; ++i)
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int mrow = m0 + wm * WM + i * 16 + 4 * g + r;
-        if (mrow < M) C[(size_t)mrow * ldc + n] = acc[i][j][r];
+      for (int j = 0; j < NTL; ++j)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) gt[(i * 16 + 4 * g + r) * GP + wn * WN + j * 16 + i16] = acc[i][j][r];
+    __syncthreads();
+    const float lr = hyper[0] * hyper[4];
+#pragma unroll
+    for (int k = 0; k < BM * BN / 4 / NT; ++k) {
+      const int c = tid + k * NT, row = c / (BN / 4), c4 = c % (BN / 4);
+      const int mrow = m0 + row, n = n0 + c4 * 4;
+      if (mrow < M && n < N) {
+        const float* gsrc = reinterpret_cast<const float*>(row < 64 ? &sA[0][0] : &sB[0][0]) + (row & 63) * GP + c4 * 4;
+        const f32x4 gv = *reinterpret_cast<const f32x4*>(gsrc);
+        const size_t o = (size_t)mrow * ldc + n;
+        f32x4 w = *reinterpret_cast<const f32x4*>(C + o);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) w[e] = fmaf(-lr, gv[e], w[e]);
+        *reinterpret_cast<f32x4*>(C + o) = w;
+        bf16x4 sh = {(bf16)w[0], (bf16)w[1], (bf16)w[2], (bf16)w[3]};
+        *reinterpret_cast<bf16x4*>(shadow + o) = sh;
       }
+    }
+  } else {
+#pragma unroll
+    for (int j = 0; j < NTL; ++j) {
+      const int n = n0 + wn * WN + j * 16 + i16;
+      if (n >= N) continue;
+#pragma unroll
+      for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int mrow = m0 + wm * WM + i * 16 + 4 * g + r;
+          if (mrow < M) C[(size_t)mrow * ldc + n] = acc[i][j][r];
+        }
+    }
   }
 }
 
@@ -516,6 +557,16 @@ int dtf_gemm_tn(const void* A, const void* B, void* C, int M, int N, int K, int 
                        (const bf16*)A, (const bf16*)B, (float*)C, M, N, K, lda, ldb, ldc);
   else
     return -1;
+  return (int)hipGetLastError();
+}
+
+// W[M,N] -= lr * (A[K,M]^T . B[K,N]), shadow = bf16(W); lr = hyper[0] * hyper[4]  (see gemm_tn_bf16<SGD>)
+int dtf_gemm_tn_sgd(const void* A, const void* B, void* W, void* shadow, const void* hyper, int M, int N, int K,
+                    int lda, int ldb, int ldw, hipStream_t s) {
+  if ((lda & 7) || (ldb & 7) || (M & 7) || (N & 7) || (ldw & 3) || !shadow || !hyper) return -3;
+  hipLaunchKernelGGL((gemm_tn_bf16<128, 128, 8, true>), dim3((N + 127) / 128, (M + 127) / 128), dim3(512), 0, s,
+                     (const bf16*)A, (const bf16*)B, (float*)W, M, N, K, lda, ldb, ldw, (bf16*)shadow,
+                     (const float*)hyper);
   return (int)hipGetLastError();
 }
 

@@ -133,7 +133,7 @@ class HipBackend(Backend):
         self.train_ds = DeviceDataset.from_float(torch.from_numpy(tr.images), torch.from_numpy(tr.int_labels), device)
         self._eval_cache = {}
         self.engine = HipEngine(spec, batch, self.train_ds, optimizer=optimizer, learning_rate=learning_rate,
-                                keep_prob=keep_prob, seed=seed, device=device)
+                                keep_prob=keep_prob, seed=seed, device=device, fuse_dense_update=True)
         self.layout = self.engine.layout
         self.use_graph = use_graph
         self._host_step = 0

@@ -81,7 +81,8 @@ class HipEngine:
     def __init__(self, spec: ModelSpec, batch: int, dataset: Optional[DeviceDataset] = None,
                  optimizer: str = "sgd", learning_rate: float = 1e-3, keep_prob: float = 1.0,
                  seed: int = 0, device="cuda", grad_scale: float = 1.0, shuffle: bool = True,
-                 adam_betas=(0.9, 0.999), adam_eps: float = 1e-8, step_inc: int = 1, multi_stream: bool = True):
+                 adam_betas=(0.9, 0.999), adam_eps: float = 1e-8, step_inc: int = 1, multi_stream: bool = True,
+                 fuse_dense_update: bool = False):
         if not torch.cuda.is_available():
             raise RuntimeError("HipEngine needs a GPU (use backend='cpu' / models.oracle on CPU)")
         self.lib = native.load()
@@ -95,6 +96,7 @@ class HipEngine:
         self.step_inc = int(step_inc)
         self.dataset = dataset
         self.multi_stream = bool(multi_stream)
+        self.fuse_dense_update = bool(fuse_dense_update)
         dev, B, H, C1, C2, FLAT = self.device, self.B, spec.hidden, spec.c1, spec.c2, spec.flat
         n = self.layout.total
 
@@ -164,6 +166,9 @@ class HipEngine:
         d.head_ks, d.c2_g, d.c1_g = self.head_ks, self.c2_g, self.c1_g
         d.optimizer = 0 if self.optimizer == "sgd" else 1
         d.shuffle, d.multi_stream = int(self.shuffle), int(self.multi_stream)
+        # fc1 SGD update inside its wgrad GEMM (single-GPU train_step only; the wd1 gradient is then never
+        # materialised in the gradient arena)
+        d.fuse_dense_update = int(self.fuse_dense_update and self.optimizer == "sgd")
         d.sample_seed, d.seed, d.keep_prob = self.seed & 0xFFFFFFFF, self.seed & (2 ** 64 - 1), self.keep_prob
         d.n_total = lay.total
         for name in lay.names():

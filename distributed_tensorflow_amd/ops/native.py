@@ -36,6 +36,7 @@ _SIGS = {
     "dtf_conv2_wgrad": [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p],
     "dtf_gemm_nt": [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_int,
                     c_float, c_uint64, c_void_p, c_int, c_void_p],
+    "dtf_gemm_tn_sgd": [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p],
     "dtf_gemm_tn": [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p],
     "dtf_gemm_nn_fwd": [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int,
                         c_float, c_uint64, c_void_p, c_void_p],
@@ -67,7 +68,7 @@ class EngineDesc(ctypes.Structure):
     _fields_ = (
         [(n, c_int) for n in ("B", "c1", "c2", "hidden", "flat", "classes", "head_ks", "c2_g", "c1_g", "optimizer",
                               "shuffle", "multi_stream")]
-        + [(n, c_uint) for n in ("ds_n", "ds_hb", "sample_seed", "pad0")]
+        + [(n, c_uint) for n in ("ds_n", "ds_hb", "sample_seed", "fuse_dense_update")]
         + [("seed", c_uint64), ("keep_prob", c_float), ("pad1", c_float), ("n_total", c_long)]
         + [(n, c_long) for n in ("off_out_w", "off_out_b", "off_bd1", "off_wd1", "off_wc2", "off_bc2", "off_wc1",
                                  "off_bc1", "head_stride", "c2_stride", "c1_stride")]

@@ -89,6 +89,24 @@ def test_training_converges_and_graph_replay(gpu_lib, dataset):
     assert torch.equal(e0.params, e1.params)  # split-K slabs, no float atomics -> bitwise reproducible
 
 
+def test_fused_dense_update_is_bitwise_the_same_training(gpu_lib, dataset):
+    """fc1 SGD update applied inside the wgrad GEMM epilogue == gradient arena + optimizer kernel."""
+    from distributed_tensorflow_amd.engine import HipEngine
+    engines = []
+    for fuse in (False, True):
+        eng = HipEngine(ModelSpec(), 96, dataset, optimizer="sgd", learning_rate=0.01, seed=3, fuse_dense_update=fuse)
+        eng.init_params(seed=13)
+        if fuse:
+            eng.capture()
+        for _ in range(12):
+            eng.train_step()
+        engines.append(eng)
+    a, b = engines
+    assert a.global_step == b.global_step == 12
+    assert torch.equal(a.params, b.params) and torch.equal(a.shadow, b.shadow) and torch.equal(a.wc2T, b.wc2T)
+    assert a.last_metrics() == b.last_metrics()
+
+
 def test_adam_and_dropout_train(gpu_lib, dataset):
     from distributed_tensorflow_amd.engine import HipEngine
     eng = HipEngine(ModelSpec(), 128, dataset, optimizer="adam", learning_rate=1e-3, keep_prob=0.5, seed=9)
