@@ -27,9 +27,16 @@ int dtf_gemm_tn_sgd(const void* A, const void* B, void* W, void* shadow, const v
 int dtf_gemm_nn_fwd(const void* A, const void* B, void* part, void* out, const void* bias, int M, int N, int K,
                     int lda, int ldb, int S, float keep_prob, uint64_t seed, const void* state, hipStream_t s);
 int dtf_transpose_bf16(const void* in, void* out, int batch, int R, int C, hipStream_t s);
-int dtf_head_fwd_bwd(const void* h1, const void* w, const void* bias, const void* labels, const void* idx,
+int dtf_head_fwd_bwd(const void* h1, const void* wT, const void* bias, const void* labels, const void* idx,
                      void* logits_out, void* loss_rows, void* correct_rows, void* dlogits, void* da, int B, int H,
                      float grad_scale, float inv_keep, int backward, hipStream_t s);
+int dtf_head_fused_fwd_bwd(const void* part, int S, const void* bias1, float keep_prob, uint64_t seed,
+                           const void* state, void* h1, const void* wT, const void* bias, const void* labels,
+                           const void* idx, void* logits_out, void* loss_rows, void* correct_rows, void* dlogits,
+                           void* da, int B, int H, float grad_scale, float inv_keep, int backward, hipStream_t s);
+int dtf_transpose_head_w(const void* w, void* wT, int H, hipStream_t s);
+int dtf_gemm_nn_partial(const void* A, const void* B, void* part, int M, int N, int K, int lda, int ldb, int S,
+                        hipStream_t s);
 int dtf_head_wgrad(const void* h1, const void* dlogits, const void* da, void* part, int B, int H, int KS,
                    hipStream_t s);
 int dtf_sgd_update(void* w, const void* g, void* shadow, const void* hyper, long n, void* state, long cursor_inc,
@@ -41,8 +48,8 @@ int dtf_reduce_segments(int count, const void** part, void** out, const int* G, 
                         hipStream_t s);
 int dtf_fused_reduce_sgd(int count, const void** part, const int* G, const int* n, const long* stride,
                          const long* seg_off, void* w, void* g, void* shadow, const void* hyper, long dense_lo,
-                         long dense_hi, void* wc2T, long wc2_off, int c1, int c2, void* state, long cursor_inc,
-                         long step_inc, long drop_inc, hipStream_t s);
+                         long dense_hi, void* wc2T, long wc2_off, int c1, int c2, void* out_wT, long out_w_off, int H,
+                         void* state, long cursor_inc, long step_inc, long drop_inc, hipStream_t s);
 int dtf_sample_indices(const void* state, void* idx, int B, unsigned n, unsigned hb, unsigned seed, int shuffle,
                        hipStream_t s);
 }

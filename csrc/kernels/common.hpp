@@ -89,6 +89,20 @@ __host__ __device__ __forceinline__ uint32_t feistel_permute(uint32_t i, uint32_
   return i;
 }
 
+// Counter-based dropout (TF: x * floor(keep + u) / keep): the mask of element `elem` at dropout
+// offset `offset` is a pure function of (seed, elem, offset), so it is never stored.
+struct DropoutArgs {
+  float keep_prob;        // 1.0 -> disabled
+  uint64_t seed;
+  const int64_t* state;   // device step state; state[2] = dropout offset (graph-replay safe)
+};
+
+__device__ __forceinline__ float dropout_scale(const DropoutArgs& d, uint64_t offset, uint64_t elem) {
+  uint32_t r[4];
+  Philox::run(d.seed, elem, offset, r);
+  return u32_to_unit_float(r[0]) < d.keep_prob ? 1.0f / d.keep_prob : 0.f;
+}
+
 // ---------------------------------------------------------------------------
 // Max-pool + ReLU gradient routing.  The forward kernels store, per pooled element, the 2x2
 // argmax q in 0..3 -- or kPoolDead when the pooled activation is not positive -- so backward

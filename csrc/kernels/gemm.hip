@@ -24,18 +24,6 @@ namespace dtf {
 
 enum { EPI_STORE = 0, EPI_BIAS_RELU_DROPOUT = 1, EPI_NOSTORE_DIAG = 2 };
 
-struct DropoutArgs {
-  float keep_prob;        // 1.0 -> disabled
-  uint64_t seed;
-  const int64_t* state;   // device step state; state[2] = dropout offset (graph-replay safe)
-};
-
-__device__ __forceinline__ float dropout_scale(const DropoutArgs& d, uint64_t offset, uint64_t elem) {
-  uint32_t r[4];
-  Philox::run(d.seed, elem, offset, r);
-  return u32_to_unit_float(r[0]) < d.keep_prob ? 1.0f / d.keep_prob : 0.f;
-}
-
 // XCD-aware tile assignment.  Workgroups are dealt round-robin over the 8 XCDs (private 4 MiB
 // L2 each), so linear ids L and L+8 share an L2.  These GEMMs are small enough that every tile is
 // resident at once and the whole grid marches through K in step; what bounds them is fabric/HBM
@@ -593,6 +581,26 @@ int dtf_gemm_nn_fwd(const void* A, const void* B, void* part, void* out, const v
   hipLaunchKernelGGL(splitk_bias_relu_dropout, dim3((unsigned)blocks), dim3(256), 0, s, (const float*)part,
                      (const float*)bias, (bf16*)out, MN, N, S, d);
   return (int)hipGetLastError();
+}
+
+// fc1 forward, GEMM part only: part[S][M][N] fp32 partial products (the bias/ReLU/dropout epilogue is
+// fused into the head kernel, dtf_head_fused_fwd_bwd).  Returns the number of splits used (> 0) or a
+// negative error.
+int dtf_gemm_nn_partial(const void* A, const void* B, void* part, int M, int N, int K, int lda, int ldb, int S,
+                        hipStream_t s) {
+  if ((K & 7) || (lda & 7) || (ldb & 7) || (N & 7)) return -3;
+  const int T = (K + 63) / 64;
+  const int tiles = ((M + 127) / 128) * ((N + 127) / 128);
+  if (S <= 0) {
+    S = (256 + tiles - 1) / tiles;
+    if (S > 8) S = 8;
+  }
+  if (S > T) S = T;
+  const int tps = (T + S - 1) / S;
+  S = (T + tps - 1) / tps;
+  hipLaunchKernelGGL((gemm_nn_splitk_bf16<128, 128, 8>), dim3((N + 127) / 128, (M + 127) / 128, S), dim3(512), 0, s,
+                     (const bf16*)A, (const bf16*)B, (float*)part, M, N, K, lda, ldb, tps);
+  return hipGetLastError() == hipSuccess ? S : -1;
 }
 
 // max number of K splits dtf_gemm_nn_fwd may use (sizes the partial buffer)

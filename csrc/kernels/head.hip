@@ -4,9 +4,9 @@
 // :152-153 argmax-equality accuracy; TF's SoftmaxCrossEntropyWithLogits kernel
 // also emits softmax - y, which is what this kernel hands to backward).
 //
-// N = 10 is far too skinny for the matrix cores, so one wave owns one batch row:
-// lanes stride the hidden dimension with 16-byte bf16 loads, reduce the 10
-// partial dot products across the wave, and every lane then holds the full
+// N = 10 is far too skinny for the matrix cores, so one workgroup owns one batch row:
+// threads stride the hidden dimension with 16-byte loads, reduce the 10
+// partial dot products across the workgroup, and every thread then holds the full
 // logits vector.  The row's loss, correctness bit, dlogits and the gradient
 // wrt the fc1 pre-activation (da = (h1 > 0) * (dlogits . W^T) / keep) are all
 // produced from registers in the same launch; h1 is stored post-ReLU and
@@ -20,33 +20,79 @@ namespace dtf {
 
 constexpr int kCls = 10;
 
-// labels: int32 dataset labels; idx: optional gather (label = labels[idx[b]])
+// Optional fused fc1 epilogue: when `part` is given, the row of h1 is first produced here from the
+// split-K partial products of the fc1 GEMM (sum of S slabs + bias -> ReLU -> dropout, exactly the
+// arithmetic of gemm.hip's splitk_bias_relu_dropout) and written out for head_wgrad.
+struct Fc1Epilogue {
+  const float* part;      // [S][B][H] fp32 or nullptr (h1 is an input then)
+  const float* bias1;     // [H]
+  int S;
+  DropoutArgs drop;
+};
+
+// labels: int32 dataset labels; idx: optional gather (label = labels[idx[b]]).
+// wT: the output weight TRANSPOSED, fp32 [10][H].  A lane owns 4 consecutive hidden units per
+// 256-wide iteration, so every load below is one contiguous 1 KiB (fp32) or 512 B (bf16) wave
+// access.  With the native [H][10] layout each lane walked 80 consecutive floats and a single wave
+// load touched 64 cache lines; the texture path made that 9 us for 2 MB of activations.
+// One 256-thread workgroup per batch row (grid-stride), thread t owns hidden units 4t..4t+3 of every
+// 1024-wide slice: 4 waves per row instead of one, so a CU holds 16+ independent load streams
+// (one wave per row left each SIMD with a single latency-bound wave).
 __global__ __launch_bounds__(256) void head_fwd_bwd(
-    const bf16* __restrict__ h1, const float* __restrict__ w, const float* __restrict__ bias,
+    bf16* __restrict__ h1, Fc1Epilogue epi, const float* __restrict__ wT, const float* __restrict__ bias,
     const int* __restrict__ labels, const int* __restrict__ idx, float* __restrict__ logits_out,
     float* __restrict__ loss_rows, float* __restrict__ correct_rows, float* __restrict__ dlogits,
     bf16* __restrict__ da, int B, int H, float grad_scale, float inv_keep, int backward) {
-  const int lane = threadIdx.x & 63;
-  const int wave_global = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
-  const int nwaves = (gridDim.x * blockDim.x) >> 6;
+  __shared__ float zred[4][kCls];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const bool do_drop = epi.part && epi.drop.keep_prob < 1.0f;
+  const uint64_t drop_off = (do_drop && epi.drop.state) ? (uint64_t)epi.drop.state[2] : 0;
+  const size_t BH = (size_t)B * H;
 
-  for (int b = wave_global; b < B; b += nwaves) {
-    const bf16* hrow = h1 + (size_t)b * H;
+  for (int b = blockIdx.x; b < B; b += gridDim.x) {
+    bf16* hrow = h1 + (size_t)b * H;
     float z[kCls];
 #pragma unroll
     for (int c = 0; c < kCls; ++c) z[c] = 0.f;
-    for (int j0 = lane * 8; j0 < H; j0 += 512) {
-      bf16x8 hv = *reinterpret_cast<const bf16x8*>(hrow + j0);
-      const float* wp = w + (size_t)j0 * kCls;
+    for (int j0 = tid * 4; j0 < H; j0 += 1024) {
+      f32x4 hf;
+      if (epi.part) {
+        const float* p = epi.part + (size_t)b * H + j0;
+        hf = *reinterpret_cast<const f32x4*>(p);
+        for (int sI = 1; sI < epi.S; ++sI) hf += *reinterpret_cast<const f32x4*>(p + (size_t)sI * BH);
+        const f32x4 bv = *reinterpret_cast<const f32x4*>(epi.bias1 + j0);
+        bf16x4 o;
 #pragma unroll
-      for (int e = 0; e < 8; ++e) {
-        float hf = (float)hv[e];
+        for (int e = 0; e < 4; ++e) {
+          float v = fmaxf(hf[e] + bv[e], 0.f);
+          if (do_drop) v *= dropout_scale(epi.drop, drop_off, (uint64_t)b * (uint64_t)H + j0 + e);
+          o[e] = (bf16)v;
+          hf[e] = (float)o[e];   // downstream math sees exactly the stored bf16 value
+        }
+        *reinterpret_cast<bf16x4*>(hrow + j0) = o;
+      } else {
+        const bf16x4 hv = *reinterpret_cast<const bf16x4*>(hrow + j0);
 #pragma unroll
-        for (int c = 0; c < kCls; ++c) z[c] = fmaf(hf, wp[e * kCls + c], z[c]);
+        for (int e = 0; e < 4; ++e) hf[e] = (float)hv[e];
+      }
+#pragma unroll
+      for (int c = 0; c < kCls; ++c) {
+        const f32x4 wv = *reinterpret_cast<const f32x4*>(wT + (size_t)c * H + j0);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) z[c] = fmaf(hf[e], wv[e], z[c]);
       }
     }
+    // fixed-order reduction: lanes (butterfly), then the four waves in index order
 #pragma unroll
-    for (int c = 0; c < kCls; ++c) z[c] = wave_sum(z[c]) + bias[c];
+    for (int c = 0; c < kCls; ++c) z[c] = wave_sum(z[c]);
+    __syncthreads();   // zred free (previous row consumed)
+    if (lane == 0) {
+#pragma unroll
+      for (int c = 0; c < kCls; ++c) zred[wave][c] = z[c];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int c = 0; c < kCls; ++c) z[c] = ((zred[0][c] + zred[1][c]) + (zred[2][c] + zred[3][c])) + bias[c];
 
     const int label = labels[idx ? idx[b] : b];
     float zmax = z[0];
@@ -65,38 +111,45 @@ __global__ __launch_bounds__(256) void head_fwd_bwd(
 #pragma unroll
     for (int c = 0; c < kCls; ++c) dl[c] = (p[c] * inv - (c == label ? 1.f : 0.f)) * grad_scale;
 
-    if (lane == 0) {
+    if (tid == 0) {
       loss_rows[b] = __logf(se) + zmax - zl;
       correct_rows[b] = (amax == label) ? 1.f : 0.f;
     }
-    if (logits_out && lane < kCls) {
+    if (logits_out && tid < kCls) {
       float v = 0.f;
 #pragma unroll
-      for (int c = 0; c < kCls; ++c) v = (c == lane) ? z[c] : v;
-      logits_out[(size_t)b * kCls + lane] = v;
+      for (int c = 0; c < kCls; ++c) v = (c == tid) ? z[c] : v;
+      logits_out[(size_t)b * kCls + tid] = v;
     }
     if (!backward) continue;
-    if (lane < kCls) {
+    if (tid < kCls) {
       float v = 0.f;
 #pragma unroll
-      for (int c = 0; c < kCls; ++c) v = (c == lane) ? dl[c] : v;
-      dlogits[(size_t)b * kCls + lane] = v;
+      for (int c = 0; c < kCls; ++c) v = (c == tid) ? dl[c] : v;
+      dlogits[(size_t)b * kCls + tid] = v;
     }
     bf16* drow = da + (size_t)b * H;
-    for (int j0 = lane * 8; j0 < H; j0 += 512) {
-      bf16x8 hv = *reinterpret_cast<const bf16x8*>(hrow + j0);
-      const float* wp = w + (size_t)j0 * kCls;
-      bf16x8 o;
+    for (int j0 = tid * 4; j0 < H; j0 += 1024) {
+      const bf16x4 hv = *reinterpret_cast<const bf16x4*>(hrow + j0);   // own earlier store when fused
+      f32x4 sacc = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-      for (int e = 0; e < 8; ++e) {
-        float s = 0.f;
+      for (int c = 0; c < kCls; ++c) {
+        const f32x4 wv = *reinterpret_cast<const f32x4*>(wT + (size_t)c * H + j0);
 #pragma unroll
-        for (int c = 0; c < kCls; ++c) s = fmaf(dl[c], wp[e * kCls + c], s);
-        o[e] = (bf16)(((float)hv[e] > 0.f) ? s * inv_keep : 0.f);
+        for (int e = 0; e < 4; ++e) sacc[e] = fmaf(dl[c], wv[e], sacc[e]);
       }
-      *reinterpret_cast<bf16x8*>(drow + j0) = o;
+      bf16x4 o;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) o[e] = (bf16)(((float)hv[e] > 0.f) ? sacc[e] * inv_keep : 0.f);
+      *reinterpret_cast<bf16x4*>(drow + j0) = o;
     }
   }
+}
+
+// out[c][j] = in[j][c]  (fp32; keeps the transposed output weight of head_fwd_bwd current)
+__global__ __launch_bounds__(256) void transpose_head_w(const float* __restrict__ in, float* __restrict__ out, int H) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;   // index into out
+  if (i < H * kCls) out[i] = in[(size_t)(i % H) * kCls + i / H];
 }
 
 // grid = (H/64, KS).  slab layout per k-split: [H*10 dW_out][12: db_out padded][H db_d1]
@@ -147,16 +200,41 @@ using namespace dtf;
 
 extern "C" {
 
-int dtf_head_fwd_bwd(const void* h1, const void* w, const void* bias, const void* labels, const void* idx,
-                     void* logits_out, void* loss_rows, void* correct_rows, void* dlogits, void* da, int B,
-                     int H, float grad_scale, float inv_keep, int backward, hipStream_t s) {
-  if (H % 8) return -3;
-  int blocks = (B + 3) / 4;
-  if (blocks > 2048) blocks = 2048;
-  hipLaunchKernelGGL(head_fwd_bwd, dim3(blocks), dim3(256), 0, s, (const bf16*)h1, (const float*)w,
+static int head_launch(void* h1, Fc1Epilogue epi, const void* wT, const void* bias, const void* labels,
+                       const void* idx, void* logits_out, void* loss_rows, void* correct_rows, void* dlogits, void* da,
+                       int B, int H, float grad_scale, float inv_keep, int backward, hipStream_t s) {
+  if (H % 4) return -3;
+  int blocks = B < 4096 ? B : 4096;
+  hipLaunchKernelGGL(head_fwd_bwd, dim3(blocks), dim3(256), 0, s, (bf16*)h1, epi, (const float*)wT,
                      (const float*)bias, (const int*)labels, (const int*)idx, (float*)logits_out,
                      (float*)loss_rows, (float*)correct_rows, (float*)dlogits, (bf16*)da, B, H, grad_scale,
                      inv_keep, backward);
+  return (int)hipGetLastError();
+}
+
+// h1 [B][H] bf16 is an input; wT = output weight transposed, fp32 [10][H]
+int dtf_head_fwd_bwd(const void* h1, const void* wT, const void* bias, const void* labels, const void* idx,
+                     void* logits_out, void* loss_rows, void* correct_rows, void* dlogits, void* da, int B,
+                     int H, float grad_scale, float inv_keep, int backward, hipStream_t s) {
+  return head_launch(const_cast<void*>(h1), Fc1Epilogue{nullptr, nullptr, 0, DropoutArgs{1.0f, 0, nullptr}}, wT, bias,
+                     labels, idx, logits_out, loss_rows, correct_rows, dlogits, da, B, H, grad_scale, inv_keep,
+                     backward, s);
+}
+
+// fused fc1 epilogue + head: h1 = dropout(relu(sum_s part[s] + bias1)) is produced (and stored) here
+int dtf_head_fused_fwd_bwd(const void* part, int S, const void* bias1, float keep_prob, uint64_t seed,
+                           const void* state, void* h1, const void* wT, const void* bias, const void* labels,
+                           const void* idx, void* logits_out, void* loss_rows, void* correct_rows, void* dlogits,
+                           void* da, int B, int H, float grad_scale, float inv_keep, int backward, hipStream_t s) {
+  if (!part || S < 1) return -3;
+  Fc1Epilogue epi{(const float*)part, (const float*)bias1, S, DropoutArgs{keep_prob, seed, (const int64_t*)state}};
+  return head_launch(h1, epi, wT, bias, labels, idx, logits_out, loss_rows, correct_rows, dlogits, da, B, H,
+                     grad_scale, inv_keep, backward, s);
+}
+
+// wT[10][H] = w[H][10]^T (fp32)
+int dtf_transpose_head_w(const void* w, void* wT, int H, hipStream_t s) {
+  hipLaunchKernelGGL(transpose_head_w, dim3((H * kCls + 255) / 256), dim3(256), 0, s, (const float*)w, (float*)wT, H);
   return (int)hipGetLastError();
 }
 

@@ -167,6 +167,9 @@ struct FusedSgdArgs {
   bf16* shadow;
   const float* hyper;
   long dense_lo4, dense_hi4;   // dense range in float4 units
+  float* out_wT;               // fp32 [10][H] transpose of the output weight for head_fwd_bwd (nullptr: none)
+  long out_w_off;
+  int H;
   bf16* wc2T;                  // [fwd pack | dgrad pack] of the wc2 shadow (nullptr: none)
   long wc2_off;
   int c1, c2;
@@ -209,6 +212,11 @@ __global__ __launch_bounds__(256) void fused_reduce_sgd(FusedSgdArgs a) {
       for (int e = 0; e < 4; ++e) wv[e] = fmaf(-lr, gs[e], wv[e]);
       *reinterpret_cast<f32x4*>(a.w + e0) = wv;
       store_bf16x4(a.shadow + e0, wv[0], wv[1], wv[2], wv[3]);
+      const long ro = e0 - a.out_w_off;
+      if (a.out_wT && ro >= 0 && ro < 10L * a.H) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) a.out_wT[(size_t)((ro + e) % 10) * a.H + (ro + e) / 10] = wv[e];
+      }
       const long r = e0 - a.wc2_off;
       const long nw = 25L * a.c1 * a.c2;
       if (a.wc2T && r >= 0 && r < nw) {
@@ -308,11 +316,11 @@ int dtf_reduce_segments(int count, const void** part, void** out, const int* G, 
 
 // Fused single-GPU SGD tail (see fused_reduce_sgd).  Segments: part[k] is [G[k]][stride[k]] and
 // lands at arena float offset seg_off[k] (n[k] floats); [dense_lo, dense_hi) is the float range whose
-// gradient is already final.  wc2T may be NULL.
+// gradient is already final.  wc2T and out_wT (fp32 [10][H] transpose of the H x 10 tensor at out_w_off) may be NULL.
 int dtf_fused_reduce_sgd(int count, const void** part, const int* G, const int* n, const long* stride,
                          const long* seg_off, void* w, void* g, void* shadow, const void* hyper, long dense_lo,
-                         long dense_hi, void* wc2T, long wc2_off, int c1, int c2, void* state, long cursor_inc,
-                         long step_inc, long drop_inc, hipStream_t s) {
+                         long dense_hi, void* wc2T, long wc2_off, int c1, int c2, void* out_wT, long out_w_off, int H,
+                         void* state, long cursor_inc, long step_inc, long drop_inc, hipStream_t s) {
   if (count < 1 || count > 3 || (dense_lo & 3) || (dense_hi & 3) || (wc2_off & 3)) return -3;
   if (wc2T && ((c1 % 32) || (c2 % 32))) return -3;
   FusedSgdArgs a;
@@ -335,6 +343,9 @@ int dtf_fused_reduce_sgd(int count, const void** part, const int* G, const int* 
   a.hyper = (const float*)hyper;
   a.dense_lo4 = dense_lo / 4;
   a.dense_hi4 = dense_hi / 4;
+  a.out_wT = (float*)out_wT;
+  a.out_w_off = out_w_off;
+  a.H = H;
   a.wc2T = (bf16*)wc2T;
   a.wc2_off = wc2_off;
   a.c1 = c1;

@@ -24,6 +24,7 @@ struct DtfEngineDesc {
   void *params, *grads, *shadow, *fc1_part, *wc2T, *adam_m, *adam_v, *state, *hyper;
   void *idx, *p1, *arg1, *p2, *arg2, *h1, *logits, *loss_rows, *correct_rows, *dlogits, *da, *dflat, *dp1;
   void *head_part, *c2_part, *c1_part;
+  void* out_wT;  // fp32 [classes][hidden]: transposed output weight for the head kernel
   void *ds_images, *ds_labels;
   // native-owned handles (filled by dtf_engine_init)
   hipStream_t side1, side2;
@@ -80,12 +81,14 @@ int dtf_engine_forward_conv(const DtfEngineDesc* e, const void* images, const vo
 int dtf_engine_forward_dense(const DtfEngineDesc* e, const void* labels, const void* idx, int backward, int n,
                              int train_mode, hipStream_t s) {
   const float keep = train_mode ? e->keep_prob : 1.0f;
-  // wd1 is consumed in its native [in, out] layout (no transposed copy); split-K + fused epilogue
-  DTF_TRY(dtf_gemm_nn_fwd(e->p2, bf16at(e->shadow, e->off_wd1), e->fc1_part, e->h1, f32at(e->params, e->off_bd1), n,
-                          e->hidden, e->flat, e->flat, e->hidden, 0, keep, e->seed, e->state, s));
-  return dtf_head_fwd_bwd(e->h1, f32at(e->params, e->off_out_w), f32at(e->params, e->off_out_b), labels, idx,
-                          e->logits, e->loss_rows, e->correct_rows, e->dlogits, e->da, n, e->hidden, 1.0f / n,
-                          1.0f / keep, backward, s);
+  // wd1 is consumed in its native [in, out] layout (no transposed copy), split-K; the bias + ReLU +
+  // dropout epilogue runs inside the head kernel, which turns the partial sums into h1 on the fly
+  const int S = dtf_gemm_nn_partial(e->p2, bf16at(e->shadow, e->off_wd1), e->fc1_part, n, e->hidden, e->flat, e->flat,
+                                    e->hidden, 0, s);
+  if (S <= 0) return S == 0 ? -1 : S;
+  return dtf_head_fused_fwd_bwd(e->fc1_part, S, f32at(e->params, e->off_bd1), keep, e->seed, e->state, e->h1, e->out_wT,
+                                f32at(e->params, e->off_out_b), labels, idx, e->logits, e->loss_rows, e->correct_rows,
+                                e->dlogits, e->da, n, e->hidden, 1.0f / n, 1.0f / keep, backward, s);
 }
 
 // head wgrad + slab reduce + fc1 wgrad: finalises the (head | wd1) prefix of the gradient arena.
@@ -157,17 +160,22 @@ int dtf_engine_update_range(const DtfEngineDesc* e, long lo, long hi, int advanc
   void* st = advance ? e->state : nullptr;
   const long cinc = (advance && advance_cursor) ? e->B : 0;
   if (e->optimizer == 0)
-    return dtf_sgd_update(f32at(e->params, lo), f32at(e->grads, lo), bf16at(e->shadow, lo), e->hyper, n, st, cinc,
-                          step_inc, 1, s);
-  return dtf_adam_update(f32at(e->params, lo), f32at(e->grads, lo), f32at(e->adam_m, lo), f32at(e->adam_v, lo),
-                         bf16at(e->shadow, lo), e->hyper, n, e->state, adam_slot, st, cinc, step_inc, 1, s);
+    DTF_TRY(dtf_sgd_update(f32at(e->params, lo), f32at(e->grads, lo), bf16at(e->shadow, lo), e->hyper, n, st, cinc,
+                           step_inc, 1, s));
+  else
+    DTF_TRY(dtf_adam_update(f32at(e->params, lo), f32at(e->grads, lo), f32at(e->adam_m, lo), f32at(e->adam_v, lo),
+                            bf16at(e->shadow, lo), e->hyper, n, e->state, adam_slot, st, cinc, step_inc, 1, s));
+  // the head kernel reads the output weight transposed: keep that copy current
+  if (lo <= e->off_out_w && e->off_out_w < hi)
+    DTF_TRY(dtf_transpose_head_w(f32at(e->params, e->off_out_w), e->out_wT, e->hidden, s));
+  return 0;
 }
 
 // only wc2 needs a derived copy: its two fragment-ordered packs (2 x 100 KB, conv2.hip); wd1 is
 // used in place by both fc1 GEMMs
 int dtf_engine_transposes(const DtfEngineDesc* e, int wc2, hipStream_t s) {
   if (wc2) DTF_TRY(dtf_conv2_pack_weights(bf16at(e->shadow, e->off_wc2), e->wc2T, e->c1, e->c2, s));
-  return 0;
+  return dtf_transpose_head_w(f32at(e->params, e->off_out_w), e->out_wT, e->hidden, s);
 }
 
 // Backward + update of the single-GPU SGD step with the fc1 weight update fused into its wgrad
@@ -202,7 +210,7 @@ static int train_tail_fused_dense(const DtfEngineDesc* e, long step_inc, hipStre
   long off[3] = {e->off_out_w, e->off_wc2, e->off_wc1};
   // dense range empty: wd1 is already updated
   return dtf_fused_reduce_sgd(3, part, G, n, st, off, e->params, e->grads, e->shadow, e->hyper, e->off_wc2, e->off_wc2,
-                              e->wc2T, e->off_wc2, e->c1, e->c2, e->state, e->B, step_inc, 1, s);
+                              e->wc2T, e->off_wc2, e->c1, e->c2, e->out_wT, e->off_out_w, e->hidden, e->state, e->B, step_inc, 1, s);
 }
 
 // one full optimisation step on the resident dataset.  SGD (the reference optimizer) ends in the
@@ -226,7 +234,7 @@ int dtf_engine_train_step(const DtfEngineDesc* e, long step_inc, hipStream_t s) 
   long st[3] = {e->head_stride, e->c2_stride, e->c1_stride};
   long off[3] = {e->off_out_w, e->off_wc2, e->off_wc1};
   return dtf_fused_reduce_sgd(3, part, G, n, st, off, e->params, e->grads, e->shadow, e->hyper, e->off_wd1, e->off_wc2,
-                              e->wc2T, e->off_wc2, e->c1, e->c2, e->state, e->B, step_inc, 1, s);
+                              e->wc2T, e->off_wc2, e->c1, e->c2, e->out_wT, e->off_out_w, e->hidden, e->state, e->B, step_inc, 1, s);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -276,7 +284,7 @@ int dtf_engine_dp_phase3(const DtfEngineDesc* e, long dense_hi, int tail_adam_sl
     long st[2] = {e->c2_stride, e->c1_stride};
     long off[2] = {e->off_wc2, e->off_wc1};
     DTF_TRY(dtf_fused_reduce_sgd(2, part, G, n, st, off, e->params, e->grads, e->shadow, e->hyper, e->off_wc2,
-                                 e->off_wc2, e->wc2T, e->off_wc2, e->c1, e->c2, e->state, e->B, step_inc, 1, s));
+                                 e->off_wc2, e->wc2T, e->off_wc2, e->c1, e->c2, nullptr, 0, 0, e->state, e->B, step_inc, 1, s));
   } else {
     DTF_TRY(dtf_engine_update_range(e, dense_hi, e->n_total, 1, 1, step_inc, tail_adam_slot, s));
     DTF_TRY(dtf_engine_transposes(e, 1, s));

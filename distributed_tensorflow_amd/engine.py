@@ -107,6 +107,7 @@ class HipEngine:
         self.grads = torch.zeros(n, **f32)
         self.shadow = torch.zeros(n, **bf)
         self.wc2T = torch.zeros((2, 25 * C1 * C2), **bf)   # [fwd pack | dgrad pack] of wc2 (csrc/kernels/conv2.hip)
+        self.out_wT = torch.zeros((10, H), **f32)          # output weight transposed, for the head kernel
         if optimizer == "adam":
             self.adam_m = torch.zeros(n, **f32)
             self.adam_v = torch.zeros(n, **f32)
@@ -174,7 +175,7 @@ class HipEngine:
         for name in lay.names():
             setattr(d, "off_" + name, lay.offsets[name])
         d.head_stride, d.c2_stride, d.c1_stride = self.head_stride, self.c2_stride, self.c1_stride
-        for name in ("params", "grads", "shadow", "fc1_part", "wc2T", "state", "hyper", "idx", "p1", "arg1", "p2", "arg2",
+        for name in ("params", "grads", "shadow", "fc1_part", "wc2T", "out_wT", "state", "hyper", "idx", "p1", "arg1", "p2", "arg2",
                      "h1", "logits", "loss_rows", "correct_rows", "dlogits", "da", "dflat", "dp1", "head_part",
                      "c2_part", "c1_part"):
             setattr(d, name, getattr(self, name).data_ptr())
@@ -332,7 +333,7 @@ class HipEngine:
         The warm-up launches (lazy kernel attribute set-up must not happen under capture) run real
         steps, so parameters / optimizer moments / step state are snapshotted and restored:
         capturing is invisible to training."""
-        keep = [self.params, self.state, self.shadow, self.wc2T]
+        keep = [self.params, self.state, self.shadow, self.wc2T, self.out_wT]
         if self.optimizer == "adam":
             keep += [self.adam_m, self.adam_v]
         snap = [t.clone() for t in keep]

@@ -43,6 +43,11 @@ _SIGS = {
     "dtf_transpose_bf16": [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p],
     "dtf_head_fwd_bwd": [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                          c_void_p, c_void_p, c_int, c_int, c_float, c_float, c_int, c_void_p],
+    "dtf_head_fused_fwd_bwd": [c_void_p, c_int, c_void_p, c_float, c_uint64, c_void_p, c_void_p, c_void_p, c_void_p,
+                               c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int,
+                               c_float, c_float, c_int, c_void_p],
+    "dtf_transpose_head_w": [c_void_p, c_void_p, c_int, c_void_p],
+    "dtf_gemm_nn_partial": [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p],
     "dtf_head_wgrad": [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p],
     "dtf_sgd_update": [c_void_p, c_void_p, c_void_p, c_void_p, c_long, c_void_p, c_long, c_long, c_long, c_void_p],
     "dtf_adam_update": [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_long, c_void_p, c_int,
@@ -53,7 +58,8 @@ _SIGS = {
                             ctypes.POINTER(c_int), ctypes.POINTER(c_long), c_void_p],
     "dtf_fused_reduce_sgd": [c_int, ctypes.POINTER(c_void_p), ctypes.POINTER(c_int), ctypes.POINTER(c_int),
                              ctypes.POINTER(c_long), ctypes.POINTER(c_long), c_void_p, c_void_p, c_void_p, c_void_p,
-                             c_long, c_long, c_void_p, c_long, c_int, c_int, c_void_p, c_long, c_long, c_long, c_void_p],
+                             c_long, c_long, c_void_p, c_long, c_int, c_int, c_void_p, c_long, c_int, c_void_p, c_long, c_long,
+                             c_long, c_void_p],
     "dtf_sample_indices": [c_void_p, c_void_p, c_int, c_uint, c_uint, c_uint, c_int, c_void_p],
     "dtf_gen_synthetic": [c_void_p, c_void_p, c_long, c_uint, c_void_p],
     "dtf_init_truncated_normal": [c_void_p, c_long, c_float, c_uint64, c_uint64, c_void_p],
@@ -74,7 +80,7 @@ class EngineDesc(ctypes.Structure):
                                  "off_bc1", "head_stride", "c2_stride", "c1_stride")]
         + [(n, c_void_p) for n in ("params", "grads", "shadow", "fc1_part", "wc2T", "adam_m", "adam_v", "state", "hyper",
                                    "idx", "p1", "arg1", "p2", "arg2", "h1", "logits", "loss_rows", "correct_rows",
-                                   "dlogits", "da", "dflat", "dp1", "head_part", "c2_part", "c1_part", "ds_images",
+                                   "dlogits", "da", "dflat", "dp1", "head_part", "c2_part", "c1_part", "out_wT", "ds_images",
                                    "ds_labels")]
         + [(n, c_void_p) for n in ("side1", "side2", "ev_head", "ev_fork", "ev_join1", "ev_join2", "ev_dgrad",
                                    "ev_dense_ready", "ev_dense_updated", "ev_tail_ready", "ev_tail_reduced")]

@@ -60,6 +60,7 @@ def test_step_matches_oracle(gpu_lib, dataset, B):
     from distributed_tensorflow_amd.ops.reference import conv2_pack_reference
     f_ref, d_ref = conv2_pack_reference(wc2.to(torch.bfloat16))
     assert torch.equal(eng.wc2T[0], f_ref) and torch.equal(eng.wc2T[1], d_ref)
+    assert torch.equal(eng.out_wT, eng.pview("out_w").reshape(spec.hidden, 10).t().contiguous())
 
 
 def test_training_converges_and_graph_replay(gpu_lib, dataset):
@@ -104,6 +105,7 @@ def test_fused_dense_update_is_bitwise_the_same_training(gpu_lib, dataset):
     a, b = engines
     assert a.global_step == b.global_step == 12
     assert torch.equal(a.params, b.params) and torch.equal(a.shadow, b.shadow) and torch.equal(a.wc2T, b.wc2T)
+    assert torch.equal(a.out_wT, b.out_wT)
     assert a.last_metrics() == b.last_metrics()
 
 

@@ -306,7 +306,10 @@ def test_head(gpu_lib, B, H):
     crows = torch.empty(B, device=DEV)
     dlog = torch.empty(B, 10, device=DEV)
     da = torch.empty(B, H, dtype=torch.bfloat16, device=DEV)
-    check(gpu_lib.dtf_head_fwd_bwd(ptr(h1), ptr(w), ptr(b), ptr(labels), None, ptr(logits), ptr(lrows), ptr(crows),
+    wT = torch.empty(10, H, device=DEV)
+    check(gpu_lib.dtf_transpose_head_w(ptr(w), ptr(wT), H, stream()), "transpose_head_w")
+    assert torch.equal(wT, w.detach().t().contiguous())
+    check(gpu_lib.dtf_head_fwd_bwd(ptr(h1), ptr(wT), ptr(b), ptr(labels), None, ptr(logits), ptr(lrows), ptr(crows),
                                    ptr(dlog), ptr(da), B, H, 1.0 / B, 1.0 / keep, 1, stream()), "head")
     assert rel_err(logits, z) < 1e-5
     assert rel_err(lrows, loss_rows) < 1e-5
@@ -325,6 +328,43 @@ def test_head(gpu_lib, B, H):
     assert rel_err(got[H * 10:H * 10 + 10], b.grad) < 1e-4
     assert float(got[H * 10 + 10:H * 10 + 12].abs().max()) == 0.0
     assert rel_err(got[H * 10 + 12:], da.float().sum(0)) < 1e-4
+
+
+@pytest.mark.parametrize("keep", [1.0, 0.6])
+def test_head_fused_fc1_epilogue_matches_two_kernel_path(gpu_lib, keep):
+    """split-K partials -> (bias, ReLU, dropout, h1, logits, loss, dlogits, da) in one launch ==
+    splitk_bias_relu_dropout followed by head_fwd_bwd, bitwise."""
+    M, N, K = 200, 1024, 3136
+    g = torch.Generator(device="cpu").manual_seed(21)
+    A = bf(torch.randn(M, K, generator=g)).to(DEV)
+    Bm = bf(torch.randn(K, N, generator=g) * 0.03).to(DEV)
+    bias1 = torch.randn(N, generator=g).to(DEV)
+    wT = (torch.randn(10, N, generator=g) * 0.1).to(DEV)
+    b = (torch.randn(10, generator=g) * 0.1).to(DEV)
+    labels = torch.randint(0, 10, (M,), generator=g, dtype=torch.int32).to(DEV)
+    state = torch.zeros(8, dtype=torch.int64, device=DEV)
+    state[2] = 5
+    part = torch.empty(8, M, N, device=DEV)
+    outs = []
+    for fused in (False, True):
+        h1 = torch.zeros(M, N, dtype=torch.bfloat16, device=DEV)
+        logits, lrows, crows = torch.empty(M, 10, device=DEV), torch.empty(M, device=DEV), torch.empty(M, device=DEV)
+        dlog, da = torch.empty(M, 10, device=DEV), torch.empty(M, N, dtype=torch.bfloat16, device=DEV)
+        tail = (ptr(wT), ptr(b), ptr(labels), None, ptr(logits), ptr(lrows), ptr(crows), ptr(dlog), ptr(da), M, N,
+                1.0 / M, 1.0 / keep, 1, stream())
+        if fused:
+            S = gpu_lib.dtf_gemm_nn_partial(ptr(A), ptr(Bm), ptr(part), M, N, K, K, N, 0, stream())
+            assert S > 0
+            check(gpu_lib.dtf_head_fused_fwd_bwd(ptr(part), S, ptr(bias1), keep, 9, ptr(state), ptr(h1), *tail), "fused")
+        else:
+            check(gpu_lib.dtf_gemm_nn_fwd(ptr(A), ptr(Bm), ptr(part), ptr(h1), ptr(bias1), M, N, K, K, N, 0, keep, 9,
+                                          ptr(state), stream()), "nn_fwd")
+            check(gpu_lib.dtf_head_fwd_bwd(ptr(h1), *tail), "head")
+        torch.cuda.synchronize()
+        outs.append((h1, logits, lrows, crows, dlog, da))
+    for x, y in zip(*outs):
+        assert torch.equal(x, y)
+    assert float(outs[0][0].float().abs().sum()) > 0
 
 
 # ------------------------------------------------------------------- optimizer
@@ -346,7 +386,8 @@ def test_reduce_segments(gpu_lib):
 def test_fused_reduce_sgd(gpu_lib):
     """One launch == reduce_segments + sgd_update + wc2 transpose, bitwise."""
     c1, c2 = 32, 64
-    n_head, n_dense, n_c2, n_c1 = 76, 1000, 25 * c1 * c2 + c2, 40
+    H = 16
+    n_head, n_dense, n_c2, n_c1 = H * 10 + 12 + H, 1000, 25 * c1 * c2 + c2, 40
     offs = [0, n_head, n_head + n_dense, n_head + n_dense + n_c2]
     total = offs[3] + n_c1
     g = torch.Generator(device="cpu").manual_seed(3)
@@ -366,12 +407,14 @@ def test_fused_reduce_sgd(gpu_lib):
     w1, g1 = w0.clone(), grads.clone()
     sh1 = torch.zeros(total, dtype=torch.bfloat16, device=DEV)
     wT = torch.zeros(2, 25 * c1 * c2, dtype=torch.bfloat16, device=DEV)
+    owT = torch.zeros(10, H, device=DEV)
     state = torch.zeros(8, dtype=torch.int64, device=DEV)
     pa = (ctypes.c_void_p * 3)(*[p.data_ptr() for p in parts])
     check(gpu_lib.dtf_fused_reduce_sgd(3, pa, (ctypes.c_int * 3)(5, 33, 7), (ctypes.c_int * 3)(n_head, n_c2, n_c1),
                                        (ctypes.c_long * 3)(n_head, n_c2, n_c1), (ctypes.c_long * 3)(offs[0], offs[2], offs[3]),
                                        ptr(w1), ptr(g1), ptr(sh1), ptr(hyper), offs[1], offs[2], ptr(wT), offs[2], c1, c2,
-                                       ptr(state), 100, 1, 1, stream()), "fused")
+                                       ptr(owT), offs[0], H, ptr(state), 100, 1, 1, stream()), "fused")
+    assert torch.equal(owT, w_ref[:H * 10].reshape(H, 10).t().contiguous())
     assert torch.equal(g1, g_ref) and torch.equal(w1, w_ref) and torch.equal(sh1, sh_ref)
     f_ref, d_ref = R.conv2_pack_reference(sh_ref[offs[2]:offs[2] + 25 * c1 * c2].reshape(25, c1, c2))
     assert torch.equal(wT[0], f_ref) and torch.equal(wT[1], d_ref)
