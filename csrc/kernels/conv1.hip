@@ -55,6 +55,14 @@ __global__ __launch_bounds__(256) void conv1_pool_fwd(const bf16* __restrict__ i
   const int g = lane >> 4, i16 = lane & 15;
   const int cchunk = blockIdx.y;   // 32-channel chunk
 
+  // The image row of this workgroup depends on the device sample cursor (load -> 64-bit divide ->
+  // Feistel -> image load): start that chain first, the weight loads below overlap with it.
+  uint32_t s_epoch = 0, s_pos = 0;
+  if (smp.state) {   // one 64-bit division per thread, once; everything after is 32-bit
+    const uint64_t c = (uint64_t)smp.state[0];
+    s_epoch = (uint32_t)(c / smp.n);
+    s_pos = (uint32_t)(c % smp.n);
+  }
   // weight fragments: lane (n = i16, g) holds k = 8g + j  <->  (ky, kx = j)
   bf16x8 wf[2][2];
   float bv[2];
@@ -70,13 +78,6 @@ __global__ __launch_bounds__(256) void conv1_pool_fwd(const bf16* __restrict__ i
   }
 
   for (int i = tid; i < 32 * kC1Pitch / 8; i += 256) reinterpret_cast<u4*>(img)[i] = (u4){0u, 0u, 0u, 0u};
-
-  uint32_t s_epoch = 0, s_pos = 0;
-  if (smp.state) {   // one 64-bit division per thread, once; everything after is 32-bit
-    const uint64_t c = (uint64_t)smp.state[0];
-    s_epoch = (uint32_t)(c / smp.n);
-    s_pos = (uint32_t)(c % smp.n);
-  }
 
   for (int b = blockIdx.x; b < B; b += gridDim.x) {
     __syncthreads();   // previous image consumed / zero fill done
