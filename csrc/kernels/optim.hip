@@ -188,9 +188,24 @@ __global__ __launch_bounds__(256) void fused_reduce_sgd(FusedSgdArgs a) {
     const int col = threadIdx.x & 15, grp = threadIdx.x >> 4;
     const long i4 = (long)blk * 16 + col;
     f32x4 a0 = {0.f, 0.f, 0.f, 0.f}, a1 = a0;
+    const long e0 = sg.arena_off + i4 * 4;
+    f32x4 wv = {0.f, 0.f, 0.f, 0.f};
     if (i4 * 4 < sg.n) {
       const float* p = sg.part + i4 * 4;
+      // the master weight is requested together with the slabs (not after the reduction)
+      if (grp == 0) wv = *reinterpret_cast<const f32x4*>(a.w + e0);
       int gI = grp;
+      if (gI + 48 < sg.G) {   // common case (G >= 64): four loads in flight per thread
+        f32x4 v0 = *reinterpret_cast<const f32x4*>(p + (size_t)gI * sg.stride);
+        f32x4 v1 = *reinterpret_cast<const f32x4*>(p + (size_t)(gI + 16) * sg.stride);
+        f32x4 v2 = *reinterpret_cast<const f32x4*>(p + (size_t)(gI + 32) * sg.stride);
+        f32x4 v3 = *reinterpret_cast<const f32x4*>(p + (size_t)(gI + 48) * sg.stride);
+        a0 += v0;
+        a1 += v1;
+        a0 += v2;
+        a1 += v3;
+        gI += 64;
+      }
       for (; gI + 16 < sg.G; gI += 32) {
         f32x4 v0 = *reinterpret_cast<const f32x4*>(p + (size_t)gI * sg.stride);
         f32x4 v1 = *reinterpret_cast<const f32x4*>(p + (size_t)(gI + 16) * sg.stride);
@@ -205,9 +220,7 @@ __global__ __launch_bounds__(256) void fused_reduce_sgd(FusedSgdArgs a) {
       f32x4 gs = red[0][col];
 #pragma unroll
       for (int t = 1; t < 16; ++t) gs += red[t][col];
-      const long e0 = sg.arena_off + i4 * 4;
       *reinterpret_cast<f32x4*>(a.g + e0) = gs;
-      f32x4 wv = *reinterpret_cast<const f32x4*>(a.w + e0);
 #pragma unroll
       for (int e = 0; e < 4; ++e) wv[e] = fmaf(-lr, gs[e], wv[e]);
       *reinterpret_cast<f32x4*>(a.w + e0) = wv;
