@@ -57,7 +57,8 @@ def main():
     B = args.per_gpu_batch
     ds = DeviceDataset.synthetic(args.dataset_size, seed=1234)
     eng = HipEngine(spec, B, ds, optimizer=args.optimizer, learning_rate=1e-3, keep_prob=args.keep_prob,
-                    seed=1000 + rank, multi_stream=not args.single_stream, fuse_dense_update=(world == 1))
+                    seed=1000 + rank, multi_stream=(not args.single_stream) and world == 1,   # DP: measured faster without the fork/join
+                    fuse_dense_update=(world == 1))
     eng.init_params(seed=7)
 
     if world > 1:

@@ -10,7 +10,7 @@ os.environ.setdefault("MASTER_ADDR", "127.0.0.1"); os.environ.setdefault("MASTER
 comm.init_process_group("nccl", 0, 1, device=torch.device("cuda", 0))
 ds = DeviceDataset.synthetic(60000)
 for B in (1024,):
-    eng = HipEngine(ModelSpec(), B, ds); eng.init_params(7)
+    eng = HipEngine(ModelSpec(), B, ds, multi_stream=os.environ.get("DTF_MS", "1") == "1"); eng.init_params(7)
     dp = SyncDataParallel(eng, tail_group=dist.new_group())
     for _ in range(20): dp.train_step()
     torch.cuda.synchronize(); t0 = time.perf_counter()
