@@ -126,11 +126,13 @@ static int backward_conv_impl(const DtfEngineDesc* e, const void* images, const 
   DTF_TRY(dtf_conv1_wgrad(images, idx, e->dp1, e->arg1, e->c1_part, e->B, e->c1, e->c1_g, s));
   if (e->multi_stream) HIP_TRY(hipStreamWaitEvent(s, e->ev_join2, 0));
   if (!reduce) return 0;
-  const void* part[2] = {e->c2_part, e->c1_part};
-  void* out[2] = {f32at(e->grads, e->off_wc2), f32at(e->grads, e->off_wc1)};
-  int G[2] = {e->c2_g, e->c1_g}, n[2] = {(int)e->c2_stride, (int)e->c1_stride};
-  long st[2] = {e->c2_stride, e->c1_stride};
-  return dtf_reduce_segments(2, part, out, G, n, st, s);
+  // reduce == 2: the head slabs (written by backward_dense with reduce == 0) are summed here too, in
+  // the same launch -- the data-parallel step needs head + conv reduced only for its tail collective
+  const void* part[3] = {e->c2_part, e->c1_part, e->head_part};
+  void* out[3] = {f32at(e->grads, e->off_wc2), f32at(e->grads, e->off_wc1), f32at(e->grads, e->off_out_w)};
+  int G[3] = {e->c2_g, e->c1_g, e->head_ks}, n[3] = {(int)e->c2_stride, (int)e->c1_stride, (int)e->head_stride};
+  long st[3] = {e->c2_stride, e->c1_stride, e->head_stride};
+  return dtf_reduce_segments(reduce == 2 ? 3 : 2, part, out, G, n, st, s);
 }
 int dtf_engine_backward_conv(const DtfEngineDesc* e, const void* images, const void* idx, int record_dgrad,
                              hipStream_t s) {
@@ -233,12 +235,13 @@ int dtf_engine_train_step(const DtfEngineDesc* e, long step_inc, hipStream_t s) 
   int G[3] = {e->head_ks, e->c2_g, e->c1_g}, n[3] = {(int)e->head_stride, (int)e->c2_stride, (int)e->c1_stride};
   long st[3] = {e->head_stride, e->c2_stride, e->c1_stride};
   long off[3] = {e->off_out_w, e->off_wc2, e->off_wc1};
-  return dtf_fused_reduce_sgd(3, part, G, n, st, off, e->params, e->grads, e->shadow, e->hyper, e->off_wd1, e->off_wc2,
+  return dtf_fused_reduce_sgd(3, part, G, n, st, off, e->params, e->grads, e->shadow, e->hyper, e->off_wd1, e->off_out_w,
                               e->wc2T, e->off_wc2, e->c1, e->c2, e->out_wT, e->off_out_w, e->hidden, e->state, e->B, step_inc, 1, s);
 }
 
 // ---------------------------------------------------------------------------------------------
-// Data-parallel step choreography (parallel/sync_dp.py).  The step is three native calls around
+// Data-parallel step choreography (parallel/sync_dp.py).  Arena = [wd1 | head | conv2 | conv1]: the dense
+// collective is wd1 alone (12.8 MB), the tail collective everything else (0.3 MB).  The step is three native calls around
 // the two collectives that Python issues through torch.distributed (RCCL): every kernel launch,
 // stream wait and event record of the overlap schedule happens here, so the host cost of a step is
 // 3 foreign calls + 2 all-reduce enqueues.  s = compute stream, comm = dense all-reduce + dense
@@ -256,14 +259,14 @@ int dtf_engine_dp_phase1(const DtfEngineDesc* e, int wait_dense_updated, hipStre
   DTF_TRY(dtf_conv2_fwd(e->p1, e->wc2T, f32at(e->params, e->off_bc2), e->p2, e->arg2, e->B, e->c1, e->c2, s));
   if (wait_dense_updated) HIP_TRY(hipStreamWaitEvent(s, e->ev_dense_updated, 0));
   DTF_TRY(dtf_engine_forward_dense(e, e->ds_labels, e->idx, 1, e->B, 1, s));
-  DTF_TRY(backward_dense_impl(e, 1, s));
+  DTF_TRY(backward_dense_impl(e, 0, s));   // the head slabs are reduced with the conv slabs in phase 2
   HIP_TRY(hipEventRecord(e->ev_dense_ready, s));
   return (int)hipStreamWaitEvent(comm, e->ev_dense_ready, 0);
 }
 
 int dtf_engine_dp_phase2(const DtfEngineDesc* e, long dense_hi, int dense_adam_slot, hipStream_t s, hipStream_t comm,
                          hipStream_t tail) {
-  DTF_TRY(backward_conv_impl(e, e->ds_images, e->idx, 1, 1, s));
+  DTF_TRY(backward_conv_impl(e, e->ds_images, e->idx, 1, 2, s));
   HIP_TRY(hipEventRecord(e->ev_tail_ready, s));
   // the dense update overwrites the bf16 wd1 that fc1 dgrad reads: order it after that kernel
   HIP_TRY(hipStreamWaitEvent(comm, e->ev_dgrad, 0));
@@ -276,15 +279,17 @@ int dtf_engine_dp_phase3(const DtfEngineDesc* e, long dense_hi, int tail_adam_sl
                          hipStream_t s, hipStream_t tail) {
   HIP_TRY(hipEventRecord(e->ev_tail_reduced, tail));
   HIP_TRY(hipStreamWaitEvent(s, e->ev_tail_reduced, 0));
-  if (e->optimizer == 0 && dense_hi == e->off_wc2) {
-    // SGD: update + bf16 shadow + wc2 repack of the (already all-reduced) conv tail in one launch --
-    // the fused tail kernel with the gradient arena itself as a single "slab" per segment
-    const void* part[2] = {f32at(e->grads, e->off_wc2), f32at(e->grads, e->off_wc1)};
-    int G[2] = {1, 1}, n[2] = {(int)e->c2_stride, (int)e->c1_stride};
-    long st[2] = {e->c2_stride, e->c1_stride};
-    long off[2] = {e->off_wc2, e->off_wc1};
-    DTF_TRY(dtf_fused_reduce_sgd(2, part, G, n, st, off, e->params, e->grads, e->shadow, e->hyper, e->off_wc2,
-                                 e->off_wc2, e->wc2T, e->off_wc2, e->c1, e->c2, nullptr, 0, 0, e->state, e->B, step_inc, 1, s));
+  if (e->optimizer == 0 && dense_hi == e->off_out_w) {
+    // SGD: update + bf16 shadow + wc2 repack + out_w transpose of the (already all-reduced) tail
+    // (head | conv2 | conv1) in one launch -- the fused tail kernel with the gradient arena itself as
+    // a single "slab" per segment
+    const void* part[3] = {f32at(e->grads, e->off_out_w), f32at(e->grads, e->off_wc2), f32at(e->grads, e->off_wc1)};
+    int G[3] = {1, 1, 1}, n[3] = {(int)e->head_stride, (int)e->c2_stride, (int)e->c1_stride};
+    long st[3] = {e->head_stride, e->c2_stride, e->c1_stride};
+    long off[3] = {e->off_out_w, e->off_wc2, e->off_wc1};
+    DTF_TRY(dtf_fused_reduce_sgd(3, part, G, n, st, off, e->params, e->grads, e->shadow, e->hyper, e->off_wc2,
+                                 e->off_wc2, e->wc2T, e->off_wc2, e->c1, e->c2, e->out_wT, e->off_out_w, e->hidden,
+                                 e->state, e->B, step_inc, 1, s));
   } else {
     DTF_TRY(dtf_engine_update_range(e, dense_hi, e->n_total, 1, 1, step_inc, tail_adam_slot, s));
     DTF_TRY(dtf_engine_transposes(e, 1, s));

@@ -101,17 +101,18 @@ def _align4(n: int) -> int:
 class ArenaLayout:
     """Flat fp32 arena holding every trainable tensor.
 
-    Order = the order in which backward finalises gradients (head, fc1, conv2,
-    conv1), so the first bytes of the gradient arena are ready first and the
-    all-reduce of the dominant ``wd1`` gradient (98 % of the payload) overlaps
-    with the conv backward kernels.  Each tensor starts on a 16-byte boundary.
+    ``wd1`` comes first: its gradient is 98 % of the payload and is final right after the
+    fc1 wgrad GEMM, so ONE collective over [0, |wd1|) overlaps with the whole conv backward.
+    Everything else (head = out_w|out_b|bd1, then conv2, conv1 -- 0.25 MB in total) follows
+    contiguously and travels as one small tail collective, after one slab reduction and before one
+    fused update.  Each tensor starts on a 16-byte boundary.
     The split-K slabs written by the wgrad kernels use the same relative layout
     as the arena segments they reduce into (head = out_w|out_b|bd1, conv2 =
     wc2|bc2, conv1 = wc1|bc1).
     """
 
     spec: ModelSpec
-    order: Tuple[str, ...] = ("out_w", "out_b", "bd1", "wd1", "wc2", "bc2", "wc1", "bc1")
+    order: Tuple[str, ...] = ("wd1", "out_w", "out_b", "bd1", "wc2", "bc2", "wc1", "bc1")
     offsets: Dict[str, int] = field(default_factory=dict)
     sizes: Dict[str, int] = field(default_factory=dict)
     total: int = 0

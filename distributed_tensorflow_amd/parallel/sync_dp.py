@@ -7,19 +7,20 @@ the ``replica_device_setter`` placement (reference .idea/MNISTDist.py:110-111):
 parameters are replicated, and each step moves ONE gradient arena through RCCL.
 
 Design for xGMI (point-to-point links, ring collectives are per-link bound):
-  * the arena is laid out in backward order, so the head|wd1 prefix -- 98 % of
-    the bytes -- is final right after the fc1 wgrad GEMM.  It is all-reduced on a
+  * the arena starts with wd1 -- 98 % of the bytes -- whose gradient is final
+    right after the fc1 wgrad GEMM.  It is all-reduced on a
     dedicated comm stream while the conv backward kernels still run on the
     compute stream.  One producer kernel finalises the whole prefix at once, so
     the default is ONE large collective (RCCL pipelines it internally over the
     xGMI links; every extra collective costs launch latency on both host and
     device); ``bucket_mb`` can split it for experiments;
-  * the small conv tail goes out as one last bucket;
+  * everything else (head + conv tensors, 0.3 MB, contiguous behind wd1) goes out as
+    one last bucket after a single slab reduction, and is updated by one fused launch;
   * buckets are byte ranges of the flat arena (no per-tensor collectives, no
     copies: RCCL reduces in place);
   * the optimizer kernel applies the 1/world scaling (hyper[4]), so no extra
     pass touches the gradients;
-  * the update of the dense (head|wd1) range runs on the comm stream right behind
+  * the update of the dense (wd1) range runs on the comm stream right behind
     its all-reduce and is only waited for by the NEXT step's fc1 forward, so the
     big all-reduce also hides behind the next step's sampler + conv forward.
 """
@@ -51,14 +52,14 @@ class SyncDataParallel:
     Timeline of step t (compute stream C, comm streams A and B):
 
       C: sample, conv1, conv2 fwd            | needs only the conv params (updated at the end of t-1)
-      C: wait(dense params of t-1 updated)   | the dominant all-reduce of step t-1 has had the whole
+      C: wait(wd1 of t-1 updated)            | the dominant all-reduce of step t-1 has had the whole
       C: fc1 fwd, head fwd/bwd               |   conv backward of t-1 AND the conv forward of t to finish
-      C: head wgrad, slab reduce, fc1 wgrad  -> event dense_ready
-      A:   all-reduce(head|wd1 buckets) ... then (after fc1 dgrad has read the old weights)
+      C: head wgrad (slabs), fc1 wgrad       -> event dense_ready
+      A:   all-reduce(wd1 buckets) ... then (after fc1 dgrad has read the old weights)
       A:   optimizer on the dense range (fp32 master + bf16 copy) -> event dense_updated
-      C: fc1 dgrad, conv2 dgrad || wgrad, conv1 wgrad, slab reduce -> event tail_ready
-      B:   all-reduce(conv tail)   (second communicator: runs concurrently with A)
-      C: wait(B); optimizer on the conv tail (+ cursor / global_step advance), wc2 transpose
+      C: fc1 dgrad, conv2 dgrad, conv2 wgrad, conv1 wgrad, ONE slab reduce (head + conv) -> event tail_ready
+      B:   all-reduce(head + conv tail)   (second communicator: runs concurrently with A)
+      C: wait(B); ONE fused launch: optimizer on the tail, state advance, wc2 repack, out_w transpose
 
     Semantics are exactly synchronous SGD/Adam (no stale gradients): only the *placement* of the
     dense update moves, hidden behind work that does not read those weights.
@@ -76,7 +77,7 @@ class SyncDataParallel:
         self.tail_stream = torch.cuda.Stream(engine.device) if tail_group is not None else self.comm_stream
         self.defer = defer_dense_update
         lay = engine.layout
-        self.n_dense = lay.segment("out_w", "wd1")[1]
+        self.n_dense = lay.segment("wd1", "wd1")[1]     # the dense collective covers wd1 only; head + conv form the tail
         be = max(1, int(bucket_mb * (1 << 20) / 4)) & ~3
         self.dense_buckets = make_buckets(0, self.n_dense, be)
         self.tail_bucket = (self.n_dense, lay.total)

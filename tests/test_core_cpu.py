@@ -100,12 +100,12 @@ def test_spec_matches_reference_contract():
     fwd, fb = s.flops_per_image()
     assert round(fwd / 1e6, 2) == 27.77
     lay = ArenaLayout(s)
-    assert lay.order[0] == "out_w" and lay.order[3] == "wd1"      # backward order
+    assert lay.order[0] == "wd1" and lay.order[1] == "out_w"      # dominant gradient first, small tail after
     assert all(o % 4 == 0 for o in lay.offsets.values())
     arena = torch.arange(lay.total, dtype=torch.float32)
     assert lay.view(arena, "wd1").shape == (3136, 1024) and lay.view(arena, "wc1").shape == (5, 5, 1, 32)
     lo, hi = lay.segment("out_w", "bd1")
-    assert (lo, hi) == (0, 1024 * 10 + 12 + 1024)
+    assert (lo, hi) == (3136 * 1024, 3136 * 1024 + 1024 * 10 + 12 + 1024)
     w = ModelSpec.wide()
     assert (w.c1, w.c2, w.hidden, w.flat) == (128, 256, 4096, 12544)
     assert list(TF_VARIABLE_NAMES.values()) == ["Variable"] + [f"Variable_{i}" for i in range(1, 9)]
@@ -217,7 +217,7 @@ def test_oracle_sgd_and_adam_learn():
 def test_bucket_plan_covers_arena_in_backward_order():
     from distributed_tensorflow_amd.parallel.sync_dp import make_buckets
     lay = ArenaLayout(ModelSpec())
-    n_dense = lay.segment("out_w", "wd1")[1]
+    n_dense = lay.segment("wd1", "wd1")[1]
     b = make_buckets(0, n_dense, 1 << 20)
     assert b[0][0] == 0 and b[-1][1] == n_dense and all(b[i][1] == b[i + 1][0] for i in range(len(b) - 1))
     assert len(b) == 4 and max(hi - lo for lo, hi in b) <= 1 << 20
