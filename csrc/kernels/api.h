@@ -14,6 +14,9 @@ int dtf_conv1_wgrad(const void* images, const void* idx, const void* gpool, cons
 int dtf_conv2_pack_weights(const void* w, void* packed, int cin, int cout, hipStream_t s);
 int dtf_conv2_fwd(const void* x, const void* wT, const void* bias, void* pooled, void* arg, int B, int cin, int cout,
                   hipStream_t s);
+int dtf_conv12_fwd(const void* images, const void* idx, void* idx_out, const void* state, unsigned n, unsigned hb,
+                   unsigned seed, int shuffle, const void* w1, const void* b1, void* p1, void* arg1, const void* wT,
+                   const void* bias2, void* p2, void* arg2, int B, hipStream_t s);
 int dtf_conv2_dgrad(const void* gpool, const void* arg, const void* w, void* dx, int B, int cin,
                     int cout, hipStream_t s);
 int dtf_conv2_wgrad(const void* x, const void* gpool, const void* arg, void* part, int B, int cin,

@@ -12,7 +12,7 @@
 // GEMM-shaped (K = all positions of the batch), so it runs on the matrix cores --
 // see conv1_wgrad below.  Each block accumulates a private [26][C] slab over its
 // images; reduce_segments sums the slabs.
-#include "common.hpp"
+#include "conv1_core.hpp"
 
 namespace dtf {
 
@@ -27,19 +27,6 @@ namespace dtf {
 //   max-pool + argmax are in-register, and one lane produces four pooled columns of its channel.
 //   The pooled row is staged through wave-private LDS and leaves as 16-byte stores.
 // grid-stride over images; 4 waves split the 14 row pairs.  w: fp32 HWIO [25][C] (rounded to bf16).
-constexpr int kC1Pitch = 96;   // pixels per padded LDS row (48 dwords: rows of lane groups g, g+1 never share a bank)
-
-// Fused batch sampler (state != nullptr): the block derives the dataset row of image b from the
-// device-resident sample cursor itself -- the stateless Feistel epoch shuffle of data.hip's
-// sample_indices, bit for bit -- and publishes it in idx_out[b] for the later consumers of the
-// batch (head labels, conv1 wgrad).  This removes the sampler launch from the head of every step.
-struct SampleArgs {
-  const int64_t* state;   // nullptr: rows come from idx (or are 0..B-1)
-  int* idx_out;
-  uint32_t n, hb, seed;
-  int shuffle;
-};
-
 template <int C>
 __global__ __launch_bounds__(256) void conv1_pool_fwd(const bf16* __restrict__ images,
                                                       const int* __restrict__ idx, SampleArgs smp,
@@ -48,49 +35,22 @@ __global__ __launch_bounds__(256) void conv1_pool_fwd(const bf16* __restrict__ i
                                                       bf16* __restrict__ pooled,
                                                       uint8_t* __restrict__ arg, int B) {
   typedef __attribute__((ext_vector_type(4))) unsigned int u4;
-  __shared__ __attribute__((aligned(16))) bf16 img[32 * kC1Pitch];          // 6 KB, zero halo
+  __shared__ __attribute__((aligned(16))) bf16 img[kC1ImgElems];            // 6 KB, zero halo
   __shared__ __attribute__((aligned(16))) bf16 orow[4][16 * 32];            // per wave: pooled row [px][32 ch]
   __shared__ __attribute__((aligned(16))) uint8_t arow[4][16 * 32];
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int g = lane >> 4, i16 = lane & 15;
   const int cchunk = blockIdx.y;   // 32-channel chunk
 
   // The image row of this workgroup depends on the device sample cursor (load -> 64-bit divide ->
   // Feistel -> image load): start that chain first, the weight loads below overlap with it.
-  uint32_t s_epoch = 0, s_pos = 0;
-  if (smp.state) {   // one 64-bit division per thread, once; everything after is 32-bit
-    const uint64_t c = (uint64_t)smp.state[0];
-    s_epoch = (uint32_t)(c / smp.n);
-    s_pos = (uint32_t)(c % smp.n);
-  }
-  // weight fragments: lane (n = i16, g) holds k = 8g + j  <->  (ky, kx = j)
-  bf16x8 wf[2][2];
-  float bv[2];
-#pragma unroll
-  for (int nt = 0; nt < 2; ++nt) {
-    const int n = cchunk * 32 + nt * 16 + i16;
-    bv[nt] = bias[n];
-#pragma unroll
-    for (int j = 0; j < 8; ++j) {
-      wf[0][nt][j] = (j < 5) ? (bf16)w[(g * 5 + j) * C + n] : (bf16)0.f;
-      wf[1][nt][j] = (j < 5 && g == 0) ? (bf16)w[(20 + j) * C + n] : (bf16)0.f;
-    }
-  }
+  const SampleCursor cur = sample_cursor(smp);
+  const Conv1Frags frags = conv1_load_frags(w, bias, C, cchunk, lane);
 
-  for (int i = tid; i < 32 * kC1Pitch / 8; i += 256) reinterpret_cast<u4*>(img)[i] = (u4){0u, 0u, 0u, 0u};
+  for (int i = tid; i < kC1ImgElems / 8; i += 256) reinterpret_cast<u4*>(img)[i] = (u4){0u, 0u, 0u, 0u};
 
   for (int b = blockIdx.x; b < B; b += gridDim.x) {
     __syncthreads();   // previous image consumed / zero fill done
-    size_t row;
-    if (smp.state) {
-      const uint32_t at = s_pos + (uint32_t)b;        // batches may span epochs (B can exceed n)
-      const uint32_t epoch = s_epoch + at / smp.n, pos = at % smp.n;
-      const uint32_t r = smp.shuffle ? feistel_permute(pos, smp.n, smp.hb, mix32(smp.seed + epoch * 0x9E3779B9u)) : pos;
-      if (tid == 0 && blockIdx.y == 0) smp.idx_out[b] = (int)r;
-      row = r;
-    } else {
-      row = idx ? (size_t)idx[b] : (size_t)b;
-    }
+    const size_t row = sample_row(smp, cur, idx, b, tid == 0 && blockIdx.y == 0);
     const unsigned* src = reinterpret_cast<const unsigned*>(images + row * 784);
     for (int i = tid; i < 392; i += 256) {   // 2 pixels (one dword) per thread-iteration
       int y = i / 14, x2 = i % 14;
@@ -98,48 +58,7 @@ __global__ __launch_bounds__(256) void conv1_pool_fwd(const bf16* __restrict__ i
     }
     __syncthreads();
     for (int rp = wave; rp < 14; rp += 4) {
-      f32x4 acc[2][2][2];   // [out row][E/O][n-tile]
-#pragma unroll
-      for (int a = 0; a < 2; ++a)
-#pragma unroll
-        for (int e = 0; e < 2; ++e)
-#pragma unroll
-          for (int nt = 0; nt < 2; ++nt) acc[a][e][nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-      for (int orow_i = 0; orow_i < 2; ++orow_i) {
-#pragma unroll
-        for (int ks = 0; ks < 2; ++ks) {
-          // input row (padded coords) = y + ky, ky = g (ks 0) or 4 (ks 1); pixels 2m .. 2m+9
-          const int r = 2 * rp + orow_i + (ks == 0 ? g : 4);
-          const unsigned* p = reinterpret_cast<const unsigned*>(img) + (r * kC1Pitch) / 2 + i16;
-          unsigned d0 = p[0], d1 = p[1], d2 = p[2], d3 = p[3], d4 = p[4];
-          u4 ev = {d0, d1, d2, d3};
-          u4 od = {__builtin_amdgcn_alignbit(d1, d0, 16), __builtin_amdgcn_alignbit(d2, d1, 16),
-                   __builtin_amdgcn_alignbit(d3, d2, 16), __builtin_amdgcn_alignbit(d4, d3, 16)};
-          bf16x8 ae = __builtin_bit_cast(bf16x8, ev), ao = __builtin_bit_cast(bf16x8, od);
-#pragma unroll
-          for (int nt = 0; nt < 2; ++nt) {
-            acc[orow_i][0][nt] = mfma16(ae, wf[ks][nt], acc[orow_i][0][nt]);
-            acc[orow_i][1][nt] = mfma16(ao, wf[ks][nt], acc[orow_i][1][nt]);
-          }
-        }
-      }
-      // pool: lane (g, i16) owns pooled columns px = 4g + r of channels nt*16 + i16
-#pragma unroll
-      for (int nt = 0; nt < 2; ++nt)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          float v0 = acc[0][0][nt][r], v1 = acc[0][1][nt][r], v2 = acc[1][0][nt][r], v3 = acc[1][1][nt][r];
-          float best = v0;
-          int bi = 0;
-          if (v1 > best) { best = v1; bi = 1; }
-          if (v2 > best) { best = v2; bi = 2; }
-          if (v3 > best) { best = v3; bi = 3; }
-          const int px = 4 * g + r;
-          const float o = fmaxf(best + bv[nt], 0.f);
-          orow[wave][px * 32 + nt * 16 + i16] = (bf16)o;
-          arow[wave][px * 32 + nt * 16 + i16] = (uint8_t)(o > 0.f ? bi : (int)kPoolDead);
-        }
+      conv1_pooled_row(img, rp, frags, orow[wave], arow[wave], lane);
       __builtin_amdgcn_wave_barrier();
       // 14 px x 32 ch: 896 B of bf16 = 56 x 16 B, 448 B of argmax = 28 x 16 B
       const size_t obase = ((size_t)b * 196 + rp * 14) * C + cchunk * 32;

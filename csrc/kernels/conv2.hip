@@ -24,7 +24,7 @@
 //   gfx950 transposing LDS read (ds_read_b64_tr_b16); dY is expanded in LDS only, never in
 //   memory.  Split-K over images across workgroups; partial slabs are summed by
 //   reduce_segments (optim.hip).
-#include "common.hpp"
+#include "conv1_core.hpp"
 
 // Timing-ablation hook (tools/conv_ablate.py builds diagnostic copies with -DDTF_ABLATE=<bits>;
 // the shipped library always has 0): 1 = no B global loads in the k-loop, 2 = no A LDS reads,
@@ -67,11 +67,28 @@ enum { MODE_FWD = 0, MODE_DGRAD = 1 };
 constexpr int igemm_tile_w(int kc) { return kc == 32 ? 20 : kTileW; }
 constexpr int igemm_tile_pos(int kc) { return kc == 32 ? 18 * 20 : kTilePos; }
 
-template <int KTOT, int KC, int NC, int IMGS, int NW, int MODE, int MINW>
+// Fused first conv block (FUSE1, forward only, 1 -> 32 channels): instead of loading the layer
+// input x = pool1 output from memory, the workgroup computes it -- dataset row lookup (batch sampler),
+// 28x28 image -> conv1 + bias + ReLU + max-pool on the matrix cores (conv1_core.hpp) -- and writes each
+// pooled row both to global memory (p1 / arg1, which backward needs) and straight into the LDS tile
+// of this kernel.  Removes one launch and the write -> read round trip of p1 from the forward path.
+struct Conv1Fused {
+  const bf16* images;   // dataset [n][784]
+  const int* idx;       // optional gather (used when smp.state == nullptr)
+  SampleArgs smp;
+  const float* w1;      // fp32 HWIO [25][32]
+  const float* b1;
+  bf16* p1;             // [B,14,14,32]
+  uint8_t* arg1;
+};
+
+template <int KTOT, int KC, int NC, int IMGS, int NW, int MODE, int MINW, bool FUSE1 = false>
 __global__ __launch_bounds__(IMGS * 2 * NW * 64, MINW) void conv5x5_igemm(
     const bf16* __restrict__ in, const uint8_t* __restrict__ in_arg, const bf16* __restrict__ wk,
     const float* __restrict__ bias, bf16* __restrict__ out, uint8_t* __restrict__ out_arg,
-    int B) {
+    int B, Conv1Fused c1f) {
+  static_assert(!FUSE1 || (MODE == MODE_FWD && KTOT == 32 && KC == 32 && NW == 2),
+                "the fused conv1 stage feeds the 32-channel forward tile, 4 waves per image");
   constexpr int NTHREADS = IMGS * 2 * NW * 64;
   constexpr int NT = NC / (16 * NW);   // n-tiles per wave
   constexpr int KSTEPS = KC / 32;      // k-steps per tap
@@ -101,7 +118,7 @@ __global__ __launch_bounds__(IMGS * 2 * NW * 64, MINW) void conv5x5_igemm(
   {
     u32x4 z = {0u, 0u, 0u, 0u};
     u32x4* t4 = reinterpret_cast<u32x4*>(smem);
-    constexpr int N16 = IMGS * TPOS * KP * 2 / 16;
+    constexpr int N16 = (IMGS * TPOS * KP * 2 + (FUSE1 ? IMGS * kC1ImgElems * 2 : 0)) / 16;   // + conv1 images (zero halo)
     for (int i = tid; i < N16; i += NTHREADS) t4[i] = z;
   }
   // lane -> (row m of the 16-row tile, k-group g)
@@ -120,7 +137,44 @@ __global__ __launch_bounds__(IMGS * 2 * NW * 64, MINW) void conv5x5_igemm(
 #pragma unroll 1
   for (int kc0 = 0; kc0 < KTOT; kc0 += KC) {
   __syncthreads();  // zero fill done / previous chunk fully consumed
-  if (MODE == MODE_FWD) {
+  if constexpr (FUSE1) {
+    typedef __attribute__((ext_vector_type(4))) unsigned int u4;
+    constexpr int TILE_BYTES = IMGS * TPOS * KP * 2;
+    bf16* img_all = reinterpret_cast<bf16*>(smem + TILE_BYTES);                                   // [IMGS][32 x 96]
+    bf16* orow_all = reinterpret_cast<bf16*>(smem + TILE_BYTES + IMGS * kC1ImgElems * 2);         // [waves][16 x 32]
+    uint8_t* arow_all = reinterpret_cast<uint8_t*>(orow_all + IMGS * 4 * 512);                     // [waves][16 x 32]
+    bf16* img_w = img_all + w_img * kC1ImgElems;
+    bf16* orow = orow_all + wave * 512;
+    uint8_t* arow = arow_all + wave * 512;
+    const int b = img0 + w_img;
+    const int tid_img = tid & 255, wi = wave & 3;
+    const SampleCursor cur = sample_cursor(c1f.smp);
+    const Conv1Frags frags = conv1_load_frags(c1f.w1, c1f.b1, 32, 0, lane);
+    if (b < B) {
+      const size_t row = sample_row(c1f.smp, cur, c1f.idx, b, tid_img == 0);
+      const unsigned* src = reinterpret_cast<const unsigned*>(c1f.images + row * 784);
+      for (int i = tid_img; i < 392; i += 256)   // 2 pixels (one dword) per thread-iteration
+        reinterpret_cast<unsigned*>(img_w)[((i / 14 + 2) * kC1Pitch + 2) / 2 + i % 14] = src[i];
+    }
+    __syncthreads();
+    for (int rp = wi; rp < 14; rp += 4) {
+      conv1_pooled_row(img_w, rp, frags, orow, arow, lane);
+      __builtin_amdgcn_wave_barrier();
+      if (b < B) {
+        // 14 px x 32 ch: 56 x 16 B of bf16 -> global p1 AND this kernel's LDS tile; 28 x 16 B of argmax codes
+        const size_t obase = ((size_t)b * 196 + rp * 14) * 32;
+        if (lane < 56) {
+          const u4 chunk = reinterpret_cast<const u4*>(orow)[lane];
+          reinterpret_cast<u4*>(c1f.p1 + obase)[lane] = chunk;
+          const int px = lane >> 2, ch = lane & 3;
+          const int tp = (rp + 2) * TW + (px + 2);
+          *reinterpret_cast<u4*>(tile + ((size_t)w_img * TPOS + tp) * KP + (ch ^ ((tp >> 1) & 3)) * 8) = chunk;
+        }
+        if (lane < 28) reinterpret_cast<u4*>(c1f.arg1 + obase)[lane] = reinterpret_cast<const u4*>(arow)[lane];
+      }
+      __builtin_amdgcn_wave_barrier();
+    }
+  } else if (MODE == MODE_FWD) {
     // all loads of a thread are issued before the first LDS write (one memory latency per
     // block, not one per chunk); indices past the end are clamped and their write is skipped
     constexpr int NCHUNK = IMGS * 196 * CH8;
@@ -551,13 +605,16 @@ using namespace dtf;
 
 #define DTF_LAUNCH_CHECK() (int)hipGetLastError()
 
-template <int KTOT, int KC, int NC, int IMGS, int NW, int MODE, int MINW = 1>
+template <int KTOT, int KC, int NC, int IMGS, int NW, int MODE, int MINW = 1, bool FUSE1 = false>
 static int launch_igemm(const void* in, const void* in_arg, const void* wk,
-                        const void* bias, void* out, void* out_arg, int B, hipStream_t s) {
+                        const void* bias, void* out, void* out_arg, int B, hipStream_t s,
+                        Conv1Fused c1f = Conv1Fused{}) {
   constexpr int threads = IMGS * 2 * NW * 64;
   constexpr int KP = (KC % 64 == 0) ? KC + 8 : KC;
-  constexpr size_t lds = (size_t)IMGS * igemm_tile_pos(KC) * KP * 2;
-  auto kern = conv5x5_igemm<KTOT, KC, NC, IMGS, NW, MODE, MINW>;
+  // fused conv1: + zero-haloed input images + per-wave pooled-row staging (bf16 row + argmax row)
+  constexpr size_t lds = (size_t)IMGS * igemm_tile_pos(KC) * KP * 2 +
+                         (FUSE1 ? (size_t)IMGS * kC1ImgElems * 2 + (size_t)IMGS * 4 * (1024 + 512) : 0);
+  auto kern = conv5x5_igemm<KTOT, KC, NC, IMGS, NW, MODE, MINW, FUSE1>;
   static bool attr_set = false;
   if (!attr_set) {
     (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -566,7 +623,7 @@ static int launch_igemm(const void* in, const void* in_arg, const void* wk,
   int grid = (B + IMGS - 1) / IMGS;
   hipLaunchKernelGGL(kern, dim3(grid), dim3(threads), lds, s, (const bf16*)in, (const uint8_t*)in_arg,
                      (const bf16*)wk, (const float*)bias, (bf16*)out,
-                     (uint8_t*)out_arg, B);
+                     (uint8_t*)out_arg, B, c1f);
   return DTF_LAUNCH_CHECK();
 }
 
@@ -588,6 +645,18 @@ int dtf_conv2_fwd(const void* x, const void* wT, const void* bias, void* pooled,
   if (cin == 128 && cout == 256)
     return launch_igemm<128, 128, 256, 1, 4, MODE_FWD>(x, nullptr, wT, bias, pooled, arg, B, s);
   return -1;
+}
+
+// Fused forward of both conv blocks of the 1 -> 32 -> 64 model (see Conv1Fused): images[n][784] (+ idx gather,
+// or the on-device batch sampler when state != NULL: rows from the sample cursor, published in idx_out)
+// -> p1/arg1 [B,14,14,32] and p2/arg2 [B,7,7,64].
+int dtf_conv12_fwd(const void* images, const void* idx, void* idx_out, const void* state, unsigned n, unsigned hb,
+                   unsigned seed, int shuffle, const void* w1, const void* b1, void* p1, void* arg1, const void* wT,
+                   const void* bias2, void* p2, void* arg2, int B, hipStream_t s) {
+  if (state && (!idx_out || n == 0 || (1ull << (2 * hb)) < n)) return -3;
+  Conv1Fused c{(const bf16*)images, (const int*)idx, SampleArgs{(const int64_t*)state, (int*)idx_out, n, hb, seed, shuffle},
+               (const float*)w1, (const float*)b1, (bf16*)p1, (uint8_t*)arg1};
+  return launch_igemm<32, 32, 64, 2, 2, MODE_FWD, 4, true>(nullptr, nullptr, wT, bias2, p2, arg2, B, s, c);
 }
 
 // dgrad: gpool[B,7,7,cout] (+arg code) -> dx[B,14,14,cin]; w = dgrad pack (second half of dtf_conv2_pack_weights)

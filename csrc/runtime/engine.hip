@@ -72,10 +72,28 @@ int dtf_engine_sample(const DtfEngineDesc* e, hipStream_t s) {
   return dtf_sample_indices(e->state, e->idx, e->B, e->ds_n, e->ds_hb, e->sample_seed, e->shuffle, s);
 }
 
-int dtf_engine_forward_conv(const DtfEngineDesc* e, const void* images, const void* idx, int n, hipStream_t s) {
-  DTF_TRY(dtf_conv1_fwd(images, idx, f32at(e->params, e->off_wc1), f32at(e->params, e->off_bc1), e->p1, e->arg1, n,
-                        e->c1, 0, s));
+// both conv blocks; the 1 -> 32 -> 64 model runs them as ONE kernel (conv1 computed inside conv2's
+// staging phase, csrc/kernels/conv2.hip Conv1Fused).  sampled != 0: rows come from the device sample
+// cursor (the batch sampler is part of the kernel) and are published in e->idx.
+static int forward_conv_impl(const DtfEngineDesc* e, const void* images, const void* idx, int sampled, int n,
+                             hipStream_t s) {
+  const void* state = sampled ? e->state : nullptr;
+  if (e->c1 == 32 && e->c2 == 64)
+    return dtf_conv12_fwd(images, sampled ? nullptr : idx, e->idx, state, e->ds_n, e->ds_hb, e->sample_seed, e->shuffle,
+                          f32at(e->params, e->off_wc1), f32at(e->params, e->off_bc1), e->p1, e->arg1, e->wc2T,
+                          f32at(e->params, e->off_bc2), e->p2, e->arg2, n, s);
+  if (sampled)
+    DTF_TRY(dtf_conv1_fwd_sampled(images, e->idx, e->state, e->ds_n, e->ds_hb, e->sample_seed, e->shuffle,
+                                  f32at(e->params, e->off_wc1), f32at(e->params, e->off_bc1), e->p1, e->arg1, n, e->c1,
+                                  0, s));
+  else
+    DTF_TRY(dtf_conv1_fwd(images, idx, f32at(e->params, e->off_wc1), f32at(e->params, e->off_bc1), e->p1, e->arg1, n,
+                          e->c1, 0, s));
   return dtf_conv2_fwd(e->p1, e->wc2T, f32at(e->params, e->off_bc2), e->p2, e->arg2, n, e->c1, e->c2, s);
+}
+
+int dtf_engine_forward_conv(const DtfEngineDesc* e, const void* images, const void* idx, int n, hipStream_t s) {
+  return forward_conv_impl(e, images, idx, 0, n, s);
 }
 
 int dtf_engine_forward_dense(const DtfEngineDesc* e, const void* labels, const void* idx, int backward, int n,
@@ -219,10 +237,7 @@ static int train_tail_fused_dense(const DtfEngineDesc* e, long step_inc, hipStre
 // fused tail: slab reductions + update + bf16 shadow + K-contiguous wc2 copy in one launch.
 int dtf_engine_train_step(const DtfEngineDesc* e, long step_inc, hipStream_t s) {
   // the batch sampler runs inside conv1 forward (rows from the device cursor, published in e->idx)
-  DTF_TRY(dtf_conv1_fwd_sampled(e->ds_images, e->idx, e->state, e->ds_n, e->ds_hb, e->sample_seed, e->shuffle,
-                                f32at(e->params, e->off_wc1), f32at(e->params, e->off_bc1), e->p1, e->arg1, e->B,
-                                e->c1, 0, s));
-  DTF_TRY(dtf_conv2_fwd(e->p1, e->wc2T, f32at(e->params, e->off_bc2), e->p2, e->arg2, e->B, e->c1, e->c2, s));
+  DTF_TRY(forward_conv_impl(e, e->ds_images, nullptr, 1, e->B, s));
   DTF_TRY(dtf_engine_forward_dense(e, e->ds_labels, e->idx, 1, e->B, 1, s));
   if (e->optimizer != 0) {
     DTF_TRY(backward_impl(e, e->ds_images, e->idx, 1, s));
@@ -253,10 +268,7 @@ int dtf_engine_train_step(const DtfEngineDesc* e, long step_inc, hipStream_t s) 
 //   phase3: tail -> ev_tail_reduced ; s waits, updates the conv tail (+ state advance), repacks wc2.
 // ---------------------------------------------------------------------------------------------
 int dtf_engine_dp_phase1(const DtfEngineDesc* e, int wait_dense_updated, hipStream_t s, hipStream_t comm) {
-  DTF_TRY(dtf_conv1_fwd_sampled(e->ds_images, e->idx, e->state, e->ds_n, e->ds_hb, e->sample_seed, e->shuffle,
-                                f32at(e->params, e->off_wc1), f32at(e->params, e->off_bc1), e->p1, e->arg1, e->B,
-                                e->c1, 0, s));
-  DTF_TRY(dtf_conv2_fwd(e->p1, e->wc2T, f32at(e->params, e->off_bc2), e->p2, e->arg2, e->B, e->c1, e->c2, s));
+  DTF_TRY(forward_conv_impl(e, e->ds_images, nullptr, 1, e->B, s));
   if (wait_dense_updated) HIP_TRY(hipStreamWaitEvent(s, e->ev_dense_updated, 0));
   DTF_TRY(dtf_engine_forward_dense(e, e->ds_labels, e->idx, 1, e->B, 1, s));
   DTF_TRY(backward_dense_impl(e, 0, s));   // the head slabs are reduced with the conv slabs in phase 2

@@ -174,6 +174,46 @@ def test_conv2_fwd(gpu_lib, B, C1, C2):
     assert bool(((arg == 4) == (pooled.float() <= 0)).all())
 
 
+@pytest.mark.parametrize("B", [1, 2, 37, 256])
+def test_fused_conv1_conv2_forward_is_bitwise_the_two_kernels(gpu_lib, B):
+    """conv1 computed inside conv2's staging phase (one launch) == conv1_fwd then conv2_fwd, with an
+    explicit gather and with the on-device batch sampler."""
+    from distributed_tensorflow_amd.data import half_bits
+    g = torch.Generator(device="cpu").manual_seed(31)
+    N, seed = 300, 11
+    images = bf(torch.rand(N, 784, generator=g)).to(DEV)
+    w1 = (torch.randn(5, 5, 1, 32, generator=g) * 0.1).to(DEV)
+    b1 = (torch.randn(32, generator=g) * 0.1).to(DEV)
+    _, _, w2, b2 = _conv2_inputs(1, 32, 64, 32)
+    packed = torch.empty(2, 25 * 32 * 64, dtype=torch.bfloat16, device=DEV)
+    check(gpu_lib.dtf_conv2_pack_weights(ptr(w2), ptr(packed), 32, 64, stream()), "pack")
+    state = torch.zeros(8, dtype=torch.int64, device=DEV)
+    state[0] = 250   # spans an epoch boundary for B > 50
+
+    def buffers():
+        return (torch.zeros(B, 14, 14, 32, dtype=torch.bfloat16, device=DEV), torch.zeros(B, 14, 14, 32, dtype=torch.uint8, device=DEV),
+                torch.zeros(B, 7, 7, 64, dtype=torch.bfloat16, device=DEV), torch.zeros(B, 7, 7, 64, dtype=torch.uint8, device=DEV))
+
+    for sampled in (False, True):
+        idx = torch.randint(0, N, (B,), generator=g, dtype=torch.int32).to(DEV)
+        p1, a1, p2, a2 = buffers()
+        if sampled:
+            check(gpu_lib.dtf_sample_indices(ptr(state), ptr(idx), B, N, half_bits(N), seed, 1, stream()), "sample")
+        check(gpu_lib.dtf_conv1_fwd(ptr(images), ptr(idx), ptr(w1), ptr(b1), ptr(p1), ptr(a1), B, 32, 0, stream()), "c1")
+        check(gpu_lib.dtf_conv2_fwd(ptr(p1), ptr(packed[0]), ptr(b2), ptr(p2), ptr(a2), B, 32, 64, stream()), "c2")
+        q1, c1, q2, c2 = buffers()
+        idx_out = torch.full((B,), -1, dtype=torch.int32, device=DEV)
+        check(gpu_lib.dtf_conv12_fwd(ptr(images), None if sampled else ptr(idx), ptr(idx_out), ptr(state) if sampled else None,
+                                     N, half_bits(N), seed, 1, ptr(w1), ptr(b1), ptr(q1), ptr(c1), ptr(packed[0]), ptr(b2),
+                                     ptr(q2), ptr(c2), B, stream()), "fused")
+        torch.cuda.synchronize()
+        assert torch.equal(p1, q1) and torch.equal(a1, c1)
+        assert torch.equal(p2, q2) and torch.equal(a2, c2)
+        if sampled:
+            assert torch.equal(idx_out, idx)
+    assert float(p2.float().abs().sum()) > 0
+
+
 @pytest.mark.parametrize("B,C1,C2", [(1, 32, 64), (5, 32, 64), (32, 32, 64), (3, 128, 256)])
 def test_conv2_backward(gpu_lib, B, C1, C2):
     g, x, w, b = _conv2_inputs(B, C1, C2, 4)
