@@ -94,10 +94,7 @@ __global__ __launch_bounds__(256) void conv1_pool_fwd(const bf16* __restrict__ i
 // A fragment is ONE aligned ds_read_b128.  dY is the max-pool/ReLU-expanded
 // gradient, staged [pos][32 c] in LDS and consumed with ds_read_b64_tr_b16.
 // grid = (G, C/32); part: [G][26*C] fp32 (25 filter taps then the bias row).
-constexpr int kCpPitch = 40;                  // elements per copy row (80 B: conflict-free taps)
-constexpr int kCpStride = 32 * kCpPitch + 8;  // elements per shifted copy
-constexpr int kCpBytes = 5 * kCpStride * 2;   // 12880
-constexpr int kDy1Bytes = 28 * 32 * 32 * 2;   // 57344
+constexpr int kDy1Bytes = 28 * kDy1RowBytes;   // 57344: the whole 28-row gradient tile
 
 template <int C>
 __global__ __launch_bounds__(256) void conv1_wgrad(const bf16* __restrict__ images,
@@ -105,27 +102,13 @@ __global__ __launch_bounds__(256) void conv1_wgrad(const bf16* __restrict__ imag
                                                    const bf16* __restrict__ gpool,
                                                    const uint8_t* __restrict__ arg,
                                                    float* __restrict__ part, int B) {
-  typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
-  typedef __attribute__((ext_vector_type(8))) short s16x8;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   bf16* cp = reinterpret_cast<bf16*>(smem);
   bf16* dyt = reinterpret_cast<bf16*>(smem + kCpBytes);
 
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int g = lane >> 4, i16 = lane & 15, qr = i16 >> 2, pc = i16 & 3;
   const int cchunk = blockIdx.y;
-
-  // A rows of this lane for the two m-tiles
-  int a_off[2];   // element offset of (copy kx, row ky) or -1 = constant fragment
-  bf16x8 a_const[2];
-#pragma unroll
-  for (int mt = 0; mt < 2; ++mt) {
-    int m = mt * 16 + i16;
-    a_off[mt] = (m < 25) ? (m % 5) * kCpStride + (m / 5) * kCpPitch : -1;
-    bf16 cv = (m == 25) ? (bf16)1.0f : (bf16)0.0f;
-#pragma unroll
-    for (int e = 0; e < 8; ++e) a_const[mt][e] = cv;
-  }
+  const Conv1WgradLane L = conv1w_lane(lane);
 
   f32x4 acc[2][2];
 #pragma unroll
@@ -139,8 +122,7 @@ __global__ __launch_bounds__(256) void conv1_wgrad(const bf16* __restrict__ imag
   // Staging.  Every global load of image b+1 (2 pixel pairs of the input, 4 x (8 gradients + 8
   // argmax codes) of the pooled gradient per thread) is issued before the k-loop of image b and
   // only consumed after it: the loop never waits on memory.  The five shifted input copies are
-  // written from the pixel pairs directly (an even shift keeps the pair dword-aligned, an odd one
-  // splits it into two 2-byte stores), not gathered pixel by pixel from global memory.
+  // written from the pixel pairs directly, not gathered pixel by pixel from global memory.
   constexpr int DY_ROUNDS = (196 * 4 + 255) / 256;   // 4
   unsigned px_r[2] = {0u, 0u};
   u32x4 gv_r[DY_ROUNDS];
@@ -161,39 +143,13 @@ __global__ __launch_bounds__(256) void conv1_wgrad(const bf16* __restrict__ imag
   auto stage = [&]() {
 #pragma unroll
     for (int r = 0; r < 2; ++r) {
-      const int i = tid + r * 256;   // pixel pair (y, 2*x2), (y, 2*x2 + 1)
-      if (i < 392) {
-        const int y = i / 14, x = 2 * (i % 14);
-        const unsigned v = px_r[r];
-        bf16* rowp = cp + (y + 2) * kCpPitch;
-#pragma unroll
-        for (int sft = 0; sft < 5; ++sft) {
-          const int c = x - sft + 2;   // column of pixel x in copy sft (copy holds x = c + sft - 2)
-          bf16* dst = rowp + sft * kCpStride + c;
-          if ((sft & 1) == 0) {
-            if (c >= 0 && c < 31) *reinterpret_cast<unsigned*>(dst) = v;
-          } else {
-            if (c >= 0) reinterpret_cast<unsigned short*>(dst)[0] = (unsigned short)(v & 0xffffu);
-            if (c + 1 >= 0 && c + 1 < 32) reinterpret_cast<unsigned short*>(dst)[1] = (unsigned short)(v >> 16);
-          }
-        }
-      }
+      const int i = tid + r * 256;
+      if (i < 392) conv1w_write_pair(cp, i, px_r[r]);
     }
 #pragma unroll
     for (int r = 0; r < DY_ROUNDS; ++r) {
       const int c = tid + r * 256;
-      if (c < 196 * 4) {
-        const int c8 = c & 3, pp = c >> 2;
-        const int py = pp / 14, px = pp % 14;
-        u32x4 o[4];
-        expand_pool_grad(gv_r[r], ar_r[r], o);
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-          int y = 2 * py + (q >> 1), x = 2 * px + (q & 1);
-          int slot = (((c8 >> 1) ^ ((x >> 3) & 1)) << 1) | (c8 & 1);
-          *reinterpret_cast<u32x4*>(dyt + (y * 32 + x) * 32 + slot * 8) = o[q];
-        }
-      }
+      if (c < 196 * 4) conv1w_expand(dyt, (c >> 2) / 14, (c >> 2) % 14, c & 3, gv_r[r], ar_r[r], 0);
     }
   };
 
@@ -203,55 +159,12 @@ __global__ __launch_bounds__(256) void conv1_wgrad(const bf16* __restrict__ imag
     stage();
     __syncthreads();
     if (b + (int)gridDim.x < B) prefetch(b + gridDim.x);
-    for (int kb = wave; kb < 28; kb += 4) {
-      const int yrow = 2 * (kb >> 1) + (g >> 1);
-      const int xb = (kb & 1) * 16 + 8 * (g & 1);
-      bf16x8 bfrag[2], afrag[2];
-#pragma unroll
-      for (int j = 0; j < 2; ++j) {
-        const bf16* p0 = dyt + (yrow * 32 + xb + qr) * 32 + ((j ^ ((xb >> 3) & 1)) << 4) + pc * 4;
-        s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)p0);
-        s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(p0 + 4 * 32));
-        s16x8 v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
-        bfrag[j] = __builtin_bit_cast(bf16x8, v);
-      }
-#pragma unroll
-      for (int mt = 0; mt < 2; ++mt) {
-        // every lane reads (constant rows read a valid dummy address) and then selects
-        int off = (a_off[mt] >= 0 ? a_off[mt] : 0) + yrow * kCpPitch + xb;
-        bf16x8 v = *reinterpret_cast<const bf16x8*>(cp + off);
-        afrag[mt] = a_off[mt] >= 0 ? v : a_const[mt];
-      }
-#pragma unroll
-      for (int mt = 0; mt < 2; ++mt)
-#pragma unroll
-        for (int j = 0; j < 2; ++j) acc[mt][j] = mfma16(afrag[mt], bfrag[j], acc[mt][j]);
-    }
+    for (int kb = wave; kb < 28; kb += 4) conv1w_kblock(cp, dyt, kb, 0, L, lane, acc);
   }
 
   // cross-wave reduction, then rows m < 26 go to the slab
   __syncthreads();
-  float* red = reinterpret_cast<float*>(smem);  // [4 waves][16][64]
-#pragma unroll
-  for (int mt = 0; mt < 2; ++mt)
-#pragma unroll
-    for (int j = 0; j < 2; ++j)
-#pragma unroll
-      for (int r = 0; r < 4; ++r) red[(wave * 16 + (mt * 2 + j) * 4 + r) * 64 + lane] = acc[mt][j][r];
-  __syncthreads();
-  if (wave != 0) return;
-  float* slab = part + (size_t)blockIdx.x * 26 * C;
-#pragma unroll
-  for (int mt = 0; mt < 2; ++mt)
-#pragma unroll
-    for (int j = 0; j < 2; ++j)
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        int e = ((mt * 2 + j) * 4 + r) * 64 + lane;
-        float s = (red[e] + red[16 * 64 + e]) + (red[32 * 64 + e] + red[48 * 64 + e]);
-        int m = mt * 16 + 4 * g + r;
-        if (m < 26) slab[m * C + cchunk * 32 + j * 16 + i16] = s;
-      }
+  conv1w_reduce_store(acc, reinterpret_cast<float*>(smem), part + (size_t)blockIdx.x * 26 * C, C, cchunk, wave, lane);
 }
 
 }  // namespace dtf

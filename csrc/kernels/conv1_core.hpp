@@ -120,4 +120,123 @@ __device__ __forceinline__ void conv1_pooled_row(const bf16* img, int rp, const 
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// Filter/bias gradient building blocks (see conv1.hip, conv1_wgrad, for the GEMM view), shared with
+// the fused conv2-dgrad -> conv1-wgrad kernel in conv2.hip.
+//   cp  : five column-shifted copies of the zero-haloed image, [5][32 rows][kCpPitch] (+8 pad)
+//   dyt : the pool/ReLU-expanded output gradient, [rows][32 x][32 ch] bf16 with the 16-byte chunk
+//         pair swizzled by (x >> 3) & 1; x = 28..31 and everything outside the image stay zero
+// ---------------------------------------------------------------------------------------------
+constexpr int kCpPitch = 40;                  // elements per copy row (80 B: conflict-free taps)
+constexpr int kCpStride = 32 * kCpPitch + 8;  // elements per shifted copy
+constexpr int kCpBytes = 5 * kCpStride * 2;   // 12880
+constexpr int kDy1RowBytes = 32 * 32 * 2;     // one image row of the gradient tile
+
+struct Conv1WgradLane {
+  int a_off[2];        // element offset of (copy kx, row ky) for the two m-tiles, or -1 = constant fragment
+  bf16x8 a_const[2];   // row 25 = all ones (bias gradient), rows 26.. = zero
+};
+
+__device__ __forceinline__ Conv1WgradLane conv1w_lane(int lane) {
+  const int i16 = lane & 15;
+  Conv1WgradLane L;
+#pragma unroll
+  for (int mt = 0; mt < 2; ++mt) {
+    const int m = mt * 16 + i16;
+    L.a_off[mt] = (m < 25) ? (m % 5) * kCpStride + (m / 5) * kCpPitch : -1;
+    const bf16 cv = (m == 25) ? (bf16)1.0f : (bf16)0.0f;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) L.a_const[mt][e] = cv;
+  }
+  return L;
+}
+
+// pixel pair i (0..391: pixels (y, 2*x2), (y, 2*x2+1), one dword) -> the five shifted copies.  An even
+// shift keeps the pair dword-aligned, an odd one splits it into two 2-byte stores.
+__device__ __forceinline__ void conv1w_write_pair(bf16* cp, int i, unsigned v) {
+  const int y = i / 14, x = 2 * (i % 14);
+  bf16* rowp = cp + (y + 2) * kCpPitch;
+#pragma unroll
+  for (int sft = 0; sft < 5; ++sft) {
+    const int c = x - sft + 2;   // column of pixel x in copy sft (copy holds x = c + sft - 2)
+    bf16* dst = rowp + sft * kCpStride + c;
+    if ((sft & 1) == 0) {
+      if (c >= 0 && c < 31) *reinterpret_cast<unsigned*>(dst) = v;
+    } else {
+      if (c >= 0) reinterpret_cast<unsigned short*>(dst)[0] = (unsigned short)(v & 0xffffu);
+      if (c + 1 >= 0 && c + 1 < 32) reinterpret_cast<unsigned short*>(dst)[1] = (unsigned short)(v >> 16);
+    }
+  }
+}
+
+// item (pooled pixel (py, px), 8-channel chunk c8): 8 pooled gradients + 8 argmax codes -> the four
+// window positions of the gradient tile; y_base = first image row held by dyt
+__device__ __forceinline__ void conv1w_expand(bf16* dyt, int py, int px, int c8, const u32x4& gv, const u32x2& a2,
+                                              int y_base) {
+  u32x4 o[4];
+  expand_pool_grad(gv, a2, o);
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const int y = 2 * py + (q >> 1) - y_base, x = 2 * px + (q & 1);
+    const int slot = (((c8 >> 1) ^ ((x >> 3) & 1)) << 1) | (c8 & 1);
+    *reinterpret_cast<u32x4*>(dyt + (y * 32 + x) * 32 + slot * 8) = o[q];
+  }
+}
+
+// one K block (2 image rows x 16 columns; kb = 2 * row_pair + column_half) of the 32 x 32 output tile
+__device__ __forceinline__ void conv1w_kblock(const bf16* cp, const bf16* dyt, int kb, int y_base,
+                                              const Conv1WgradLane& L, int lane, f32x4 (&acc)[2][2]) {
+  typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
+  typedef __attribute__((ext_vector_type(8))) short s16x8;
+  const int g = lane >> 4, i16 = lane & 15, qr = i16 >> 2, pc = i16 & 3;
+  const int yrow = 2 * (kb >> 1) + (g >> 1);
+  const int xb = (kb & 1) * 16 + 8 * (g & 1);
+  bf16x8 bfrag[2], afrag[2];
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    const bf16* p0 = dyt + ((yrow - y_base) * 32 + xb + qr) * 32 + ((j ^ ((xb >> 3) & 1)) << 4) + pc * 4;
+    s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)p0);
+    s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(p0 + 4 * 32));
+    s16x8 v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+    bfrag[j] = __builtin_bit_cast(bf16x8, v);
+  }
+#pragma unroll
+  for (int mt = 0; mt < 2; ++mt) {
+    // every lane reads (constant rows read a valid dummy address) and then selects
+    const int off = (L.a_off[mt] >= 0 ? L.a_off[mt] : 0) + yrow * kCpPitch + xb;
+    const bf16x8 v = *reinterpret_cast<const bf16x8*>(cp + off);
+    afrag[mt] = L.a_off[mt] >= 0 ? v : L.a_const[mt];
+  }
+#pragma unroll
+  for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) acc[mt][j] = mfma16(afrag[mt], bfrag[j], acc[mt][j]);
+}
+
+// cross-wave (4 waves) reduction through `red` (>= 16 KB of LDS, free to overwrite), then rows
+// m < 26 of the 32 x 32 tile go to the slab [26][C] at channel chunk cchunk.  Call after a barrier.
+__device__ __forceinline__ void conv1w_reduce_store(const f32x4 (&acc)[2][2], float* red, float* slab, int C,
+                                                    int cchunk, int wave, int lane) {
+  const int g = lane >> 4, i16 = lane & 15;
+#pragma unroll
+  for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) red[(wave * 16 + (mt * 2 + j) * 4 + r) * 64 + lane] = acc[mt][j][r];
+  __syncthreads();
+  if (wave != 0) return;
+#pragma unroll
+  for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int e = ((mt * 2 + j) * 4 + r) * 64 + lane;
+        const float s = (red[e] + red[16 * 64 + e]) + (red[32 * 64 + e] + red[48 * 64 + e]);
+        const int m = mt * 16 + 4 * g + r;
+        if (m < 26) slab[m * C + cchunk * 32 + j * 16 + i16] = s;
+      }
+}
+
 }  // namespace dtf
