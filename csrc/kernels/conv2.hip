@@ -82,13 +82,29 @@ struct Conv1Fused {
   uint8_t* arg1;
 };
 
+// The same fusion in backward (FUSE1 with MODE_DGRAD): the dgrad result dx = gradient wrt pool1 is
+// consumed only by the conv1 filter gradient, so it never leaves the workgroup.  After the k-loop the
+// tile memory is re-used for dx (bf16 [IMGS][196][32]), the five shifted copies of the input image and
+// half of the pool/ReLU-expanded gradient tile at a time (14 rows, LDS budget), and the 4 waves run
+// conv1_core.hpp's wgrad K blocks over the workgroup's images; the workgroup writes one [26][32] slab.
+// Removes a launch and the 12.8 MB write + read of dx.
+struct Conv1WgradFused {
+  const bf16* images;     // dataset [n][784]
+  const int* idx;         // batch gather
+  const uint8_t* arg1;    // [B,14,14,32] argmax codes of pool1
+  float* part;            // [gridDim.x][26 * 32]
+};
+constexpr int kFusedC1wDyRows = 14;
+
 template <int KTOT, int KC, int NC, int IMGS, int NW, int MODE, int MINW, bool FUSE1 = false>
 __global__ __launch_bounds__(IMGS * 2 * NW * 64, MINW) void conv5x5_igemm(
     const bf16* __restrict__ in, const uint8_t* __restrict__ in_arg, const bf16* __restrict__ wk,
     const float* __restrict__ bias, bf16* __restrict__ out, uint8_t* __restrict__ out_arg,
-    int B, Conv1Fused c1f) {
-  static_assert(!FUSE1 || (MODE == MODE_FWD && KTOT == 32 && KC == 32 && NW == 2),
+    int B, Conv1Fused c1f, Conv1WgradFused c1w) {
+  static_assert(!FUSE1 || MODE != MODE_FWD || (KTOT == 32 && KC == 32 && NW == 2),
                 "the fused conv1 stage feeds the 32-channel forward tile, 4 waves per image");
+  static_assert(!FUSE1 || MODE != MODE_DGRAD || (NC == 32 && IMGS * 2 * NW == 4),
+                "the fused conv1 wgrad stage takes 32-channel dx and runs on 4 waves");
   constexpr int NTHREADS = IMGS * 2 * NW * 64;
   constexpr int NT = NC / (16 * NW);   // n-tiles per wave
   constexpr int KSTEPS = KC / 32;      // k-steps per tap
@@ -118,7 +134,7 @@ __global__ __launch_bounds__(IMGS * 2 * NW * 64, MINW) void conv5x5_igemm(
   {
     u32x4 z = {0u, 0u, 0u, 0u};
     u32x4* t4 = reinterpret_cast<u32x4*>(smem);
-    constexpr int N16 = (IMGS * TPOS * KP * 2 + (FUSE1 ? IMGS * kC1ImgElems * 2 : 0)) / 16;   // + conv1 images (zero halo)
+    constexpr int N16 = (IMGS * TPOS * KP * 2 + ((FUSE1 && MODE == MODE_FWD) ? IMGS * kC1ImgElems * 2 : 0)) / 16;   // + conv1 images (zero halo)
     for (int i = tid; i < N16; i += NTHREADS) t4[i] = z;
   }
   // lane -> (row m of the 16-row tile, k-group g)
@@ -137,7 +153,7 @@ __global__ __launch_bounds__(IMGS * 2 * NW * 64, MINW) void conv5x5_igemm(
 #pragma unroll 1
   for (int kc0 = 0; kc0 < KTOT; kc0 += KC) {
   __syncthreads();  // zero fill done / previous chunk fully consumed
-  if constexpr (FUSE1) {
+  if constexpr (FUSE1 && MODE == MODE_FWD) {
     typedef __attribute__((ext_vector_type(4))) unsigned int u4;
     constexpr int TILE_BYTES = IMGS * TPOS * KP * 2;
     bf16* img_all = reinterpret_cast<bf16*>(smem + TILE_BYTES);                                   // [IMGS][32 x 96]
@@ -338,11 +354,75 @@ __global__ __launch_bounds__(IMGS * 2 * NW * 64, MINW) void conv5x5_igemm(
         }
       }
     }
-    __syncthreads();
-    if (!(DTF_ABLATE & 16)) {
+    if constexpr (FUSE1) {
+      // ---- conv1 filter/bias gradient of this workgroup's images, dx taken from LDS ----
+      constexpr int OT_BYTES = IMGS * 196 * NC * 2;
+      bf16* cp = reinterpret_cast<bf16*>(smem + OT_BYTES);
+      bf16* dyt = reinterpret_cast<bf16*>(smem + OT_BYTES + kCpBytes);
       const int nimg = min(IMGS, B - img0);
-      u32x4* gp = reinterpret_cast<u32x4*>(out + (size_t)img0 * 196 * NC);
-      for (int c = tid; c < nimg * 196 * NC / 8; c += NTHREADS) gp[c] = reinterpret_cast<const u32x4*>(ot)[c];
+      // every global load of this phase up front: 2 pixel pairs per image, and the argmax codes of the
+      // (image, tile half, round) items this thread expands
+      unsigned px_r[IMGS][2];
+      u32x2 ar_r[IMGS][2][2];
+#pragma unroll
+      for (int im = 0; im < IMGS; ++im) {
+        const int b = min(img0 + im, B - 1);
+        const unsigned* src = reinterpret_cast<const unsigned*>(c1w.images + (size_t)c1w.idx[b] * 784);
+#pragma unroll
+        for (int r = 0; r < 2; ++r) px_r[im][r] = src[min(tid + r * 256, 391)];
+#pragma unroll
+        for (int half = 0; half < 2; ++half)
+#pragma unroll
+          for (int r = 0; r < 2; ++r) {
+            const int c = min(tid + r * 256, 98 * 4 - 1);
+            ar_r[im][half][r] = *reinterpret_cast<const u32x2*>(c1w.arg1 + ((size_t)b * 196 + half * 98 + (c >> 2)) * 32 + (c & 3) * 8);
+          }
+      }
+      // the copy halos and the x = 28..31 pad of the gradient tile must be zero (this memory held the conv2 tile)
+      for (int i = tid; i < (kCpBytes + kFusedC1wDyRows * kDy1RowBytes) / 16; i += NTHREADS)
+        reinterpret_cast<u32x4*>(smem + OT_BYTES)[i] = (u32x4){0u, 0u, 0u, 0u};
+      const Conv1WgradLane L = conv1w_lane(lane);
+      f32x4 acc1[2][2];
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) acc1[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+      __syncthreads();   // dx complete in ot, zero fill done
+#pragma unroll
+      for (int im = 0; im < IMGS; ++im) {
+        if (im < nimg) {   // uniform
+#pragma unroll
+          for (int r = 0; r < 2; ++r) {
+            const int i = tid + r * 256;
+            if (i < 392) conv1w_write_pair(cp, i, px_r[im][r]);
+          }
+#pragma unroll
+          for (int half = 0; half < 2; ++half) {
+#pragma unroll
+            for (int r = 0; r < 2; ++r) {
+              const int c = tid + r * 256;
+              if (c < 98 * 4) {
+                const int pp = half * 98 + (c >> 2), c8 = c & 3;
+                const u32x4 gv = *reinterpret_cast<const u32x4*>(ot + ((size_t)im * 196 + pp) * NC + c8 * 8);
+                conv1w_expand(dyt, pp / 14, pp % 14, c8, gv, ar_r[im][half][r], half * kFusedC1wDyRows);
+              }
+            }
+            __syncthreads();
+            for (int kb = half * 14 + wave; kb < half * 14 + 14; kb += 4)
+              conv1w_kblock(cp, dyt, kb, half * kFusedC1wDyRows, L, lane, acc1);
+            __syncthreads();
+          }
+        }
+      }
+      conv1w_reduce_store(acc1, reinterpret_cast<float*>(smem + OT_BYTES), c1w.part + (size_t)blockIdx.x * 26 * 32, 32, 0,
+                          wave, lane);
+    } else {
+      __syncthreads();
+      if (!(DTF_ABLATE & 16)) {
+        const int nimg = min(IMGS, B - img0);
+        u32x4* gp = reinterpret_cast<u32x4*>(out + (size_t)img0 * 196 * NC);
+        for (int c = tid; c < nimg * 196 * NC / 8; c += NTHREADS) gp[c] = reinterpret_cast<const u32x4*>(ot)[c];
+      }
     }
   }
 }
@@ -608,12 +688,15 @@ using namespace dtf;
 template <int KTOT, int KC, int NC, int IMGS, int NW, int MODE, int MINW = 1, bool FUSE1 = false>
 static int launch_igemm(const void* in, const void* in_arg, const void* wk,
                         const void* bias, void* out, void* out_arg, int B, hipStream_t s,
-                        Conv1Fused c1f = Conv1Fused{}) {
+                        Conv1Fused c1f = Conv1Fused{}, Conv1WgradFused c1w = Conv1WgradFused{}) {
   constexpr int threads = IMGS * 2 * NW * 64;
   constexpr int KP = (KC % 64 == 0) ? KC + 8 : KC;
   // fused conv1: + zero-haloed input images + per-wave pooled-row staging (bf16 row + argmax row)
-  constexpr size_t lds = (size_t)IMGS * igemm_tile_pos(KC) * KP * 2 +
-                         (FUSE1 ? (size_t)IMGS * kC1ImgElems * 2 + (size_t)IMGS * 4 * (1024 + 512) : 0);
+  constexpr size_t tile_lds = (size_t)IMGS * igemm_tile_pos(KC) * KP * 2;
+  constexpr size_t fwd_extra = (size_t)IMGS * kC1ImgElems * 2 + (size_t)IMGS * 4 * (1024 + 512);
+  // fused conv1 wgrad: dx + shifted image copies + half a gradient tile, aliased over the (dead) conv2 tile
+  constexpr size_t c1w_lds = (size_t)IMGS * 196 * NC * 2 + kCpBytes + (size_t)kFusedC1wDyRows * kDy1RowBytes;
+  constexpr size_t lds = !FUSE1 ? tile_lds : (MODE == MODE_FWD ? tile_lds + fwd_extra : (tile_lds > c1w_lds ? tile_lds : c1w_lds));
   auto kern = conv5x5_igemm<KTOT, KC, NC, IMGS, NW, MODE, MINW, FUSE1>;
   static bool attr_set = false;
   if (!attr_set) {
@@ -623,7 +706,7 @@ static int launch_igemm(const void* in, const void* in_arg, const void* wk,
   int grid = (B + IMGS - 1) / IMGS;
   hipLaunchKernelGGL(kern, dim3(grid), dim3(threads), lds, s, (const bf16*)in, (const uint8_t*)in_arg,
                      (const bf16*)wk, (const float*)bias, (bf16*)out,
-                     (uint8_t*)out_arg, B, c1f);
+                     (uint8_t*)out_arg, B, c1f, c1w);
   return DTF_LAUNCH_CHECK();
 }
 
@@ -667,6 +750,15 @@ int dtf_conv2_dgrad(const void* gpool, const void* arg, const void* w, void* dx,
   if (cin == 128 && cout == 256)
     return launch_igemm<256, 128, 128, 1, 2, MODE_DGRAD>(gpool, arg, w, nullptr, dx, nullptr, B, s);
   return -1;
+}
+
+// Fused conv2 dgrad -> conv1 filter/bias gradient of the 1 -> 32 -> 64 model (see Conv1WgradFused): dx is
+// never written.  part1 must hold ((B + 1) / 2) slabs of 26 * 32 floats (one per workgroup).
+int dtf_conv2_dgrad_conv1_wgrad(const void* gpool, const void* arg2, const void* w, const void* images,
+                                const void* idx, const void* arg1, void* part1, int B, hipStream_t s) {
+  if (!idx) return -3;
+  Conv1WgradFused c{(const bf16*)images, (const int*)idx, (const uint8_t*)arg1, (float*)part1};
+  return launch_igemm<64, 32, 32, 2, 1, MODE_DGRAD, 3, true>(gpool, arg2, w, nullptr, nullptr, nullptr, B, s, Conv1Fused{}, c);
 }
 
 // wgrad partial slabs: part [G][25*cin*cout + cout]

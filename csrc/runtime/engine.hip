@@ -109,6 +109,17 @@ int dtf_engine_forward_dense(const DtfEngineDesc* e, const void* labels, const v
                                 e->dlogits, e->da, n, e->hidden, 1.0f / n, 1.0f / keep, backward, s);
 }
 
+// conv2 dgrad followed by the conv1 filter gradient.  The 1 -> 32 -> 64 model runs both as ONE kernel
+// (dx stays in LDS; csrc/kernels/conv2.hip Conv1WgradFused) which writes exactly (B + 1) / 2 slabs --
+// engine.py sizes c1_g accordingly.
+static int dgrad_conv1_wgrad(const DtfEngineDesc* e, const void* images, const void* idx, hipStream_t s) {
+  if (e->c1 == 32 && e->c2 == 64 && idx && e->c1_g == (e->B + 1) / 2)
+    return dtf_conv2_dgrad_conv1_wgrad(e->dflat, e->arg2, bf16at(e->wc2T, 25L * e->c1 * e->c2), images, idx, e->arg1,
+                                       e->c1_part, e->B, s);
+  DTF_TRY(dtf_conv2_dgrad(e->dflat, e->arg2, bf16at(e->wc2T, 25L * e->c1 * e->c2), e->dp1, e->B, e->c1, e->c2, s));
+  return dtf_conv1_wgrad(images, idx, e->dp1, e->arg1, e->c1_part, e->B, e->c1, e->c1_g, s);
+}
+
 // head wgrad + slab reduce + fc1 wgrad: finalises the (head | wd1) prefix of the gradient arena.
 // reduce == 0 leaves the head slabs unreduced (the fused single-GPU SGD tail sums them itself).
 static int backward_dense_impl(const DtfEngineDesc* e, int reduce, hipStream_t s) {
@@ -140,8 +151,7 @@ static int backward_conv_impl(const DtfEngineDesc* e, const void* images, const 
   }
   DTF_TRY(dtf_conv2_wgrad(e->p1, e->dflat, e->arg2, e->c2_part, e->B, e->c1, e->c2, e->c2_g, s2));
   if (e->multi_stream) HIP_TRY(hipEventRecord(e->ev_join2, s2));
-  DTF_TRY(dtf_conv2_dgrad(e->dflat, e->arg2, bf16at(e->wc2T, 25L * e->c1 * e->c2), e->dp1, e->B, e->c1, e->c2, s));
-  DTF_TRY(dtf_conv1_wgrad(images, idx, e->dp1, e->arg1, e->c1_part, e->B, e->c1, e->c1_g, s));
+  DTF_TRY(dgrad_conv1_wgrad(e, images, idx, s));
   if (e->multi_stream) HIP_TRY(hipStreamWaitEvent(s, e->ev_join2, 0));
   if (!reduce) return 0;
   // reduce == 2: the head slabs (written by backward_dense with reduce == 0) are summed here too, in
@@ -216,8 +226,7 @@ static int train_tail_fused_dense(const DtfEngineDesc* e, long step_inc, hipStre
   DTF_TRY(dtf_gemm_tn_sgd(e->p2, e->da, f32at(e->params, e->off_wd1), bf16at(e->shadow, e->off_wd1), e->hyper, e->flat,
                           e->hidden, e->B, e->flat, e->hidden, e->hidden, s1));
   DTF_TRY(dtf_conv2_wgrad(e->p1, e->dflat, e->arg2, e->c2_part, e->B, e->c1, e->c2, e->c2_g, s2));
-  DTF_TRY(dtf_conv2_dgrad(e->dflat, e->arg2, bf16at(e->wc2T, 25L * e->c1 * e->c2), e->dp1, e->B, e->c1, e->c2, s));
-  DTF_TRY(dtf_conv1_wgrad(e->ds_images, e->idx, e->dp1, e->arg1, e->c1_part, e->B, e->c1, e->c1_g, s));
+  DTF_TRY(dgrad_conv1_wgrad(e, e->ds_images, e->idx, s));
   if (e->multi_stream) {
     HIP_TRY(hipEventRecord(e->ev_join1, s1));
     HIP_TRY(hipEventRecord(e->ev_join2, s2));

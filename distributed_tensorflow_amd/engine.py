@@ -141,7 +141,12 @@ class HipEngine:
         self.c2_g = max(1, min((B + 1) // 2, int(os.environ.get("DTF_C2_G", "64"))))
         self.c2_stride = 25 * C1 * C2 + C2
         self.c2_part = torch.empty((self.c2_g, self.c2_stride), **f32)
-        self.c1_g = max(1, min(B, 512))
+        # conv1 wgrad slabs: the fused conv2-dgrad -> conv1-wgrad kernel of the 32/64 model writes one per
+        # workgroup (2 images each); the stand-alone kernel takes any grid
+        # Measured (bench.py A/B): +2.7 % at batch 256, neutral at 1024, -10 % at 4096+ (lower occupancy of the
+        # dgrad phase, one slab per two images) -> fused up to 1024 images per GPU.  Env var: A/B switch for tools.
+        fused_c1w = (C1, C2) == (32, 64) and B <= 1024 and os.environ.get("DTF_FUSED_C1W", "1") == "1"
+        self.c1_g = (B + 1) // 2 if fused_c1w else max(1, min(B, 512))
         self.c1_stride = 26 * C1
         self.c1_part = torch.empty((self.c1_g, self.c1_stride), **f32)
 

@@ -214,6 +214,34 @@ def test_fused_conv1_conv2_forward_is_bitwise_the_two_kernels(gpu_lib, B):
     assert float(p2.float().abs().sum()) > 0
 
 
+@pytest.mark.parametrize("B", [1, 2, 33, 128])
+def test_fused_conv2_dgrad_conv1_wgrad_matches_the_two_kernels(gpu_lib, B):
+    """dx kept in LDS and consumed by the conv1 filter gradient in the same launch == conv2_dgrad then
+    conv1_wgrad (same arithmetic per image; only the image -> slab assignment differs)."""
+    g = torch.Generator(device="cpu").manual_seed(41)
+    N = 200
+    images = bf(torch.rand(N, 784, generator=g)).to(DEV)
+    idx = torch.randint(0, N, (B,), generator=g, dtype=torch.int32).to(DEV)
+    _, _, w2, _ = _conv2_inputs(1, 32, 64, 42)
+    packed = torch.empty(2, 25 * 32 * 64, dtype=torch.bfloat16, device=DEV)
+    check(gpu_lib.dtf_conv2_pack_weights(ptr(w2), ptr(packed), 32, 64, stream()), "pack")
+    gp = bf(torch.randn(B, 7, 7, 64, generator=g)).to(DEV)
+    arg2 = torch.randint(0, 5, (B, 7, 7, 64), generator=g, dtype=torch.uint8).to(DEV)
+    arg1 = torch.randint(0, 5, (B, 14, 14, 32), generator=g, dtype=torch.uint8).to(DEV)
+    dx = torch.empty(B, 14, 14, 32, dtype=torch.bfloat16, device=DEV)
+    check(gpu_lib.dtf_conv2_dgrad(ptr(gp), ptr(arg2), ptr(packed[1]), ptr(dx), B, 32, 64, stream()), "dgrad")
+    G = (B + 1) // 2
+    ref = torch.zeros(G, 26 * 32, device=DEV)
+    check(gpu_lib.dtf_conv1_wgrad(ptr(images), ptr(idx), ptr(dx), ptr(arg1), ptr(ref), B, 32, G, stream()), "conv1_wgrad")
+    got = torch.full((G, 26 * 32), float("nan"), device=DEV)
+    check(gpu_lib.dtf_conv2_dgrad_conv1_wgrad(ptr(gp), ptr(arg2), ptr(packed[1]), ptr(images), ptr(idx), ptr(arg1),
+                                              ptr(got), B, stream()), "fused")
+    torch.cuda.synchronize()
+    assert bool(torch.isfinite(got).all())
+    assert rel_err(got.sum(0), ref.sum(0)) < 1e-5
+    assert float(ref.sum(0).abs().sum()) > 0
+
+
 @pytest.mark.parametrize("B,C1,C2", [(1, 32, 64), (5, 32, 64), (32, 32, 64), (3, 128, 256)])
 def test_conv2_backward(gpu_lib, B, C1, C2):
     g, x, w, b = _conv2_inputs(B, C1, C2, 4)
