@@ -36,6 +36,7 @@ def main():
     ap.add_argument("--keep_prob", type=float, default=1.0)
     ap.add_argument("--dataset_size", type=int, default=60000)
     ap.add_argument("--single_stream", action="store_true", help="disable the fork/join side streams in backward")
+    ap.add_argument("--multi_stream", action="store_true", help="force the fork/join side streams (default: by batch size)")
     ap.add_argument("--no_graph", action="store_true", help="eager launches instead of HIP-graph replay (1 GPU)")
     args = ap.parse_args()
 
@@ -57,7 +58,9 @@ def main():
     B = args.per_gpu_batch
     ds = DeviceDataset.synthetic(args.dataset_size, seed=1234)
     eng = HipEngine(spec, B, ds, optimizer=args.optimizer, learning_rate=1e-3, keep_prob=args.keep_prob,
-                    seed=1000 + rank, multi_stream=(not args.single_stream) and world == 1,   # DP: measured faster without the fork/join
+                    seed=1000 + rank,
+                    # None = engine default (by batch size); the data-parallel path measured faster without the fork/join
+                    multi_stream=False if (args.single_stream or world > 1) else (True if args.multi_stream else None),
                     fuse_dense_update=(world == 1))
     eng.init_params(seed=7)
 
