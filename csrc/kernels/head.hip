@@ -158,7 +158,7 @@ __global__ __launch_bounds__(256) void head_wgrad(const bf16* __restrict__ h1,
                                                   const bf16* __restrict__ da, float* __restrict__ part,
                                                   int B, int H, int rows_per_split) {
   __shared__ float red[4][64][kCls + 1];
-  const int jc = threadIdx.x & 63, sub = threadIdx.x >> 6;
+  const int jc = threadIdx.x & 63, sub = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // wave-uniform row phase
   const int j = blockIdx.x * 64 + jc;
   const int b0 = blockIdx.y * rows_per_split;
   const int b1 = min(B, b0 + rows_per_split);
@@ -166,7 +166,25 @@ __global__ __launch_bounds__(256) void head_wgrad(const bf16* __restrict__ h1,
 #pragma unroll
   for (int c = 0; c <= kCls; ++c) acc[c] = 0.f;
   if (j < H) {
-    for (int b = b0 + sub; b < b1; b += 4) {
+    // four rows per trip: their activation loads are issued together (a one-row loop was a chain of
+    // dependent-latency trips), and the dlogits row address is wave-uniform -> scalar loads
+    int b = b0 + sub;
+    for (; b + 12 < b1; b += 16) {
+      float hf[4], dv[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        hf[u] = (float)h1[(size_t)(b + 4 * u) * H + j];
+        dv[u] = (float)da[(size_t)(b + 4 * u) * H + j];
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const float* dl = dlogits + (size_t)(b + 4 * u) * kCls;
+#pragma unroll
+        for (int c = 0; c < kCls; ++c) acc[c] = fmaf(hf[u], dl[c], acc[c]);
+        acc[kCls] += dv[u];
+      }
+    }
+    for (; b < b1; b += 4) {
       const float hf = (float)h1[(size_t)b * H + j];
       const float* dl = dlogits + (size_t)b * kCls;
 #pragma unroll
