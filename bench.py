@@ -38,6 +38,7 @@ def main():
     ap.add_argument("--single_stream", action="store_true", help="disable the fork/join side streams in backward")
     ap.add_argument("--multi_stream", action="store_true", help="force the fork/join side streams (default: by batch size)")
     ap.add_argument("--no_graph", action="store_true", help="eager launches instead of HIP-graph replay (1 GPU)")
+    ap.add_argument("--graph", action="store_true", help="force HIP-graph replay (default: only above 1024 images/GPU)")
     args = ap.parse_args()
 
     from distributed_tensorflow_amd.engine import DeviceDataset, HipEngine
@@ -64,12 +65,17 @@ def main():
                     fuse_dense_update=(world == 1))
     eng.init_params(seed=7)
 
+    use_graph = False
     if world > 1:
         dp = SyncDataParallel(eng, tail_group=torch.distributed.new_group())
         dp.broadcast_parameters()
         step = dp.train_step
     else:
-        if not args.no_graph:
+        # The whole step is one foreign call into the native executor either way.  Measured A/B: with the
+        # single-stream 9-kernel step, eager launches run 2.5-5 % faster than replaying the captured graph up
+        # to 1024 images/GPU; from 2048 up the graph (with its backward fork/join) wins by ~6 %.
+        use_graph = args.graph or (not args.no_graph and B > 1024)
+        if use_graph:
             eng.capture()
         step = eng.train_step
 
@@ -111,7 +117,7 @@ def main():
             "data": "synthetic (HBM-resident 28x28x1, random TF-style init)",
             "config": {"model": spec.name, "global_batch": global_batch, "per_gpu_batch": B, "seq_len": None,
                        "parallelism": f"dp{world}", "optimizer": args.optimizer, "keep_prob": args.keep_prob,
-                       "graph": (world == 1 and not args.no_graph)},
+                       "graph": bool(world == 1 and use_graph)},
             "model_tflops": round(value * fb / 1e12, 2),
             "final_loss": round(loss, 4),
         }))
