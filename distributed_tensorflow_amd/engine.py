@@ -140,7 +140,10 @@ class HipEngine:
         self.head_ks = max(1, min(32, B // 8))
         self.head_stride = H * spec.classes + 12 + H
         self.head_part = torch.empty((self.head_ks, self.head_stride), **f32)
-        self.c2_g = max(1, min((B + 1) // 2, int(os.environ.get("DTF_C2_G", "64"))))
+        # conv2 wgrad split-K over images: G slabs x (C1/16 * C2/32) output tiles workgroups.  64 slabs fill the
+        # chip for the 32/64 model (4 tiles); the widened model has 64 tiles and 3.3 MB slabs -> 8 slabs
+        c2_tiles = (C1 // 16) * (C2 // 32)
+        self.c2_g = max(1, min((B + 1) // 2, int(os.environ.get("DTF_C2_G", "64" if c2_tiles <= 4 else "8"))))
         self.c2_stride = 25 * C1 * C2 + C2
         self.c2_part = torch.empty((self.c2_g, self.c2_stride), **f32)
         # conv1 wgrad slabs: the fused conv2-dgrad -> conv1-wgrad kernel of the 32/64 model writes one per
