@@ -221,3 +221,19 @@ def test_bucket_plan_covers_arena_in_backward_order():
     b = make_buckets(0, n_dense, 1 << 20)
     assert b[0][0] == 0 and b[-1][1] == n_dense and all(b[i][1] == b[i + 1][0] for i in range(len(b) - 1))
     assert len(b) == 4 and max(hi - lo for lo, hi in b) <= 1 << 20
+
+
+def test_conv2_pack_reference_matches_the_documented_index_formula():
+    """The fragment-ordered conv2 weight layout (csrc/kernels/conv2.hip pack_conv2_weights) as an explicit
+    index formula vs the reshape/permute reference used by the GPU tests."""
+    from distributed_tensorflow_amd.ops.reference import conv2_pack_reference
+    cin, cout = 32, 64
+    w = torch.arange(25 * cin * cout, dtype=torch.float32).reshape(25, cin, cout)
+    f, d = conv2_pack_reference(w)
+    g = torch.Generator().manual_seed(0)
+    for _ in range(200):
+        tap, ci, co = (int(torch.randint(0, n, (1,), generator=g)) for n in (25, cin, cout))
+        fi = ((tap * (cin // 32) + ci // 32) * (cout // 16) + co // 16) * 512 + (((ci % 32) // 8) * 16 + co % 16) * 8 + ci % 8
+        di = ((tap * (cout // 32) + co // 32) * (cin // 16) + ci // 16) * 512 + (((co % 32) // 8) * 16 + ci % 16) * 8 + co % 8
+        assert f[fi] == w[tap, ci, co] and d[di] == w[tap, ci, co]
+    assert sorted(f.tolist()) == sorted(w.reshape(-1).tolist())   # a permutation
