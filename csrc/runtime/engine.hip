@@ -272,9 +272,9 @@ int dtf_engine_train_step(const DtfEngineDesc* e, long step_inc, hipStream_t s) 
 // update stream, tail = conv-tail all-reduce stream (may equal comm).
 //   phase1: sampler+conv forward | wait(dense params of the previous step) | dense forward, head,
 //           dense wgrads -> ev_dense_ready ; comm waits for it.         [Python: all-reduce dense on comm]
-//   phase2: fc1 dgrad (-> ev_dgrad), conv backward -> ev_tail_ready ; comm: wait ev_dgrad, update
-//           dense range -> ev_dense_updated ; tail waits ev_tail_ready.  [Python: all-reduce tail on tail]
-//   phase3: tail -> ev_tail_reduced ; s waits, updates the conv tail (+ state advance), repacks wc2.
+//   phase2: fc1 dgrad (-> ev_dgrad), conv backward ; comm: wait ev_dgrad, update dense range ->
+//           ev_dense_updated.                       [Python: all-reduce tail, on s itself by default]
+//   phase3: updates the tail (+ state advance), repacks wc2.  (With a separate tail stream: two event pairs.)
 // ---------------------------------------------------------------------------------------------
 int dtf_engine_dp_phase1(const DtfEngineDesc* e, int wait_dense_updated, hipStream_t s, hipStream_t comm) {
   DTF_TRY(forward_conv_impl(e, e->ds_images, nullptr, 1, e->B, s));
@@ -288,18 +288,25 @@ int dtf_engine_dp_phase1(const DtfEngineDesc* e, int wait_dense_updated, hipStre
 int dtf_engine_dp_phase2(const DtfEngineDesc* e, long dense_hi, int dense_adam_slot, hipStream_t s, hipStream_t comm,
                          hipStream_t tail) {
   DTF_TRY(backward_conv_impl(e, e->ds_images, e->idx, 1, 2, s));
-  HIP_TRY(hipEventRecord(e->ev_tail_ready, s));
   // the dense update overwrites the bf16 wd1 that fc1 dgrad reads: order it after that kernel
   HIP_TRY(hipStreamWaitEvent(comm, e->ev_dgrad, 0));
   DTF_TRY(dtf_engine_update_range(e, 0, dense_hi, 0, 0, 0, dense_adam_slot, comm));
   HIP_TRY(hipEventRecord(e->ev_dense_updated, comm));
-  return (int)hipStreamWaitEvent(tail, e->ev_tail_ready, 0);
+  // tail == s: the tail collective is issued on the compute stream itself (everything after it depends on
+  // it anyway), which needs no events at all; a separate tail stream is ordered behind the conv backward
+  if (tail != s) {
+    HIP_TRY(hipEventRecord(e->ev_tail_ready, s));
+    HIP_TRY(hipStreamWaitEvent(tail, e->ev_tail_ready, 0));
+  }
+  return 0;
 }
 
 int dtf_engine_dp_phase3(const DtfEngineDesc* e, long dense_hi, int tail_adam_slot, long step_inc, int wait_dense,
                          hipStream_t s, hipStream_t tail) {
-  HIP_TRY(hipEventRecord(e->ev_tail_reduced, tail));
-  HIP_TRY(hipStreamWaitEvent(s, e->ev_tail_reduced, 0));
+  if (tail != s) {
+    HIP_TRY(hipEventRecord(e->ev_tail_reduced, tail));
+    HIP_TRY(hipStreamWaitEvent(s, e->ev_tail_reduced, 0));
+  }
   if (e->optimizer == 0 && dense_hi == e->off_out_w) {
     // SGD: update + bf16 shadow + wc2 repack + out_w transpose of the (already all-reduced) tail
     // (head | conv2 | conv1) in one launch -- the fused tail kernel with the gradient arena itself as

@@ -58,8 +58,8 @@ class SyncDataParallel:
       A:   all-reduce(wd1 buckets) ... then (after fc1 dgrad has read the old weights)
       A:   optimizer on the dense range (fp32 master + bf16 copy) -> event dense_updated
       C: fc1 dgrad, conv2 dgrad, conv2 wgrad, conv1 wgrad, ONE slab reduce (head + conv) -> event tail_ready
-      B:   all-reduce(head + conv tail)   (second communicator: runs concurrently with A)
-      C: wait(B); ONE fused launch: optimizer on the tail, state advance, wc2 repack, out_w transpose
+      C:   all-reduce(head + conv tail)   (second communicator: runs concurrently with A inside RCCL)
+      C: ONE fused launch: optimizer on the tail, state advance, wc2 repack, out_w transpose
 
     Semantics are exactly synchronous SGD/Adam (no stale gradients): only the *placement* of the
     dense update moves, hidden behind work that does not read those weights.
@@ -74,7 +74,12 @@ class SyncDataParallel:
         self.tail_group = tail_group if tail_group is not None else group
         self.world = dist.get_world_size(group)
         self.comm_stream = torch.cuda.Stream(engine.device)
-        self.tail_stream = torch.cuda.Stream(engine.device) if tail_group is not None else self.comm_stream
+        # The tail collective runs on the COMPUTE stream by default: it sits at the very end of backward and
+        # everything after it depends on it, so a stream of its own buys no overlap and costs four event calls
+        # (5-8 us of host time each on this stack, and the step is host-bound).  What it does need is its own
+        # communicator (tail_group), so that it is not ordered behind the long dense all-reduce inside RCCL.
+        # Without a second communicator it has to queue on the comm stream behind the dense collective.
+        self.tail_stream = None if tail_group is not None else self.comm_stream
         self.defer = defer_dense_update
         lay = engine.layout
         self.n_dense = lay.segment("wd1", "wd1")[1]     # the dense collective covers wd1 only; head + conv form the tail
@@ -104,14 +109,18 @@ class SyncDataParallel:
         eng = self.eng
         lib, d = eng.lib, eng._d()
         cur = torch.cuda.current_stream(eng.device).cuda_stream
-        comm, tail = self.comm_stream.cuda_stream, self.tail_stream.cuda_stream
+        comm = self.comm_stream.cuda_stream
+        tail = cur if self.tail_stream is None else self.tail_stream.cuda_stream
         check(lib.dtf_engine_dp_phase1(d, int(self._have_pending_dense), cur, comm), "dp_phase1")
         with torch.cuda.stream(self.comm_stream):
             for lo, hi in self.dense_buckets:
                 self._allreduce(lo, hi, self.group)
         check(lib.dtf_engine_dp_phase2(d, self.n_dense, self.DENSE_SLOT, cur, comm, tail), "dp_phase2")
-        with torch.cuda.stream(self.tail_stream):
+        if self.tail_stream is None:
             self._allreduce(*self.tail_bucket, self.tail_group)
+        else:
+            with torch.cuda.stream(self.tail_stream):
+                self._allreduce(*self.tail_bucket, self.tail_group)
         check(lib.dtf_engine_dp_phase3(d, self.n_dense, self.TAIL_SLOT, eng.step_inc, int(not self.defer), cur, tail),
               "dp_phase3")
         self._have_pending_dense = self.defer

@@ -21,14 +21,17 @@ def t(fn, n=200):
     torch.cuda.synchronize(); return h / n * 1e6, (time.perf_counter() - t0) / n * 1e6
 lib, d = eng.lib, eng._d()
 cur = torch.cuda.current_stream().cuda_stream
-comm_s, tail_s = dp.comm_stream.cuda_stream, dp.tail_stream.cuda_stream
+comm_s = dp.comm_stream.cuda_stream
+tail_s = cur if dp.tail_stream is None else dp.tail_stream.cuda_stream
 def p1(): check(lib.dtf_engine_dp_phase1(d, 0, cur, comm_s), "p1")
 def p2(): check(lib.dtf_engine_dp_phase2(d, dp.n_dense, 3, cur, comm_s, tail_s), "p2")
 def p3(): check(lib.dtf_engine_dp_phase3(d, dp.n_dense, 4, 1, 0, cur, tail_s), "p3")
 def ar_dense():
     with torch.cuda.stream(dp.comm_stream): dp._allreduce(0, dp.n_dense, dp.group)
 def ar_tail():
-    with torch.cuda.stream(dp.tail_stream): dp._allreduce(*dp.tail_bucket, dp.tail_group)
+    if dp.tail_stream is None: dp._allreduce(*dp.tail_bucket, dp.tail_group)
+    else:
+        with torch.cuda.stream(dp.tail_stream): dp._allreduce(*dp.tail_bucket, dp.tail_group)
 def ctx():
     with torch.cuda.stream(dp.comm_stream): pass
 for name, fn in (("phase1", p1), ("phase2", p2), ("phase3", p3), ("allreduce dense (13 MB)", ar_dense),
