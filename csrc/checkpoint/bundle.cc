@@ -16,6 +16,13 @@
 //     with magic 0xdb4775248b80fb57
 //   * minimal protobuf wire encode/decode for BundleHeaderProto, BundleEntryProto,
 //     TensorShapeProto, VersionDef
+//
+// TF < 0.12 -- the version the reference script was written for (tf.initialize_all_variables,
+// reference .idea/MNISTDist.py:156) -- wrote Saver "V1" files instead: ONE sstable <prefix> whose
+// key "" holds a SavedTensorSlices{meta} proto (names, shapes, dtypes, slices) and whose other keys
+// (OrderedCode(0, name, ndims, start/length per dim)) hold SavedTensorSlices{data} protos with the
+// values in a TensorProto.  Both directions of that are here too (reader_open detects the format),
+// so logdirs written by the reference resume here.
 // Exposed through a C ABI (see bottom) and bound from Python with ctypes.
 #include <algorithm>
 #include <cstdint>
@@ -510,7 +517,275 @@ struct Reader {
   int num_shards = 1;
   std::vector<Entry> entries;  // sorted
   std::string err;
+  bool v1 = false;
+  std::vector<std::string> mem;  // V1: assembled tensor bytes, parallel to entries
 };
+
+// ------------------------------------------------------------------ Saver V1 (tensor-slice files)
+static size_t dtype_size(int dt) {
+  switch (dt) {
+    case 1: case 3: return 4;   // DT_FLOAT, DT_INT32
+    case 2: case 9: return 8;   // DT_DOUBLE, DT_INT64
+    case 4: case 10: return 1;  // DT_UINT8, DT_BOOL
+    default: return 0;
+  }
+}
+
+struct Extent {
+  int64_t start = 0;
+  int64_t length = -1;  // -1: the whole dimension
+};
+
+static bool decode_slice(const uint8_t* b, size_t len, std::vector<Extent>* out) {
+  PbReader r{b, b + len};
+  int f, wt;
+  while (r.next(&f, &wt)) {
+    if (f == 1 && wt == 2) {
+      const uint8_t* eb; size_t el;
+      if (!r.bytes(&eb, &el)) return false;
+      PbReader e{eb, eb + el};
+      Extent x;
+      int f2, wt2;
+      while (e.next(&f2, &wt2)) {
+        if (f2 == 1 && wt2 == 0) x.start = (int64_t)e.varint();
+        else if (f2 == 2 && wt2 == 0) x.length = (int64_t)e.varint();
+        else e.skip(wt2);
+      }
+      if (!e.ok) return false;
+      out->push_back(x);
+    } else {
+      r.skip(wt);
+    }
+  }
+  return r.ok;
+}
+
+// TensorProto -> raw little-endian element bytes of `dtype` (the type comes from the meta entry: the
+// V1 writer fills only the typed *_val field).  Accepts packed and unpacked repeated encodings and
+// tensor_content.
+static bool decode_tensor_proto(const uint8_t* b, size_t len, int dtype, std::string* out) {
+  PbReader r{b, b + len};
+  int f, wt;
+  while (r.next(&f, &wt)) {
+    const bool fixed4 = (f == 5 && dtype == 1), fixed8 = (f == 6 && dtype == 2);
+    const bool vint = (f == 7 && (dtype == 3 || dtype == 4)) || (f == 10 && dtype == 9) || (f == 11 && dtype == 10);
+    if (f == 4 && wt == 2) {  // tensor_content
+      const uint8_t* c; size_t cl;
+      if (!r.bytes(&c, &cl)) return false;
+      out->append((const char*)c, cl);
+    } else if ((fixed4 || fixed8) && wt == 2) {  // packed floats / doubles are already little-endian bytes
+      const uint8_t* c; size_t cl;
+      if (!r.bytes(&c, &cl) || cl % (fixed4 ? 4 : 8)) return false;
+      out->append((const char*)c, cl);
+    } else if (fixed4 && wt == 5) {
+      if (r.end - r.p < 4) return false;
+      out->append((const char*)r.p, 4);
+      r.p += 4;
+    } else if (fixed8 && wt == 1) {
+      if (r.end - r.p < 8) return false;
+      out->append((const char*)r.p, 8);
+      r.p += 8;
+    } else if (vint && (wt == 2 || wt == 0)) {
+      const size_t es = dtype_size(dtype);
+      PbReader v{r.p, r.end};
+      if (wt == 2) {
+        const uint8_t* c; size_t cl;
+        if (!r.bytes(&c, &cl)) return false;
+        v = PbReader{c, c + cl};
+        if (!cl) continue;
+      }
+      do {
+        uint64_t x = v.varint();
+        if (!v.ok) return false;
+        out->append((const char*)&x, es);  // little-endian host: the low `es` bytes are the value
+      } while (wt == 2 && v.p < v.end);
+      if (wt == 0) r.p = v.p;
+    } else {
+      r.skip(wt);
+    }
+  }
+  return r.ok;
+}
+
+// copy a slice (extents `ex`, row-major `src`) into the full row-major tensor `dst` of shape `dims`
+static bool copy_slice(std::string* dst, const std::vector<int64_t>& dims, const std::vector<Extent>& ex,
+                       const std::string& src, size_t es) {
+  const size_t nd = dims.size();
+  if (ex.size() != nd) return false;
+  std::vector<int64_t> start(nd), len(nd);
+  int64_t n = 1;
+  for (size_t d = 0; d < nd; ++d) {
+    start[d] = ex[d].length < 0 ? 0 : ex[d].start;
+    len[d] = ex[d].length < 0 ? dims[d] : ex[d].length;
+    if (start[d] < 0 || len[d] < 0 || start[d] + len[d] > dims[d]) return false;
+    n *= len[d];
+  }
+  if ((uint64_t)n * es != src.size()) return false;
+  if (n == 0) return true;
+  if (nd == 0) { memcpy(&(*dst)[0], src.data(), es); return true; }
+  std::vector<int64_t> stride(nd, 1);
+  for (size_t d = nd - 1; d-- > 0;) stride[d] = stride[d + 1] * dims[d + 1];
+  const size_t run = (size_t)len[nd - 1] * es;
+  std::vector<int64_t> idx(nd, 0);
+  const char* sp = src.data();
+  for (;;) {
+    int64_t off = 0;
+    for (size_t d = 0; d < nd; ++d) off += (start[d] + idx[d]) * stride[d];
+    memcpy(&(*dst)[(size_t)off * es], sp, run);
+    sp += run;
+    size_t d = nd - 1;  // odometer over all dimensions but the last
+    for (;;) {
+      if (d == 0) return true;
+      --d;
+      if (++idx[d] < len[d]) break;
+      idx[d] = 0;
+    }
+  }
+}
+
+static bool load_v1(const std::string& file, Reader* r) {
+  std::vector<std::pair<std::string, std::string>> kv;
+  if (!read_table(file, &kv, &r->err)) return false;
+  std::map<std::string, size_t> by_name;
+  bool have_meta = false;
+  // pass 1: the meta entry (key "") names every tensor with its full shape and type
+  for (auto& e : kv) {
+    if (!e.first.empty()) continue;
+    PbReader top{(const uint8_t*)e.second.data(), (const uint8_t*)e.second.data() + e.second.size()};
+    int f, wt;
+    while (top.next(&f, &wt)) {
+      if (!(f == 1 && wt == 2)) { top.skip(wt); continue; }
+      const uint8_t* mb; size_t ml;
+      if (!top.bytes(&mb, &ml)) break;
+      PbReader m{mb, mb + ml};
+      int f2, wt2;
+      while (m.next(&f2, &wt2)) {
+        if (!(f2 == 1 && wt2 == 2)) { m.skip(wt2); continue; }
+        const uint8_t* tb; size_t tl;
+        if (!m.bytes(&tb, &tl)) break;
+        PbReader t{tb, tb + tl};
+        Entry en;
+        int f3, wt3;
+        while (t.next(&f3, &wt3)) {
+          const uint8_t* xb; size_t xl;
+          if (f3 == 1 && wt3 == 2) { if (t.bytes(&xb, &xl)) en.name.assign((const char*)xb, xl); }
+          else if (f3 == 2 && wt3 == 2) { if (!t.bytes(&xb, &xl) || !decode_shape(xb, xl, &en.dims)) t.ok = false; }
+          else if (f3 == 3 && wt3 == 0) en.dtype = (int)t.varint();
+          else t.skip(wt3);
+        }
+        if (!t.ok) { r->err = "bad SavedSliceMeta"; return false; }
+        const size_t es = dtype_size(en.dtype);
+        if (!es) { r->err = "unsupported dtype in V1 checkpoint for " + en.name; return false; }
+        int64_t n = 1;
+        for (int64_t d : en.dims) n *= d;
+        en.size = n * (int64_t)es;
+        by_name[en.name] = r->entries.size();
+        r->entries.push_back(en);
+        r->mem.emplace_back((size_t)en.size, '\0');
+      }
+      if (!m.ok) { r->err = "bad SavedTensorSliceMeta"; return false; }
+      have_meta = true;
+    }
+    if (!top.ok) { r->err = "bad SavedTensorSlices (meta)"; return false; }
+  }
+  if (!have_meta) { r->err = "no SavedTensorSliceMeta entry: not a Saver V1 file"; return false; }
+  // pass 2: data entries; every slice is copied into place (a plain Saver writes one full slice per tensor)
+  std::vector<int64_t> filled(r->entries.size(), 0);
+  for (auto& e : kv) {
+    if (e.first.empty()) continue;
+    PbReader top{(const uint8_t*)e.second.data(), (const uint8_t*)e.second.data() + e.second.size()};
+    int f, wt;
+    while (top.next(&f, &wt)) {
+      if (!(f == 2 && wt == 2)) { top.skip(wt); continue; }
+      const uint8_t* sb; size_t sl;
+      if (!top.bytes(&sb, &sl)) break;
+      PbReader ss{sb, sb + sl};
+      std::string name;
+      std::vector<Extent> ex;
+      const uint8_t* tp = nullptr; size_t tpl = 0;
+      int f2, wt2;
+      while (ss.next(&f2, &wt2)) {
+        const uint8_t* xb; size_t xl;
+        if (f2 == 1 && wt2 == 2) { if (ss.bytes(&xb, &xl)) name.assign((const char*)xb, xl); }
+        else if (f2 == 2 && wt2 == 2) { if (!ss.bytes(&xb, &xl) || !decode_slice(xb, xl, &ex)) ss.ok = false; }
+        else if (f2 == 3 && wt2 == 2) { ss.bytes(&tp, &tpl); }
+        else ss.skip(wt2);
+      }
+      if (!ss.ok) { r->err = "bad SavedSlice"; return false; }
+      auto it = by_name.find(name);
+      if (it == by_name.end()) { r->err = "slice of a tensor the meta entry does not list: " + name; return false; }
+      const Entry& en = r->entries[it->second];
+      std::string bytes;
+      if (tp && !decode_tensor_proto(tp, tpl, en.dtype, &bytes)) { r->err = "bad TensorProto for " + name; return false; }
+      if (!copy_slice(&r->mem[it->second], en.dims, ex, bytes, dtype_size(en.dtype))) {
+        r->err = "slice extents / data size do not fit the tensor shape for " + name;
+        return false;
+      }
+      filled[it->second] += (int64_t)bytes.size();
+    }
+    if (!top.ok) { r->err = "bad SavedTensorSlices (data)"; return false; }
+  }
+  for (size_t i = 0; i < r->entries.size(); ++i)
+    if (filled[i] != r->entries[i].size) { r->err = "slices do not cover tensor " + r->entries[i].name; return false; }
+  r->v1 = true;
+  return true;
+}
+
+// OrderedCode pieces of tensorflow/core/lib/strings/ordered_code (only what slice keys use)
+static void ordered_num(std::string* s, uint64_t v) {
+  uint8_t buf[9];
+  int len = 0;
+  while (v > 0) { ++len; buf[9 - len] = (uint8_t)(v & 0xff); v >>= 8; }
+  buf[9 - len - 1] = (uint8_t)len;
+  ++len;
+  s->append((const char*)buf + 9 - len, (size_t)len);
+}
+static void ordered_string(std::string* s, const std::string& v) {
+  for (char c : v) {
+    if (c == '\0') s->append("\0\xff", 2);
+    else if ((uint8_t)c == 0xff) s->append("\xff\0", 2);
+    else s->push_back(c);
+  }
+  s->append("\0\x01", 2);
+}
+static void ordered_small_signed(std::string* s, int64_t v) { s->push_back((char)(0x80 ^ (uint8_t)v)); }  // |v| < 64
+
+static std::string full_slice_proto(size_t ndim) {
+  std::string s;
+  for (size_t d = 0; d < ndim; ++d) pb_bytes_field(&s, 1, std::string());  // Extent{}: start 0, no length = everything
+  return s;
+}
+
+static std::string v1_slice_key(const std::string& name, size_t ndim) {
+  std::string k;
+  ordered_num(&k, 0);
+  ordered_string(&k, name);
+  ordered_num(&k, ndim);
+  for (size_t d = 0; d < ndim; ++d) {
+    ordered_small_signed(&k, 0);   // start
+    ordered_small_signed(&k, -1);  // length: kFullExtent
+  }
+  return k;
+}
+
+static bool encode_tensor_proto(const Entry& e, const std::string& bytes, std::string* out, std::string* err) {
+  const size_t es = dtype_size(e.dtype);
+  if (e.dtype == 1 || e.dtype == 2) {
+    pb_bytes_field(out, e.dtype == 1 ? 5 : 6, bytes);  // packed float_val / double_val
+  } else if (e.dtype == 3 || e.dtype == 9) {
+    std::string packed;
+    for (size_t i = 0; i + es <= bytes.size(); i += es) {
+      int64_t v;
+      if (es == 4) { int32_t x; memcpy(&x, &bytes[i], 4); v = x; } else memcpy(&v, &bytes[i], 8);
+      put_varint64(&packed, (uint64_t)v);  // negative values sign-extend to ten bytes, as protobuf does
+    }
+    pb_bytes_field(out, e.dtype == 3 ? 7 : 10, packed);
+  } else {
+    *err = "Saver V1 writer supports float/double/int32/int64 only (" + e.name + ")";
+    return false;
+  }
+  return true;
+}
 
 }  // namespace dtfckpt
 
@@ -562,6 +837,41 @@ int dtf_ckpt_writer_finish(void* wp) {
   return 0;
 }
 
+// Saver V1: one sstable <prefix> (meta entry + one full slice per tensor); see the file header.
+int dtf_ckpt_writer_finish_v1(void* wp) {
+  Writer* w = (Writer*)wp;
+  std::map<std::string, std::string> kv;  // the table wants bytewise key order
+  std::string meta;
+  for (auto& it : w->entries) {
+    const Entry& e = it.second;
+    std::string t;
+    pb_bytes_field(&t, 1, e.name);
+    pb_bytes_field(&t, 2, encode_shape(e.dims));
+    pb_varint_field(&t, 3, (uint64_t)e.dtype);
+    pb_bytes_field(&t, 4, full_slice_proto(e.dims.size()));
+    pb_bytes_field(&meta, 1, t);  // SavedTensorSliceMeta.tensor
+    std::string ss, tp;
+    pb_bytes_field(&ss, 1, e.name);
+    pb_bytes_field(&ss, 2, full_slice_proto(e.dims.size()));
+    if (!encode_tensor_proto(e, w->payload[it.first], &tp, &w->err)) return -1;
+    pb_bytes_field(&ss, 3, tp);
+    std::string sts;
+    pb_bytes_field(&sts, 2, ss);  // SavedTensorSlices.data
+    kv[v1_slice_key(e.name, e.dims.size())] = sts;
+  }
+  std::string ver;
+  pb_varint_field(&ver, 1, 1);  // VersionDef.producer = TF_CHECKPOINT_VERSION (1)
+  pb_bytes_field(&meta, 2, ver);
+  std::string top;
+  pb_bytes_field(&top, 1, meta);  // SavedTensorSlices.meta
+  kv[""] = top;
+  std::vector<std::pair<std::string, std::string>> sorted(kv.begin(), kv.end());
+  if (!write_file_atomic(w->prefix, build_table(sorted, 262144), &w->err)) return -1;
+  return 0;
+}
+
+int dtf_ckpt_reader_is_v1(void* rp) { return ((Reader*)rp)->v1 ? 1 : 0; }
+
 const char* dtf_ckpt_writer_error(void* wp) { return ((Writer*)wp)->err.c_str(); }
 void dtf_ckpt_writer_free(void* wp) { delete (Writer*)wp; }
 
@@ -570,7 +880,13 @@ void* dtf_ckpt_reader_open(const char* prefix) {
   r->prefix = prefix;
   std::string file;
   if (!read_file(r->prefix + ".index", &file)) {
-    r->err = "cannot read " + r->prefix + ".index";
+    // no bundle index: a Saver V1 checkpoint is the single file <prefix> itself
+    if (read_file(r->prefix, &file) && file.size() >= 48 &&
+        get_fixed64((const uint8_t*)file.data() + file.size() - 8) == kTableMagic) {
+      load_v1(file, r);
+      return r;
+    }
+    r->err = "cannot read " + r->prefix + ".index (V2) and " + r->prefix + " is not a Saver V1 file";
     return r;
   }
   std::vector<std::pair<std::string, std::string>> kv;
@@ -624,6 +940,10 @@ int dtf_ckpt_reader_read(void* rp, int i, void* dst, int64_t nbytes) {
   if (i < 0 || i >= (int)r->entries.size()) return -1;
   const Entry& e = r->entries[i];
   if (nbytes != e.size) { r->err = "size mismatch for " + e.name; return -1; }
+  if (r->v1) {
+    if (nbytes) memcpy(dst, r->mem[(size_t)i].data(), (size_t)nbytes);
+    return 0;
+  }
   std::string path = shard_name(r->prefix, e.shard_id, r->num_shards);
   FILE* f = fopen(path.c_str(), "rb");
   if (!f) { r->err = "cannot open " + path; return -1; }

@@ -1,4 +1,5 @@
-"""ctypes binding of libdtf_ckpt.so: read/write TensorFlow V2 ("tensor bundle") checkpoints."""
+"""ctypes binding of libdtf_ckpt.so: read/write TensorFlow checkpoints -- V2 ("tensor bundle",
+TF >= 0.12) and Saver V1 (the single-file format of the TF 0.x the reference script targets)."""
 from __future__ import annotations
 
 import ctypes
@@ -39,6 +40,8 @@ def _load():
         lib.dtf_ckpt_writer_new.restype = c_void_p
         lib.dtf_ckpt_writer_add.argtypes = [c_void_p, c_char_p, c_int, c_int, ctypes.POINTER(c_int64), c_void_p, c_int64]
         lib.dtf_ckpt_writer_finish.argtypes = [c_void_p]
+        lib.dtf_ckpt_writer_finish_v1.argtypes = [c_void_p]
+        lib.dtf_ckpt_reader_is_v1.argtypes = [c_void_p]
         lib.dtf_ckpt_writer_error.argtypes = [c_void_p]
         lib.dtf_ckpt_writer_error.restype = c_char_p
         lib.dtf_ckpt_writer_free.argtypes = [c_void_p]
@@ -68,8 +71,28 @@ def crc32c_masked(data: bytes) -> int:
     return int(lib.dtf_crc32c_mask(lib.dtf_crc32c(data, len(data))))
 
 
-def write_bundle(prefix: str, tensors: Dict[str, np.ndarray]) -> None:
-    """Write ``<prefix>.index`` + ``<prefix>.data-00000-of-00001``."""
+def write_v1(prefix: str, tensors: Dict[str, np.ndarray]) -> None:
+    """Write the single Saver-V1 file ``<prefix>`` (what ``tf.train.Saver`` produced before TF 0.12)."""
+    write_bundle(prefix, tensors, version=1)
+
+
+def checkpoint_format(prefix: str) -> int:
+    """1 or 2: the on-disk format of the checkpoint at ``prefix``."""
+    lib = _load()
+    r = lib.dtf_ckpt_reader_open(str(prefix).encode())
+    try:
+        err = lib.dtf_ckpt_reader_error(r).decode()
+        if err:
+            raise CheckpointError(f"{prefix}: {err}")
+        return 1 if lib.dtf_ckpt_reader_is_v1(r) else 2
+    finally:
+        lib.dtf_ckpt_reader_free(r)
+
+
+def write_bundle(prefix: str, tensors: Dict[str, np.ndarray], version: int = 2) -> None:
+    """Write ``<prefix>.index`` + ``<prefix>.data-00000-of-00001`` (version 2) or the V1 file ``<prefix>``."""
+    if version not in (1, 2):
+        raise CheckpointError(f"write version {version}: TensorFlow has Saver formats 1 and 2")
     lib = _load()
     w = lib.dtf_ckpt_writer_new(str(prefix).encode())
     try:
@@ -83,7 +106,7 @@ def write_bundle(prefix: str, tensors: Dict[str, np.ndarray]) -> None:
             if lib.dtf_ckpt_writer_add(w, name.encode(), _NP_TO_DT[a.dtype], a.ndim, dims,
                                        a.ctypes.data_as(c_void_p), a.nbytes) != 0:
                 raise CheckpointError(lib.dtf_ckpt_writer_error(w).decode())
-        if lib.dtf_ckpt_writer_finish(w) != 0:
+        if (lib.dtf_ckpt_writer_finish if version == 2 else lib.dtf_ckpt_writer_finish_v1)(w) != 0:
             raise CheckpointError(lib.dtf_ckpt_writer_error(w).decode())
     finally:
         lib.dtf_ckpt_writer_free(w)
@@ -95,7 +118,7 @@ def list_bundle(prefix: str) -> Dict[str, tuple]:
 
 
 def read_bundle(prefix: str) -> Dict[str, np.ndarray]:
-    """Read every tensor of a V2 checkpoint (crc-verified)."""
+    """Read every tensor of a checkpoint (V2 bundle or Saver V1, detected from the files; crc-verified)."""
     return _read(prefix, data=True)
 
 

@@ -6,7 +6,9 @@ tf.train.Saver()`` handed to the Supervisor, :159-165).
   variable names (``Variable`` ... ``Variable_8``; optimizer slots use TF's
   ``Variable/Adam`` naming) and maintains the text-proto ``checkpoint`` state file
   with ``max_to_keep`` (default 5) rotation, exactly like TF.
-* ``latest_checkpoint(logdir)`` / ``Saver.restore(prefix)`` are the other direction.
+* ``latest_checkpoint(logdir)`` / ``Saver.restore(prefix)`` are the other direction; they also take
+  the single-file Saver **V1** checkpoints that the TF 0.x the reference targets wrote (so a logdir
+  left by the reference resumes here), and ``Saver(write_version=1)`` writes that format.
 Native layouts equal TF's (HWIO / [in,out] / HWC flatten), so import/export is a
 plain copy of each tensor.
 """
@@ -88,11 +90,15 @@ def read_checkpoint_state(logdir: str) -> List[str]:
 
 
 def latest_checkpoint(logdir: str) -> Optional[str]:
-    """tf.train.latest_checkpoint: newest prefix whose .index exists, else None."""
+    """tf.train.latest_checkpoint: newest prefix whose files exist (.index, or the V1 file itself), else None."""
     for p in reversed(read_checkpoint_state(logdir)):
-        if os.path.exists(p + ".index"):
+        if _exists(p):
             return p
     return None
+
+
+def _exists(prefix: str) -> bool:
+    return os.path.exists(prefix + ".index") or os.path.isfile(prefix)
 
 
 def _write_state(logdir: str, prefixes: List[str]):
@@ -106,8 +112,9 @@ def _write_state(logdir: str, prefixes: List[str]):
 
 
 class Saver:
-    def __init__(self, max_to_keep: int = 5):
+    def __init__(self, max_to_keep: int = 5, write_version: int = 2):
         self.max_to_keep = max_to_keep
+        self.write_version = write_version
         self._kept: List[str] = []
 
     def save(self, tf_tensors: Dict[str, np.ndarray], save_path: str, global_step: Optional[int] = None) -> str:
@@ -115,15 +122,15 @@ class Saver:
         prefix = save_path if global_step is None else f"{save_path}-{int(global_step)}"
         logdir = os.path.dirname(prefix) or "."
         os.makedirs(logdir, exist_ok=True)
-        bundle.write_bundle(prefix, tf_tensors)
+        bundle.write_bundle(prefix, tf_tensors, version=self.write_version)
         if not self._kept:
-            self._kept = [p for p in read_checkpoint_state(logdir) if os.path.exists(p + ".index")]
+            self._kept = [p for p in read_checkpoint_state(logdir) if _exists(p)]
         if prefix in self._kept:
             self._kept.remove(prefix)
         self._kept.append(prefix)
         while self.max_to_keep and len(self._kept) > self.max_to_keep:
             old = self._kept.pop(0)
-            for suffix in (".index", ".data-00000-of-00001"):
+            for suffix in (".index", ".data-00000-of-00001", "", ".meta"):
                 try:
                     os.remove(old + suffix)
                 except FileNotFoundError:

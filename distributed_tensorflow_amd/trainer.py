@@ -29,6 +29,7 @@ from .data.mnist import read_data_sets
 from .models.spec import ModelSpec
 from .parallel import comm
 from .parallel.strategies import (AsyncP2PServer, AsyncP2PWorker, AsyncRounds, LocalStrategy, SyncAllReduce)
+from .checkpoint import Saver
 from .supervisor import Supervisor
 from .utils.metrics import MetricsLogger, StepTimer, format_display_line
 
@@ -132,7 +133,7 @@ def run(F, log=print) -> dict:
         strategy = AsyncRounds(backend, task, chief_rank, staleness=F.staleness)
 
     sv = Supervisor(backend, is_chief=task.is_chief, logdir=F.logdir or None, save_model_secs=F.save_model_secs,
-                    init_seed=F.seed, log=log)
+                    saver=Saver(write_version=getattr(F, "saver_write_version", 2)), init_seed=F.seed, log=log)
     timer = StepTimer()
     images_per_step = F.batch_size * (task.num_workers if mode == "sync" else 1)
     t_start = time.perf_counter()

@@ -41,6 +41,7 @@ flags.DEFINE_string("model", "deep_mnist", "deep_mnist | wide (conv 128/256, fc4
 flags.DEFINE_string("backend", "auto", "auto | hip (MI355X kernels) | cpu (PyTorch oracle, gloo) | torch / torch_bf16 (fp32 / autocast ATen reference on the GPU)")
 flags.DEFINE_string("logdir", "/tmp/train_logs", "checkpoint directory (reference hard-codes /tmp/train_logs); '' disables")
 flags.DEFINE_float("save_model_secs", 600.0, "seconds between chief checkpoints (reference: 600)")
+flags.DEFINE_integer("saver_write_version", 2, "checkpoint format the chief writes: 2 = tensor bundle, 1 = TF<0.12 Saver file (both are read)")
 flags.DEFINE_boolean("synthetic", False, "use MNIST-shaped synthetic data (automatic when data_dir has no idx files)")
 flags.DEFINE_boolean("eval", True, "evaluate on the 10k test split at the end (chief)")
 flags.DEFINE_integer("seed", 0, "base random seed")
