@@ -44,6 +44,10 @@ int dtf_gemm_nn_partial(const void* A, const void* B, void* part, int M, int N, 
                         hipStream_t s);
 int dtf_head_wgrad(const void* h1, const void* dlogits, const void* da, void* part, int B, int H, int KS,
                    hipStream_t s);
+// fc1 dgrad GEMM (C = A . B^T, bf16 store) + the head wgrad as extra workgroups of the same launch
+int dtf_gemm_nt_head_wgrad(const void* A, const void* B, void* C, int M, int N, int K, int lda, int ldb, int ldc,
+                           const void* h1, const void* dlogits, const void* da, void* part, int Bsz, int H, int KS,
+                           hipStream_t s);
 int dtf_sgd_update(void* w, const void* g, void* shadow, const void* hyper, long n, void* state, long cursor_inc,
                    long step_inc, long drop_inc, hipStream_t s);
 int dtf_adam_update(void* w, const void* g, void* m, void* v, void* shadow, const void* hyper, long n, void* tstate,

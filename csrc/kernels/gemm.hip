@@ -19,6 +19,7 @@
 //       bijection of k is a valid GEMM), which makes the transposed reads
 //       bank-conflict free.
 #include "common.hpp"
+#include "head_wgrad_core.hpp"
 
 namespace dtf {
 
@@ -30,10 +31,9 @@ enum { EPI_STORE = 0, EPI_BIAS_RELU_DROPOUT = 1, EPI_NOSTORE_DIAG = 2 };
 // traffic (measured: ~11 B/clk/CU, i.e. operand panels re-fetched by every XCD).  Giving each XCD a
 // compact BH x (chunk/BH) rectangle of tiles makes its L2 fetch each A/B panel once per rectangle
 // instead of once per tile.  Bijective for any tile count (guide T1).
-__device__ __forceinline__ void xcd_tile(int gx, int gy, int& tx, int& ty) {
+__device__ __forceinline__ void xcd_tile_linear(int L, int gx, int gy, int& tx, int& ty) {
   constexpr int NX = 8, BH = 4;
   const int total = gx * gy;
-  const int L = blockIdx.x + gx * blockIdx.y;
   const int xcd = L % NX, slot = L / NX;
   const int q = total / NX, r = total % NX;
   const int idx = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + slot;
@@ -43,6 +43,9 @@ __device__ __forceinline__ void xcd_tile(int gx, int gy, int& tx, int& ty) {
   const int h = min(BH, gy - band * BH);
   tx = rem / h;
   ty = band * BH + rem % h;
+}
+__device__ __forceinline__ void xcd_tile(int gx, int gy, int& tx, int& ty) {
+  xcd_tile_linear(blockIdx.x + gx * blockIdx.y, gx, gy, tx, ty);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -91,10 +94,14 @@ __device__ __forceinline__ void gemm_pipeline(int T, GL&& gload, SW&& swrite, CP
   }
 }
 
-template <int BM, int BN, int NW, int EPI>
+// HEADW: the launch is a 1-D grid of the GEMM's tiles FOLLOWED by hw.nbx * KS workgroups that compute the
+// output-layer weight gradient (head_wgrad_core.hpp) -- independent work that fills the CUs this GEMM
+// leaves idle (fc1 dgrad: 200 tiles on 256 CUs) instead of paying for a launch of its own.
+template <int BM, int BN, int NW, int EPI, bool HEADW = false>
 __global__ __launch_bounds__(NW * 64) void gemm_nt_bf16(const bf16* A, const bf16* Bm, bf16* __restrict__ C,
                                                         const float* __restrict__ bias, int M, int N, int K,
-                                                        int lda, int ldb, int ldc, DropoutArgs drop) {
+                                                        int lda, int ldb, int ldc, DropoutArgs drop,
+                                                        HeadWgradArgs hw = HeadWgradArgs{}) {
   constexpr int BK = 64, NT = NW * 64;
   constexpr int WAVES_N = NW / 2;
   constexpr int WM = BM / 2, WN = BN / WAVES_N;
@@ -106,7 +113,18 @@ __global__ __launch_bounds__(NW * 64) void gemm_nt_bf16(const bf16* A, const bf1
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wave / WAVES_N, wn = wave % WAVES_N;
   int tile_x, tile_y;
-  xcd_tile(gridDim.x, gridDim.y, tile_x, tile_y);
+  if constexpr (HEADW) {
+    static_assert(sizeof(sA) >= sizeof(float) * head_wgrad_lds_floats<NW>(), "head wgrad scratch must fit in sA");
+    const int gx = (N + BN - 1) / BN, gy = (M + BM - 1) / BM;
+    const int extra = (int)blockIdx.x - gx * gy;
+    if (extra >= 0) {
+      head_wgrad_block<NW>(hw, extra % hw.nbx, extra / hw.nbx, reinterpret_cast<float*>(&sA[0][0]));
+      return;
+    }
+    xcd_tile_linear((int)blockIdx.x, gx, gy, tile_x, tile_y);
+  } else {
+    xcd_tile(gridDim.x, gridDim.y, tile_x, tile_y);
+  }
   const int m0 = tile_y * BM, n0 = tile_x * BN;
   const int i16 = lane & 15, g = lane >> 4;
 
@@ -520,7 +538,7 @@ int dtf_gemm_nt(const void* A, const void* B, void* C, const void* bias, int M, 
 #define NT_CASE(BMN, E)                                                                               \
   hipLaunchKernelGGL((gemm_nt_bf16<BMN, BMN, BMN / 16, E>),                                           \
                      dim3((N + BMN - 1) / BMN, (M + BMN - 1) / BMN), dim3(BMN * 4), 0, s, (const bf16*)A, \
-                     (const bf16*)B, (bf16*)C, (const float*)bias, M, N, K, lda, ldb, ldc, d)
+                     (const bf16*)B, (bf16*)C, (const float*)bias, M, N, K, lda, ldb, ldc, d, HeadWgradArgs{})
   if (tile == 128 && epi == 0) NT_CASE(128, EPI_STORE);
   else if (tile == 128 && epi == 1) NT_CASE(128, EPI_BIAS_RELU_DROPOUT);
   else if (tile == 64 && epi == 0) NT_CASE(64, EPI_STORE);
@@ -529,6 +547,31 @@ int dtf_gemm_nt(const void* A, const void* B, void* C, const void* bias, int M, 
   else if (tile == 64 && epi == 2) NT_CASE(64, EPI_NOSTORE_DIAG);
   else return -1;
 #undef NT_CASE
+  return (int)hipGetLastError();
+}
+
+// fc1 dgrad (C = A . B^T, plain store) and the output-layer weight gradient in ONE launch: the GEMM's
+// tiles plus ceil(H/64) * KS reduction workgroups.  Falls back to two launches when the GEMM is too small
+// for the 128x128 / 512-thread configuration the fused kernel is built for.
+int dtf_head_wgrad(const void* h1, const void* dlogits, const void* da, void* part, int B, int H, int KS,
+                   hipStream_t s);
+int dtf_gemm_nt_head_wgrad(const void* A, const void* Bw, void* C, int M, int N, int K, int lda, int ldb, int ldc,
+                           const void* h1, const void* dlogits, const void* da, void* part, int Bsz, int H, int KS,
+                           hipStream_t s) {
+  if ((K & 63) || (lda & 7) || (ldb & 7)) return -3;
+  if (KS <= 0) return -2;
+  const long tiles = (long)((M + 127) / 128) * ((N + 127) / 128);
+  if (tiles < 192) {
+    int rc = dtf_head_wgrad(h1, dlogits, da, part, Bsz, H, KS, s);
+    if (rc) return rc;
+    return dtf_gemm_nt(A, Bw, C, nullptr, M, N, K, lda, ldb, ldc, 0, 1.0f, 0, nullptr, 0, s);
+  }
+  HeadWgradArgs hw{(const bf16*)h1, (const float*)dlogits, (const bf16*)da, (float*)part, Bsz, H, (Bsz + KS - 1) / KS,
+                   (H + 63) / 64};
+  DropoutArgs d{1.0f, 0, nullptr};
+  hipLaunchKernelGGL((gemm_nt_bf16<128, 128, 8, EPI_STORE, true>), dim3((unsigned)(tiles + (long)hw.nbx * KS)), dim3(512),
+                     0, s, (const bf16*)A, (const bf16*)Bw, (bf16*)C, (const float*)nullptr, M, N, K, lda, ldb, ldc, d,
+                     hw);
   return (int)hipGetLastError();
 }
 

@@ -15,6 +15,7 @@
 // head_wgrad reduces over the batch: dW_out = h1^T . dlogits, db_out, and the
 // fc1 bias gradient db_d1 = colsum(da), as deterministic split-K slabs.
 #include "common.hpp"
+#include "head_wgrad_core.hpp"
 
 namespace dtf {
 
@@ -153,63 +154,10 @@ __global__ __launch_bounds__(256) void transpose_head_w(const float* __restrict_
 }
 
 // grid = (H/64, KS).  slab layout per k-split: [H*10 dW_out][12: db_out padded][H db_d1]
-__global__ __launch_bounds__(256) void head_wgrad(const bf16* __restrict__ h1,
-                                                  const float* __restrict__ dlogits,
-                                                  const bf16* __restrict__ da, float* __restrict__ part,
-                                                  int B, int H, int rows_per_split) {
-  __shared__ float red[4][64][kCls + 1];
-  const int jc = threadIdx.x & 63, sub = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // wave-uniform row phase
-  const int j = blockIdx.x * 64 + jc;
-  const int b0 = blockIdx.y * rows_per_split;
-  const int b1 = min(B, b0 + rows_per_split);
-  float acc[kCls + 1];
-#pragma unroll
-  for (int c = 0; c <= kCls; ++c) acc[c] = 0.f;
-  if (j < H) {
-    // four rows per trip: their activation loads are issued together (a one-row loop was a chain of
-    // dependent-latency trips), and the dlogits row address is wave-uniform -> scalar loads
-    int b = b0 + sub;
-    for (; b + 12 < b1; b += 16) {
-      float hf[4], dv[4];
-#pragma unroll
-      for (int u = 0; u < 4; ++u) {
-        hf[u] = (float)h1[(size_t)(b + 4 * u) * H + j];
-        dv[u] = (float)da[(size_t)(b + 4 * u) * H + j];
-      }
-#pragma unroll
-      for (int u = 0; u < 4; ++u) {
-        const float* dl = dlogits + (size_t)(b + 4 * u) * kCls;
-#pragma unroll
-        for (int c = 0; c < kCls; ++c) acc[c] = fmaf(hf[u], dl[c], acc[c]);
-        acc[kCls] += dv[u];
-      }
-    }
-    for (; b < b1; b += 4) {
-      const float hf = (float)h1[(size_t)b * H + j];
-      const float* dl = dlogits + (size_t)b * kCls;
-#pragma unroll
-      for (int c = 0; c < kCls; ++c) acc[c] = fmaf(hf, dl[c], acc[c]);
-      acc[kCls] += (float)da[(size_t)b * H + j];
-    }
-  }
-#pragma unroll
-  for (int c = 0; c <= kCls; ++c) red[sub][jc][c] = acc[c];
-  __syncthreads();
-  float* slab = part + (size_t)blockIdx.y * ((size_t)H * kCls + 12 + H);
-  if (sub == 0 && j < H) {
-#pragma unroll
-    for (int c = 0; c <= kCls; ++c) {
-      float s = red[0][jc][c] + red[1][jc][c] + red[2][jc][c] + red[3][jc][c];
-      if (c < kCls) slab[(size_t)j * kCls + c] = s;
-      else slab[(size_t)H * kCls + 12 + j] = s;
-    }
-  }
-  if (blockIdx.x == 0 && threadIdx.x < 12) {
-    float s = 0.f;
-    if (threadIdx.x < kCls)
-      for (int b = b0; b < b1; ++b) s += dlogits[(size_t)b * kCls + threadIdx.x];
-    slab[(size_t)H * kCls + threadIdx.x] = s;
-  }
+// (body in head_wgrad_core.hpp: the training step runs it inside the fc1 dgrad GEMM launch instead)
+__global__ __launch_bounds__(256) void head_wgrad(HeadWgradArgs a) {
+  __shared__ float red[head_wgrad_lds_floats<4>()];
+  head_wgrad_block<4>(a, blockIdx.x, blockIdx.y, red);
 }
 
 }  // namespace dtf
@@ -261,8 +209,8 @@ int dtf_head_wgrad(const void* h1, const void* dlogits, const void* da, void* pa
                    hipStream_t s) {
   if (KS <= 0) return -2;
   int rps = (B + KS - 1) / KS;
-  hipLaunchKernelGGL(head_wgrad, dim3((H + 63) / 64, KS), dim3(256), 0, s, (const bf16*)h1,
-                     (const float*)dlogits, (const bf16*)da, (float*)part, B, H, rps);
+  HeadWgradArgs a{(const bf16*)h1, (const float*)dlogits, (const bf16*)da, (float*)part, B, H, rps, (H + 63) / 64};
+  hipLaunchKernelGGL(head_wgrad, dim3((H + 63) / 64, KS), dim3(256), 0, s, a);
   return (int)hipGetLastError();
 }
 

@@ -121,10 +121,12 @@ static int dgrad_conv1_wgrad(const DtfEngineDesc* e, const void* images, const v
 }
 
 // head wgrad + slab reduce + fc1 wgrad: finalises the (head | wd1) prefix of the gradient arena.
-// reduce == 0 leaves the head slabs unreduced (the fused single-GPU SGD tail sums them itself).
+// reduce == 0 leaves the head slabs unreduced (the fused single-GPU SGD tail sums them itself);
+// reduce == -1 does not compute them either: the training step runs the head wgrad inside the fc1
+// dgrad launch (backward_conv_impl with head_w != 0).
 static int backward_dense_impl(const DtfEngineDesc* e, int reduce, hipStream_t s) {
-  DTF_TRY(dtf_head_wgrad(e->h1, e->dlogits, e->da, e->head_part, e->B, e->hidden, e->head_ks, s));
-  if (reduce) {
+  if (reduce >= 0) DTF_TRY(dtf_head_wgrad(e->h1, e->dlogits, e->da, e->head_part, e->B, e->hidden, e->head_ks, s));
+  if (reduce > 0) {
     const void* part[1] = {e->head_part};
     void* out[1] = {f32at(e->grads, e->off_out_w)};
     int G[1] = {e->head_ks}, n[1] = {(int)e->head_stride};
@@ -138,10 +140,18 @@ int dtf_engine_backward_dense(const DtfEngineDesc* e, hipStream_t s) { return ba
 
 // fc1 dgrad -> {conv2 dgrad -> conv1 wgrad} || conv2 wgrad (side stream) -> slab reduce.
 // record_dgrad != 0: e->ev_dgrad is recorded right after fc1 dgrad (the last reader of bf16 wd1).
+static int fc1_dgrad(const DtfEngineDesc* e, int head_w, hipStream_t s) {
+  if (head_w)   // + the output-layer weight gradient as extra workgroups of the same launch
+    return dtf_gemm_nt_head_wgrad(e->da, bf16at(e->shadow, e->off_wd1), e->dflat, e->B, e->flat, e->hidden, e->hidden,
+                                  e->hidden, e->flat, e->h1, e->dlogits, e->da, e->head_part, e->B, e->hidden,
+                                  e->head_ks, s);
+  return dtf_gemm_nt(e->da, bf16at(e->shadow, e->off_wd1), e->dflat, nullptr, e->B, e->flat, e->hidden, e->hidden,
+                     e->hidden, e->flat, 0, 1.0f, 0, nullptr, 0, s);
+}
+
 static int backward_conv_impl(const DtfEngineDesc* e, const void* images, const void* idx, int record_dgrad,
-                              int reduce, hipStream_t s) {
-  DTF_TRY(dtf_gemm_nt(e->da, bf16at(e->shadow, e->off_wd1), e->dflat, nullptr, e->B, e->flat, e->hidden, e->hidden,
-                      e->hidden, e->flat, 0, 1.0f, 0, nullptr, 0, s));
+                              int reduce, int head_w, hipStream_t s) {
+  DTF_TRY(fc1_dgrad(e, head_w, s));
   if (record_dgrad) HIP_TRY(hipEventRecord(e->ev_dgrad, s));
   hipStream_t s2 = s;
   if (e->multi_stream) {
@@ -164,20 +174,21 @@ static int backward_conv_impl(const DtfEngineDesc* e, const void* images, const 
 }
 int dtf_engine_backward_conv(const DtfEngineDesc* e, const void* images, const void* idx, int record_dgrad,
                              hipStream_t s) {
-  return backward_conv_impl(e, images, idx, record_dgrad, 1, s);
+  return backward_conv_impl(e, images, idx, record_dgrad, 1, 0, s);
 }
 
 // whole backward; the dense-layer weight gradients run on side1 next to the conv chain
 static int backward_impl(const DtfEngineDesc* e, const void* images, const void* idx, int reduce, hipStream_t s) {
+  // the head slabs come out of the fc1 dgrad launch and are reduced with the conv slabs (one launch)
   if (!e->multi_stream) {
-    DTF_TRY(backward_dense_impl(e, reduce, s));
-    return backward_conv_impl(e, images, idx, 0, reduce, s);
+    DTF_TRY(backward_dense_impl(e, -1, s));
+    return backward_conv_impl(e, images, idx, 0, reduce ? 2 : 0, 1, s);
   }
   HIP_TRY(hipEventRecord(e->ev_head, s));
   HIP_TRY(hipStreamWaitEvent(e->side1, e->ev_head, 0));
-  DTF_TRY(backward_dense_impl(e, reduce, e->side1));
+  DTF_TRY(backward_dense_impl(e, -1, e->side1));
   HIP_TRY(hipEventRecord(e->ev_join1, e->side1));
-  DTF_TRY(backward_conv_impl(e, images, idx, 0, reduce, s));
+  DTF_TRY(backward_conv_impl(e, images, idx, 0, reduce ? 2 : 0, 1, s));
   return (int)hipStreamWaitEvent(s, e->ev_join1, 0);
 }
 int dtf_engine_backward(const DtfEngineDesc* e, const void* images, const void* idx, hipStream_t s) {
@@ -212,9 +223,7 @@ int dtf_engine_transposes(const DtfEngineDesc* e, int wc2, hipStream_t s) {
 // GEMM (gemm_tn_bf16<SGD>): dW_d1 -- 12.8 of the 13.1 MB of gradients -- is applied straight from
 // the accumulators and never written.  fc1 dgrad reads the bf16 wd1, so it runs first.
 static int train_tail_fused_dense(const DtfEngineDesc* e, long step_inc, hipStream_t s) {
-  DTF_TRY(dtf_head_wgrad(e->h1, e->dlogits, e->da, e->head_part, e->B, e->hidden, e->head_ks, s));
-  DTF_TRY(dtf_gemm_nt(e->da, bf16at(e->shadow, e->off_wd1), e->dflat, nullptr, e->B, e->flat, e->hidden, e->hidden,
-                      e->hidden, e->flat, 0, 1.0f, 0, nullptr, 0, s));
+  DTF_TRY(fc1_dgrad(e, 1, s));
   hipStream_t s1 = s, s2 = s;
   if (e->multi_stream) {
     HIP_TRY(hipEventRecord(e->ev_fork, s));
@@ -280,14 +289,14 @@ int dtf_engine_dp_phase1(const DtfEngineDesc* e, int wait_dense_updated, hipStre
   DTF_TRY(forward_conv_impl(e, e->ds_images, nullptr, 1, e->B, s));
   if (wait_dense_updated) HIP_TRY(hipStreamWaitEvent(s, e->ev_dense_updated, 0));
   DTF_TRY(dtf_engine_forward_dense(e, e->ds_labels, e->idx, 1, e->B, 1, s));
-  DTF_TRY(backward_dense_impl(e, 0, s));   // the head slabs are reduced with the conv slabs in phase 2
+  DTF_TRY(backward_dense_impl(e, -1, s));   // fc1 wgrad only: the head wgrad rides in phase 2's fc1 dgrad launch
   HIP_TRY(hipEventRecord(e->ev_dense_ready, s));
   return (int)hipStreamWaitEvent(comm, e->ev_dense_ready, 0);
 }
 
 int dtf_engine_dp_phase2(const DtfEngineDesc* e, long dense_hi, int dense_adam_slot, hipStream_t s, hipStream_t comm,
                          hipStream_t tail) {
-  DTF_TRY(backward_conv_impl(e, e->ds_images, e->idx, 1, 2, s));
+  DTF_TRY(backward_conv_impl(e, e->ds_images, e->idx, 1, 2, 1, s));
   // the dense update overwrites the bf16 wd1 that fc1 dgrad reads: order it after that kernel
   HIP_TRY(hipStreamWaitEvent(comm, e->ev_dgrad, 0));
   DTF_TRY(dtf_engine_update_range(e, 0, dense_hi, 0, 0, 0, dense_adam_slot, comm));

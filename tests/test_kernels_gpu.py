@@ -398,6 +398,38 @@ def test_head(gpu_lib, B, H):
     assert rel_err(got[H * 10 + 12:], da.float().sum(0)) < 1e-4
 
 
+@pytest.mark.parametrize("B,KS", [(1024, 32), (1000, 7), (64, 8)])
+def test_fc1_dgrad_with_head_wgrad_workgroups_matches_the_two_kernels(gpu_lib, B, KS):
+    """One launch = the fc1 dgrad GEMM tiles + the output-layer wgrad workgroups (gemm.hip HEADW).
+    The GEMM result is bitwise the plain kernel's; the reduction (8 row phases instead of 4, so a
+    different fp32 summation order) matches the stand-alone kernel and the fp32 reference.
+    B = 64 is below the 128-tile threshold: the call falls back to the two launches."""
+    H, F_ = 1024, 3136
+    g = torch.Generator(device="cpu").manual_seed(33)
+    da = bf(torch.randn(B, H, generator=g) * (torch.rand(B, H, generator=g) > 0.5)).to(DEV)
+    w = bf(torch.randn(F_, H, generator=g) * 0.03).to(DEV)            # wd1 [flat][hidden]: dflat = da . wd1^T
+    h1 = bf(torch.randn(B, H, generator=g).clamp_min(0)).to(DEV)
+    dlog = (torch.randn(B, 10, generator=g) / B).to(DEV)
+    stride = H * 10 + 12 + H
+    C0 = torch.empty(B, F_, dtype=torch.bfloat16, device=DEV)
+    C1 = torch.full((B, F_), 7.0, dtype=torch.bfloat16, device=DEV)
+    part0 = torch.empty(KS, stride, device=DEV)
+    part1 = torch.full((KS, stride), 3.0, device=DEV)
+    check(gpu_lib.dtf_gemm_nt(ptr(da), ptr(w), ptr(C0), None, B, F_, H, H, H, F_, 0, 1.0, 0, None, 0, stream()), "nt")
+    check(gpu_lib.dtf_head_wgrad(ptr(h1), ptr(dlog), ptr(da), ptr(part0), B, H, KS, stream()), "head_wgrad")
+    check(gpu_lib.dtf_gemm_nt_head_wgrad(ptr(da), ptr(w), ptr(C1), B, F_, H, H, H, F_, ptr(h1), ptr(dlog), ptr(da),
+                                         ptr(part1), B, H, KS, stream()), "nt+head_wgrad")
+    torch.cuda.synchronize()
+    assert torch.equal(C0, C1)
+    assert rel_err(C1, da.float() @ w.float().t()) < 4e-3
+    # padding floats 10, 11 of the db_out block are written as zeros by both
+    assert rel_err(part1, part0) < 1e-5
+    got = part1.sum(0)
+    assert rel_err(got[:H * 10].reshape(H, 10), h1.float().t() @ dlog) < 1e-4
+    assert rel_err(got[H * 10:H * 10 + 10], dlog.sum(0)) < 1e-4
+    assert rel_err(got[H * 10 + 12:], da.float().sum(0)) < 1e-4
+
+
 @pytest.mark.parametrize("keep", [1.0, 0.6])
 def test_head_fused_fc1_epilogue_matches_two_kernel_path(gpu_lib, keep):
     """split-K partials -> (bias, ReLU, dropout, h1, logits, loss, dlogits, da) in one launch ==
