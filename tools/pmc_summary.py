@@ -13,6 +13,6 @@ for f in files:
 counters = sorted({c for v in acc.values() for c in v})
 print(f"{'kernel':44s} " + " ".join(f"{c[-18:]:>18s}" for c in counters))
 for name, cs in sorted(acc.items()):
-    if not name.startswith(("conv", "gemm", "head", "reduce", "sgd", "_ZN3dtf", "transpose", "sample", "adam")):
+    if not name.startswith(("conv", "gemm", "head", "reduce", "sgd", "_ZN3dtf", "transpose", "sample", "adam", "fused")):
         continue
     print(f"{name:44s} " + " ".join(f"{(sum(cs[c])/len(cs[c]) if c in cs else 0):18.0f}" for c in counters))
