@@ -35,6 +35,10 @@
 #endif
 // Tile configuration of the 32->64 layer: KTOT, KC, NC, IMGS, NW, MODE, min waves/SIMD
 // (overridable so tools/conv_ablate.py can sweep it)
+// Diagnostic: delay the second half of the grid by DTF_STAGGER microseconds (tools/conv_ablate.py stagger)
+#ifndef DTF_STAGGER
+#define DTF_STAGGER 0
+#endif
 #ifndef DTF_FWD_CFG
 #define DTF_FWD_CFG 32, 32, 64, 2, 2, MODE_FWD, 4
 #endif
@@ -129,6 +133,13 @@ __global__ __launch_bounds__(IMGS * 2 * NW * 64, MINW) void conv5x5_igemm(
   const int w_h = (wave / NW) & 1;
   const int w_n = wave % NW;
   const int img0 = blockIdx.x * IMGS;
+#ifndef DTF_STAGGER_MODE
+#define DTF_STAGGER_MODE 0
+#endif
+  if (DTF_STAGGER > 0 && (DTF_STAGGER_MODE == 0 ? blockIdx.x >= gridDim.x / 2
+                          : DTF_STAGGER_MODE == 1 ? (blockIdx.x & 1) != 0
+                          : DTF_STAGGER_MODE == 2 ? ((blockIdx.x >> 3) & 1) != 0 : ((blockIdx.x >> 8) & 1) != 0))
+    for (int i = 0; i < DTF_STAGGER; ++i) __builtin_amdgcn_s_sleep(32);   // ~1 us per trip
 
   // ---- zero the whole tile (halo + slack), then fill the interior ----
   {

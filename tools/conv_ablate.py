@@ -14,6 +14,7 @@ CFGS = {"fwd": ["32,32,64,1,2,MODE_FWD,4", "32,32,64,2,1,MODE_FWD,2", "32,32,64,
                 "32,32,64,2,2,MODE_FWD,3", "32,32,64,2,2,MODE_FWD,4"],
         "dgrad": ["64,32,32,1,2,MODE_DGRAD,4", "64,32,32,2,1,MODE_DGRAD,2", "64,64,32,1,1,MODE_DGRAD,2", "64,64,32,2,1,MODE_DGRAD,2",
                   "64,32,32,4,1,MODE_DGRAD,4", "64,32,32,2,1,MODE_DGRAD,4", "64,64,32,1,1,MODE_DGRAD,4"]}
+STAGGER = [0, 3, 6, 9]
 if sys.argv[1] == "buildcfg":
     os.makedirs(OUT, exist_ok=True)
     for kind, lst in CFGS.items():
@@ -22,6 +23,14 @@ if sys.argv[1] == "buildcfg":
                                    f"-DDTF_{kind.upper()}_CFG={c}", "-I", ROOT + "/csrc/kernels", ROOT + "/csrc/kernels/conv2.hip",
                                    "-o", f"{OUT}/conv2_{kind}{i}.so"])
     print("built cfgs")
+elif sys.argv[1] == "buildstagger":
+    os.makedirs(OUT, exist_ok=True)
+    mode = os.environ.get("STAGGER_MODE", "0")
+    for d in STAGGER:
+        subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",
+                               f"-DDTF_STAGGER={d}", f"-DDTF_STAGGER_MODE={mode}", "-I", ROOT + "/csrc/kernels", ROOT + "/csrc/kernels/conv2.hip",
+                               "-o", f"{OUT}/conv2_st{d}.so"])
+    print("built stagger")
 elif sys.argv[1] == "build":
     os.makedirs(OUT, exist_ok=True)
     for v in sorted(set(WG) | set(IG)):
@@ -45,13 +54,17 @@ else:
     s = torch.cuda.current_stream().cuda_stream
     P = ctypes.c_void_p
     cfg = which.startswith("cfg")
-    if cfg:
+    stg = which.startswith("st_")
+    if stg:
+        which = which[3:]
+        items = {d: f"second half +{d} us" for d in STAGGER}
+    elif cfg:
         which = which[3:]
         items = {i: c for i, c in enumerate(CFGS[which])}
     else:
         items = WG if which == "wgrad" else IG
     for v, name in items.items():
-        lib = ctypes.CDLL(f"{OUT}/conv2_{which}{v}.so" if cfg else f"{OUT}/conv2_ab{v}.so")
+        lib = ctypes.CDLL(f"{OUT}/conv2_st{v}.so" if stg else f"{OUT}/conv2_{which}{v}.so" if cfg else f"{OUT}/conv2_ab{v}.so")
         if which == "wgrad":
             f = lib.dtf_conv2_wgrad; f.argtypes = [P] * 4 + [ctypes.c_int] * 4 + [P]
             call = lambda: f(x.data_ptr(), gp.data_ptr(), arg.data_ptr(), part.data_ptr(), B, 32, 64, G, s)
