@@ -46,7 +46,23 @@
 #define DTF_DGRAD_CFG 64, 32, 32, 2, 1, MODE_DGRAD, 3
 #endif
 
+// Diagnostic (-DDTF_TIMING=1, tools/conv_timeline.py): wave 0 of every igemm workgroup stamps the 100 MHz wall
+// clock at its phase boundaries into a buffer registered with dtf_conv2_set_timing_buf
+#ifndef DTF_TIMING
+#define DTF_TIMING 0
+#endif
+
 namespace dtf {
+
+#if DTF_TIMING
+__device__ long long* g_timing_buf = nullptr;
+#define DTF_STAMP(slot)                                                                     \
+  do {                                                                                      \
+    if (threadIdx.x == 0 && g_timing_buf) g_timing_buf[(size_t)blockIdx.x * 8 + (slot)] = wall_clock64(); \
+  } while (0)
+#else
+#define DTF_STAMP(slot) do {} while (0)
+#endif
 
 constexpr int kTileW = 18;          // 14 + 2*2 halo
 constexpr int kTilePos = 328;       // 18*18 = 324 (+4 slack for the dummy window's reads)
@@ -133,6 +149,10 @@ __global__ __launch_bounds__(IMGS * 2 * NW * 64, MINW) void conv5x5_igemm(
   const int w_h = (wave / NW) & 1;
   const int w_n = wave % NW;
   const int img0 = blockIdx.x * IMGS;
+  DTF_STAMP(0);
+#if DTF_TIMING
+  if (threadIdx.x == 0 && g_timing_buf) g_timing_buf[(size_t)blockIdx.x * 8 + 6] = clock64();
+#endif
 #ifndef DTF_STAGGER_MODE
 #define DTF_STAGGER_MODE 0
 #endif
@@ -248,6 +268,7 @@ __global__ __launch_bounds__(IMGS * 2 * NW * 64, MINW) void conv5x5_igemm(
     }
   }
   __syncthreads();
+  DTF_STAMP(1);
 
   // ---- main loop over this chunk ----
   // B fragment: column n = lane&15 of n-tile nt, k = kc0 + 8g..8g+7
@@ -316,7 +337,9 @@ __global__ __launch_bounds__(IMGS * 2 * NW * 64, MINW) void conv5x5_igemm(
   // stores scattered over positions ----
   // C/D map: lane holds rows 4*(lane>>4)+r -> window (lane>>4), q = r; col = lane&15
   const int ewin = 4 * w_h + g;  // window index along x (0..7; 7 is the dummy window)
+  DTF_STAMP(2);   // this wave's k-loop issued (MFMAs may still drain)
   __syncthreads();
+  DTF_STAMP(3);   // every wave's k-loop done
   if (MODE == MODE_FWD) {
     bf16* ot = reinterpret_cast<bf16*>(smem);                      // [IMGS][49][NC]
     uint8_t* oa = reinterpret_cast<uint8_t*>(smem) + IMGS * 49 * NC * 2;  // [IMGS][49][NC]
@@ -341,6 +364,7 @@ __global__ __launch_bounds__(IMGS * 2 * NW * 64, MINW) void conv5x5_igemm(
       }
     }
     __syncthreads();
+    DTF_STAMP(4);
     if (!(DTF_ABLATE & 16)) {
       const int nimg = min(IMGS, B - img0);
       u32x4* gp = reinterpret_cast<u32x4*>(out + (size_t)img0 * 49 * NC);
@@ -348,6 +372,10 @@ __global__ __launch_bounds__(IMGS * 2 * NW * 64, MINW) void conv5x5_igemm(
       u32x4* ga = reinterpret_cast<u32x4*>(out_arg + (size_t)img0 * 49 * NC);
       for (int c = tid; c < nimg * 49 * NC / 16; c += NTHREADS) ga[c] = reinterpret_cast<const u32x4*>(oa)[c];
     }
+    DTF_STAMP(5);
+#if DTF_TIMING
+    if (threadIdx.x == 0 && g_timing_buf) g_timing_buf[(size_t)blockIdx.x * 8 + 7] = clock64();
+#endif
   } else {
     bf16* ot = reinterpret_cast<bf16*>(smem);  // [IMGS][196][NC]
     if (ewin < 7) {
@@ -695,6 +723,13 @@ __global__ __launch_bounds__(512, 2) void conv5x5_wgrad(
 using namespace dtf;
 
 #define DTF_LAUNCH_CHECK() (int)hipGetLastError()
+
+#if DTF_TIMING
+extern "C" int dtf_conv2_set_timing_buf(void* p) {
+  long long* q = (long long*)p;
+  return (int)hipMemcpyToSymbol(HIP_SYMBOL(dtf::g_timing_buf), &q, sizeof(q));
+}
+#endif
 
 template <int KTOT, int KC, int NC, int IMGS, int NW, int MODE, int MINW = 1, bool FUSE1 = false>
 static int launch_igemm(const void* in, const void* in_arg, const void* wk,

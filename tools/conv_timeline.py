@@ -1,0 +1,51 @@
+"""Phase timeline of the conv2 forward implicit-GEMM kernel from in-kernel clock stamps.
+  python tools/conv_timeline.py build      (CPU box: diag_build/conv2_timing.so, -DDTF_TIMING=1)
+  python tools/conv_timeline.py run        (GPU)
+Stamps per workgroup (100 MHz wall clock): 0 start, 1 tile staged (+sync), 2 wave 0 left its k-loop,
+3 all waves left the k-loop, 4 epilogue in LDS (+sync), 5 stores issued; 6/7 = shader clock at start/end.
+"""
+import ctypes, os, subprocess, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+OUT = os.path.join(ROOT, "diag_build")
+if sys.argv[1] == "build":
+    os.makedirs(OUT, exist_ok=True)
+    subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",
+                           "-DDTF_TIMING=1", "-I", ROOT + "/csrc/kernels", ROOT + "/csrc/kernels/conv2.hip",
+                           "-o", f"{OUT}/conv2_timing.so"])
+    print("built")
+else:
+    import torch
+    B = int(sys.argv[2]) if len(sys.argv) > 2 else 1024
+    lib = ctypes.CDLL(f"{OUT}/conv2_timing.so")
+    P = ctypes.c_void_p
+    x = torch.rand(B, 14, 14, 32, device="cuda").bfloat16()
+    w = (torch.randn(2, 25 * 64 * 32, device="cuda") * 0.05).bfloat16()
+    bias = torch.zeros(64, device="cuda")
+    pooled = torch.empty(B, 7, 7, 64, device="cuda", dtype=torch.bfloat16)
+    arg = torch.empty(B, 7, 7, 64, device="cuda", dtype=torch.uint8)
+    nblk = (B + 1) // 2
+    buf = torch.zeros(nblk, 8, dtype=torch.int64, device="cuda")
+    s = torch.cuda.current_stream().cuda_stream
+    f = lib.dtf_conv2_fwd; f.argtypes = [P] * 5 + [ctypes.c_int] * 3 + [P]
+    lib.dtf_conv2_set_timing_buf.argtypes = [P]
+    for _ in range(5):
+        f(x.data_ptr(), w.data_ptr(), bias.data_ptr(), pooled.data_ptr(), arg.data_ptr(), B, 32, 64, s)
+    torch.cuda.synchronize()
+    assert lib.dtf_conv2_set_timing_buf(buf.data_ptr()) == 0
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    f(x.data_ptr(), w.data_ptr(), bias.data_ptr(), pooled.data_ptr(), arg.data_ptr(), B, 32, 64, s)
+    e1.record(); torch.cuda.synchronize()
+    t = buf.cpu().double()
+    t0 = t[:, 0].min()
+    ns = (t[:, :6] - t0) * 10.0     # 100 MHz -> ns
+    names = ["start", "staged", "wave0 k-loop end", "all k-loops end", "epilogue in LDS", "stores issued"]
+    print(f"B={B}: {nblk} workgroups, event time {e0.elapsed_time(e1) * 1e3:.1f} us")
+    for i, n in enumerate(names):
+        c = ns[:, i]
+        print(f"  {n:18s} min {c.min() / 1e3:6.2f}  median {c.median() / 1e3:6.2f}  max {c.max() / 1e3:6.2f} us")
+    d = ns[:, 1:] - ns[:, :-1]
+    for i, n in enumerate(["staging", "k-loop (wave 0)", "k-loop skew", "epilogue math", "stores"]):
+        print(f"  phase {n:16s} median {d[:, i].median() / 1e3:6.2f}  max {d[:, i].max() / 1e3:6.2f} us")
+    mhz = ((t[:, 7] - t[:, 6]) / ((t[:, 5] - t[:, 0]) * 10.0) * 1e3)
+    print(f"  shader clock over the workgroup lifetime: median {mhz.median():.0f} MHz")
