@@ -112,15 +112,23 @@ __device__ __forceinline__ float dropout_scale(const DropoutArgs& d, uint64_t of
 // ---------------------------------------------------------------------------
 constexpr unsigned kPoolDead = 4;
 
+// Packed 16-bit formulation (v_pk_lshlrev_b16 / v_pk_ashrrev_i16): the two codes of a dword go to its
+// 16-bit halves, onehot = 1 << code, and the mask of window position q is bit q of onehot smeared over
+// the half (shift it to bit 15, arithmetic shift back).  3 independent VALU ops per (dword, q) and no
+// VCC: the compare + select version was a serial v_cmp -> s_nop -> v_cndmask chain through one VCC
+// (~1300 cycles per call in conv2 wgrad's staging, tools/conv_timeline.py).
 __device__ __forceinline__ void expand_pool_grad(const u32x4& g, const u32x2& a, u32x4 (&o)[4]) {
+  typedef short s16x2 __attribute__((ext_vector_type(2)));
 #pragma unroll
   for (int d = 0; d < 4; ++d) {
     const unsigned ab = (d < 2 ? a[0] : a[1]) >> ((d & 1) * 16);
-    const unsigned a0 = ab & 0xffu, a1 = (ab >> 8) & 0xffu;
+    const unsigned c = (ab & 0xffu) | ((ab & 0xff00u) << 8);          // codes 0..4 in the two halves
+    const s16x2 onehot = (s16x2){1, 1} << __builtin_bit_cast(s16x2, c);
 #pragma unroll
-    for (unsigned q = 0; q < 4; ++q) {
-      const unsigned m = (a0 == q ? 0x0000ffffu : 0u) | (a1 == q ? 0xffff0000u : 0u);
-      o[q][d] = g[d] & m;
+    for (int q = 0; q < 4; ++q) {
+      const s16x2 sh = {(short)(15 - q), (short)(15 - q)};
+      const s16x2 m = (onehot << sh) >> (s16x2){15, 15};              // 0xffff where code == q
+      o[q][d] = g[d] & __builtin_bit_cast(unsigned, m);
     }
   }
 }

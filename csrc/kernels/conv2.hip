@@ -537,6 +537,14 @@ __global__ __launch_bounds__(512, 2) void conv5x5_wgrad(
 
   const int b_begin = blockIdx.x * imgs_per_block;
   const int b_end = min(B, b_begin + imgs_per_block);
+#if DTF_TIMING
+  // slots per workgroup (gridDim.x * blockIdx.y + blockIdx.x), 16 each: wave 0 -> 0..7, wave 7 -> 8..15:
+  // 0 start, 1 loop entered, 2 loop left, 3 reduced, 4 sum(wait for prefetched loads), 5 sum(k-loop), 6 sum(stage), 7 sum(barrier wait)
+  long long* tb = (g_timing_buf && (lane == 0) && (wave == 0 || wave == 7))
+                      ? g_timing_buf + ((size_t)(blockIdx.y * gridDim.x + blockIdx.x) * 16 + (wave ? 8 : 0)) : nullptr;
+  long long t_k = 0, t_s = 0, t_w = 0, t_v = 0, t_prev = wall_clock64();
+  if (tb) tb[0] = t_prev;
+#endif
 
   f32x4 acc[7][2];
 #pragma unroll
@@ -599,11 +607,35 @@ __global__ __launch_bounds__(512, 2) void conv5x5_wgrad(
   __syncthreads();  // zero fill done
   if (b_begin < b_end) stage(0);
   if (b_begin + 1 < b_end) prefetch(b_begin + 1);
+#if DTF_TIMING
+  if (tb) tb[1] = wall_clock64();
+#endif
   for (int b = b_begin; b < b_end; ++b) {
     const int boff = ((b - b_begin) & 1) * kBufElems;
     // image b is staged in buffer boff; every wave is done reading the other buffer (image b-1),
-    // which this iteration refills with image b+1 after its own k-loop
+    // which this iteration refills with image b+1
+#if DTF_TIMING
+    t_prev = wall_clock64();
+#endif
     __syncthreads();
+#if DTF_TIMING
+    { long long t = wall_clock64(); t_w += t - t_prev; t_prev = t; }
+#endif
+    // Image b+1 goes into the other buffer BEFORE this wave's k-loop: the staging waves (0..3: gradient
+    // expansion, ~0.6 us of VALU + LDS writes per image) then work while their SIMD partners (waves 4..7)
+    // already run MFMAs, and run their own k-loop while the partners drain -- with the staging after the
+    // k-loop all eight waves competed for the matrix pipe first and it then sat idle during the staging
+    // (tools/conv_timeline.py: 9.1 us of staging on the critical path of a 31 us kernel).
+#if DTF_TIMING
+    { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); long long t = wall_clock64(); t_v += t - t_prev; t_prev = t; }
+#endif
+    if (b + 1 < b_end) {
+      stage(kBufElems - boff);
+      if (b + 2 < b_end) prefetch(b + 2);
+    }
+#if DTF_TIMING
+    { long long t = wall_clock64(); t_s += t - t_prev; t_prev = t; }
+#endif
     // k-loop over this wave's row pairs, software-pipelined: the 18 transposed reads of step r+2
     // are in flight while the 14 MFMAs of step r issue (two fragment sets, loop unrolled by two)
     const bf16* a_img = a_lane + boff;
@@ -666,11 +698,13 @@ __global__ __launch_bounds__(512, 2) void conv5x5_wgrad(
         mma_frags(af0, bf0);
       }
     }
-    if (b + 1 < b_end) {
-      stage(kBufElems - boff);
-      if (b + 2 < b_end) prefetch(b + 2);
-    }
+#if DTF_TIMING
+    { asm volatile("s_nop 0" ::: "memory"); long long t = wall_clock64(); t_k += t - t_prev; t_prev = t; }
+#endif
   }
+#if DTF_TIMING
+  if (tb) { tb[2] = wall_clock64(); tb[5] = t_k; tb[6] = t_s; tb[7] = t_w; tb[4] = t_v; }
+#endif
 
   // ---- sum the two kh halves through LDS; kh = 0 waves write their taps: rows ci, cols co ----
   __syncthreads();
@@ -686,6 +720,9 @@ __global__ __launch_bounds__(512, 2) void conv5x5_wgrad(
     red[(tw * 58 + 57) * 64 + lane] = bsum[1];
   }
   __syncthreads();
+#if DTF_TIMING
+  if (tb) tb[3] = wall_clock64();
+#endif
   if (kh == 1) return;
   float* slab = part + (size_t)blockIdx.x * (25 * C_IN * C_OUT + C_OUT);
 #pragma unroll

@@ -36,6 +36,31 @@ else:
     e0.record()
     f(x.data_ptr(), w.data_ptr(), bias.data_ptr(), pooled.data_ptr(), arg.data_ptr(), B, 32, 64, s)
     e1.record(); torch.cuda.synchronize()
+    if len(sys.argv) > 3 and sys.argv[3] == "wgrad":
+        G = 64
+        gp = torch.randn(B, 7, 7, 64, device="cuda").bfloat16()
+        arg = torch.randint(0, 5, (B, 7, 7, 64), device="cuda", dtype=torch.uint8)
+        part = torch.empty(G, 25 * 32 * 64 + 64, device="cuda")
+        buf2 = torch.zeros(G * 4, 16, dtype=torch.int64, device="cuda")
+        fw = lib.dtf_conv2_wgrad; fw.argtypes = [P] * 4 + [ctypes.c_int] * 4 + [P]
+        call = lambda: fw(x.data_ptr(), gp.data_ptr(), arg.data_ptr(), part.data_ptr(), B, 32, 64, G, s)
+        lib.dtf_conv2_set_timing_buf(None)
+        for _ in range(5): call()
+        torch.cuda.synchronize()
+        assert lib.dtf_conv2_set_timing_buf(buf2.data_ptr()) == 0
+        call(); torch.cuda.synchronize()
+        t = buf2.cpu().double().reshape(G * 4, 2, 8)
+        t0 = t[:, 0, 0].min()
+        for wv, name in ((0, "wave 0 (stages x + dY)"), (1, "wave 7 (stages x only)")):
+            a = t[:, wv, :]
+            print(f"wgrad B={B} {name}: {G * 4} workgroups, {B // G} images each")
+            for i, n in enumerate(["start", "loop entered", "loop left", "reduced"]):
+                c = (a[:, i] - t0) * 10.0
+                print(f"  {n:14s} min {c.min() / 1e3:6.2f}  median {c.median() / 1e3:6.2f}  max {c.max() / 1e3:6.2f} us")
+            for i, n in ((5, "sum k-loop"), (4, "sum wait for prefetch"), (6, "sum stage+prefetch issue"), (7, "sum barrier wait")):
+                c = a[:, i] * 10.0
+                print(f"  {n:26s} median {c.median() / 1e3:6.2f}  max {c.max() / 1e3:6.2f} us")
+        sys.exit(0)
     t = buf.cpu().double()
     t0 = t[:, 0].min()
     ns = (t[:, :6] - t0) * 10.0     # 100 MHz -> ns
