@@ -161,6 +161,22 @@ __global__ __launch_bounds__(IMGS * 2 * NW * 64, MINW) void conv5x5_igemm(
                           : DTF_STAGGER_MODE == 2 ? ((blockIdx.x >> 3) & 1) != 0 : ((blockIdx.x >> 8) & 1) != 0))
     for (int i = 0; i < DTF_STAGGER; ++i) __builtin_amdgcn_s_sleep(32);   // ~1 us per trip
 
+  // Fused conv1 stage: the dependent chain cursor -> dataset row -> image pixels (two memory round trips)
+  // and the filter fragments are requested BEFORE the LDS zero fill, which then runs under their latency
+  // (tools/conv_timeline.py: 3.8 us from workgroup start to "images in LDS" with the loads after the fill).
+  unsigned c1_px[2] = {0u, 0u};
+  Conv1Frags c1_frags;
+  if constexpr (FUSE1 && MODE == MODE_FWD) {
+    const int b = img0 + w_img, tid_img = tid & 255;
+    const SampleCursor cur = sample_cursor(c1f.smp);
+    c1_frags = conv1_load_frags(c1f.w1, c1f.b1, 32, 0, lane);
+    if (b < B) {
+      const size_t row = sample_row(c1f.smp, cur, c1f.idx, b, tid_img == 0);
+      const unsigned* src = reinterpret_cast<const unsigned*>(c1f.images + row * 784);
+      c1_px[0] = src[tid_img];                      // 2 pixels (one dword) per load
+      c1_px[1] = src[min(tid_img + 256, 391)];
+    }
+  }
   // ---- zero the whole tile (halo + slack), then fill the interior ----
   {
     u32x4 z = {0u, 0u, 0u, 0u};
@@ -195,15 +211,16 @@ __global__ __launch_bounds__(IMGS * 2 * NW * 64, MINW) void conv5x5_igemm(
     uint8_t* arow = arow_all + wave * 512;
     const int b = img0 + w_img;
     const int tid_img = tid & 255, wi = wave & 3;
-    const SampleCursor cur = sample_cursor(c1f.smp);
-    const Conv1Frags frags = conv1_load_frags(c1f.w1, c1f.b1, 32, 0, lane);
+    const Conv1Frags& frags = c1_frags;
     if (b < B) {
-      const size_t row = sample_row(c1f.smp, cur, c1f.idx, b, tid_img == 0);
-      const unsigned* src = reinterpret_cast<const unsigned*>(c1f.images + row * 784);
-      for (int i = tid_img; i < 392; i += 256)   // 2 pixels (one dword) per thread-iteration
-        reinterpret_cast<unsigned*>(img_w)[((i / 14 + 2) * kC1Pitch + 2) / 2 + i % 14] = src[i];
+#pragma unroll
+      for (int r = 0; r < 2; ++r) {
+        const int i = tid_img + r * 256;
+        if (i < 392) reinterpret_cast<unsigned*>(img_w)[((i / 14 + 2) * kC1Pitch + 2) / 2 + i % 14] = c1_px[r];
+      }
     }
     __syncthreads();
+    DTF_STAMP(6);   // (fused forward only: overwrites the start clock) input images in LDS
     for (int rp = wi; rp < 14; rp += 4) {
       conv1_pooled_row(img_w, rp, frags, orow, arow, lane);
       __builtin_amdgcn_wave_barrier();

@@ -61,6 +61,39 @@ else:
                 c = a[:, i] * 10.0
                 print(f"  {n:26s} median {c.median() / 1e3:6.2f}  max {c.max() / 1e3:6.2f} us")
         sys.exit(0)
+    if len(sys.argv) > 3 and sys.argv[3] == "fused":
+        n = 60000
+        images = torch.rand(n, 784, device="cuda").bfloat16()
+        state = torch.zeros(8, dtype=torch.int64, device="cuda")
+        idx_out = torch.zeros(B, dtype=torch.int32, device="cuda")
+        w1 = torch.randn(25, 32, device="cuda") * 0.1
+        b1 = torch.full((32,), 0.1, device="cuda")
+        p1 = torch.empty(B, 14, 14, 32, device="cuda", dtype=torch.bfloat16)
+        arg1 = torch.empty(B, 14, 14, 32, device="cuda", dtype=torch.uint8)
+        ff = lib.dtf_conv12_fwd
+        U, I = ctypes.c_uint, ctypes.c_int
+        ff.argtypes = [P, P, P, P, U, U, U, I, P, P, P, P, P, P, P, P, I, P]
+        call = lambda: ff(images.data_ptr(), None, idx_out.data_ptr(), state.data_ptr(), n, 8, 1234, 1, w1.data_ptr(), b1.data_ptr(),
+                          p1.data_ptr(), arg1.data_ptr(), w.data_ptr(), bias.data_ptr(), pooled.data_ptr(), arg.data_ptr(), B, s)
+        lib.dtf_conv2_set_timing_buf(None)
+        for _ in range(5): assert call() == 0
+        torch.cuda.synchronize()
+        buf.zero_()
+        assert lib.dtf_conv2_set_timing_buf(buf.data_ptr()) == 0
+        call(); torch.cuda.synchronize()
+        t = buf.cpu().double()
+        t0 = t[:, 0].min()
+        order = [0, 6, 1, 2, 3, 4, 5]
+        names = ["start", "images in LDS", "conv1 done, tile staged", "wave0 k-loop end", "all k-loops end", "epilogue in LDS", "stores issued"]
+        ns = (t[:, order] - t0) * 10.0
+        print(f"fused conv1+conv2 forward B={B}: {nblk} workgroups")
+        for i, nm in enumerate(names):
+            c = ns[:, i]
+            print(f"  {nm:24s} min {c.min() / 1e3:6.2f}  median {c.median() / 1e3:6.2f}  max {c.max() / 1e3:6.2f} us")
+        d = ns[:, 1:] - ns[:, :-1]
+        for i, nm in enumerate(["zero fill + image load", "conv1 rows", "k-loop (wave 0)", "k-loop skew", "epilogue math", "stores"]):
+            print(f"  phase {nm:24s} median {d[:, i].median() / 1e3:6.2f}  max {d[:, i].max() / 1e3:6.2f} us")
+        sys.exit(0)
     t = buf.cpu().double()
     t0 = t[:, 0].min()
     ns = (t[:, :6] - t0) * 10.0     # 100 MHz -> ns
