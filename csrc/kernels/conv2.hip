@@ -646,7 +646,10 @@ __global__ __launch_bounds__(512, 2) void conv5x5_wgrad(
 #if DTF_TIMING
     { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); long long t = wall_clock64(); t_v += t - t_prev; t_prev = t; }
 #endif
-    if (b + 1 < b_end) {
+#ifndef DTF_WGRAD_STAGE_LAST
+#define DTF_WGRAD_STAGE_LAST 0   // diagnostic: 1 = the old order (k-loop first)
+#endif
+    if (!DTF_WGRAD_STAGE_LAST && b + 1 < b_end) {
       stage(kBufElems - boff);
       if (b + 2 < b_end) prefetch(b + 2);
     }
@@ -718,6 +721,10 @@ __global__ __launch_bounds__(512, 2) void conv5x5_wgrad(
 #if DTF_TIMING
     { asm volatile("s_nop 0" ::: "memory"); long long t = wall_clock64(); t_k += t - t_prev; t_prev = t; }
 #endif
+    if (DTF_WGRAD_STAGE_LAST && b + 1 < b_end) {
+      stage(kBufElems - boff);
+      if (b + 2 < b_end) prefetch(b + 2);
+    }
   }
 #if DTF_TIMING
   if (tb) { tb[2] = wall_clock64(); tb[5] = t_k; tb[6] = t_s; tb[7] = t_w; tb[4] = t_v; }

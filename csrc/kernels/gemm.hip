@@ -552,7 +552,7 @@ int dtf_gemm_nt(const void* A, const void* B, void* C, const void* bias, int M, 
 
 // fc1 dgrad (C = A . B^T, plain store) and the output-layer weight gradient in ONE launch: the GEMM's
 // tiles plus ceil(H/64) * KS reduction workgroups.  Falls back to two launches when the GEMM is too small
-// for the 128x128 / 512-thread configuration the fused kernel is built for.
+// for the 128x128 / 512-thread configuration the fused kernel is built for, or has more than one round of tiles.
 int dtf_head_wgrad(const void* h1, const void* dlogits, const void* da, void* part, int B, int H, int KS,
                    hipStream_t s);
 int dtf_gemm_nt_head_wgrad(const void* A, const void* Bw, void* C, int M, int N, int K, int lda, int ldb, int ldc,
@@ -561,7 +561,10 @@ int dtf_gemm_nt_head_wgrad(const void* A, const void* Bw, void* C, int M, int N,
   if ((K & 63) || (lda & 7) || (ldb & 7)) return -3;
   if (KS <= 0) return -2;
   const long tiles = (long)((M + 127) / 128) * ((N + 127) / 128);
-  if (tiles < 192) {
+  // One launch only while the GEMM is a single round of tiles with CUs to spare (192..256 tiles on 256 CUs).
+  // With more tiles the reduction workgroups -- dispatched after the last tile -- become a serial tail
+  // (measured: -3 % at 4096 images, -5 % at 8192), and there the separate kernel packs 4 workgroups per CU.
+  if (tiles < 192 || tiles > 256) {
     int rc = dtf_head_wgrad(h1, dlogits, da, part, Bsz, H, KS, s);
     if (rc) return rc;
     return dtf_gemm_nt(A, Bw, C, nullptr, M, N, K, lda, ldb, ldc, 0, 1.0f, 0, nullptr, 0, s);
