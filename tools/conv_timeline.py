@@ -93,6 +93,17 @@ else:
         d = ns[:, 1:] - ns[:, :-1]
         for i, nm in enumerate(["zero fill + image load", "conv1 rows", "k-loop (wave 0)", "k-loop skew", "epilogue math", "stores"]):
             print(f"  phase {nm:24s} median {d[:, i].median() / 1e3:6.2f}  max {d[:, i].max() / 1e3:6.2f} us")
+        # who is slow?  by XCD (blockIdx % 8), by dispatch half, and the deciles of the conv1 phase
+        c1 = d[:, 1] / 1e3
+        bid = torch.arange(nblk)
+        print("  conv1 phase by XCD      :", " ".join(f"{c1[bid % 8 == x].median():5.2f}" for x in range(8)))
+        print("  conv1 phase by half     :", f"{c1[: nblk // 2].median():5.2f} {c1[nblk // 2:].median():5.2f}")
+        qs = torch.quantile(c1, torch.linspace(0, 1, 11, dtype=torch.double))
+        print("  conv1 phase deciles     :", " ".join(f"{q:5.2f}" for q in qs))
+        end = ns[:, 6] / 1e3
+        qs = torch.quantile(end, torch.linspace(0, 1, 11, dtype=torch.double))
+        print("  workgroup end deciles   :", " ".join(f"{q:5.2f}" for q in qs))
+        print("  end by XCD (median/max) :", " ".join(f"{end[bid % 8 == x].median():5.1f}/{end[bid % 8 == x].max():4.1f}" for x in range(8)))
         sys.exit(0)
     t = buf.cpu().double()
     t0 = t[:, 0].min()
