@@ -58,7 +58,7 @@ namespace dtf {
 __device__ long long* g_timing_buf = nullptr;
 #define DTF_STAMP(slot)                                                                     \
   do {                                                                                      \
-    if (threadIdx.x == 0 && g_timing_buf) g_timing_buf[(size_t)blockIdx.x * 8 + (slot)] = wall_clock64(); \
+    if (threadIdx.x == 0 && g_timing_buf) g_timing_buf[(size_t)blockIdx.x * 16 + (slot)] = wall_clock64(); \
   } while (0)
 #else
 #define DTF_STAMP(slot) do {} while (0)
@@ -151,7 +151,7 @@ __global__ __launch_bounds__(IMGS * 2 * NW * 64, MINW) void conv5x5_igemm(
   const int img0 = blockIdx.x * IMGS;
   DTF_STAMP(0);
 #if DTF_TIMING
-  if (threadIdx.x == 0 && g_timing_buf) g_timing_buf[(size_t)blockIdx.x * 8 + 6] = clock64();
+  if (threadIdx.x == 0 && g_timing_buf) g_timing_buf[(size_t)blockIdx.x * 16 + 6] = clock64();
 #endif
 #ifndef DTF_STAGGER_MODE
 #define DTF_STAGGER_MODE 0
@@ -221,8 +221,14 @@ __global__ __launch_bounds__(IMGS * 2 * NW * 64, MINW) void conv5x5_igemm(
     }
     __syncthreads();
     DTF_STAMP(6);   // (fused forward only: overwrites the start clock) input images in LDS
+#if DTF_TIMING
+    long long tr_mma = 0, tr_copy = 0, tr_prev = wall_clock64();
+#endif
     for (int rp = wi; rp < 14; rp += 4) {
       conv1_pooled_row(img_w, rp, frags, orow, arow, lane);
+#if DTF_TIMING
+      { long long t = wall_clock64(); tr_mma += t - tr_prev; tr_prev = t; }
+#endif
       __builtin_amdgcn_wave_barrier();
       if (b < B) {
         // 14 px x 32 ch: 56 x 16 B of bf16 -> global p1 AND this kernel's LDS tile; 28 x 16 B of argmax codes
@@ -237,7 +243,16 @@ __global__ __launch_bounds__(IMGS * 2 * NW * 64, MINW) void conv5x5_igemm(
         if (lane < 28) reinterpret_cast<u4*>(c1f.arg1 + obase)[lane] = reinterpret_cast<const u4*>(arow)[lane];
       }
       __builtin_amdgcn_wave_barrier();
+#if DTF_TIMING
+      { long long t = wall_clock64(); tr_copy += t - tr_prev; tr_prev = t; }
+#endif
     }
+#if DTF_TIMING
+    if (threadIdx.x == 0 && g_timing_buf) {   // wave 0: 4 rows (0, 4, 8, 12)
+      g_timing_buf[(size_t)blockIdx.x * 16 + 8] = tr_mma;
+      g_timing_buf[(size_t)blockIdx.x * 16 + 9] = tr_copy;
+    }
+#endif
   } else if (MODE == MODE_FWD) {
     // all loads of a thread are issued before the first LDS write (one memory latency per
     // block, not one per chunk); indices past the end are clamped and their write is skipped
@@ -391,7 +406,7 @@ __global__ __launch_bounds__(IMGS * 2 * NW * 64, MINW) void conv5x5_igemm(
     }
     DTF_STAMP(5);
 #if DTF_TIMING
-    if (threadIdx.x == 0 && g_timing_buf) g_timing_buf[(size_t)blockIdx.x * 8 + 7] = clock64();
+    if (threadIdx.x == 0 && g_timing_buf) g_timing_buf[(size_t)blockIdx.x * 16 + 7] = clock64();
 #endif
   } else {
     bf16* ot = reinterpret_cast<bf16*>(smem);  // [IMGS][196][NC]

@@ -24,7 +24,7 @@ else:
     pooled = torch.empty(B, 7, 7, 64, device="cuda", dtype=torch.bfloat16)
     arg = torch.empty(B, 7, 7, 64, device="cuda", dtype=torch.uint8)
     nblk = (B + 1) // 2
-    buf = torch.zeros(nblk, 8, dtype=torch.int64, device="cuda")
+    buf = torch.zeros(nblk, 16, dtype=torch.int64, device="cuda")
     s = torch.cuda.current_stream().cuda_stream
     f = lib.dtf_conv2_fwd; f.argtypes = [P] * 5 + [ctypes.c_int] * 3 + [P]
     lib.dtf_conv2_set_timing_buf.argtypes = [P]
@@ -93,6 +93,9 @@ else:
         d = ns[:, 1:] - ns[:, :-1]
         for i, nm in enumerate(["zero fill + image load", "conv1 rows", "k-loop (wave 0)", "k-loop skew", "epilogue math", "stores"]):
             print(f"  phase {nm:24s} median {d[:, i].median() / 1e3:6.2f}  max {d[:, i].max() / 1e3:6.2f} us")
+        rows = t[:, 8:10] * 10.0 / 1e3 / 4.0
+        print(f"  wave 0, per pooled row  : LDS reads + MFMAs + pooling epilogue {rows[:, 0].median():5.2f} us, copy-out {rows[:, 1].median():5.2f} us"
+              f"   (first half {rows[: nblk // 2, 0].median():5.2f} / {rows[: nblk // 2, 1].median():5.2f}, second half {rows[nblk // 2:, 0].median():5.2f} / {rows[nblk // 2:, 1].median():5.2f})")
         # who is slow?  by XCD (blockIdx % 8), by dispatch half, and the deciles of the conv1 phase
         c1 = d[:, 1] / 1e3
         bid = torch.arange(nblk)
