@@ -51,7 +51,14 @@ def resolve_task(F) -> TaskInfo:
 def _pick_backend(F) -> str:
     if F.backend != "auto":
         return F.backend
-    return "hip" if torch.cuda.is_available() else "cpu"
+    if not torch.cuda.is_available():
+        return "cpu"
+    dtype = getattr(F, "dtype", "bf16")
+    if dtype not in ("bf16", "fp32"):
+        raise SystemExit(f"--dtype must be bf16 or fp32, got {dtype!r}")
+    # the hand-written kernels compute in bf16 (fp32 accumulate, fp32 master weights); an all-fp32
+    # run on the GPU is the ATen/MIOpen reference backend
+    return "hip" if dtype == "bf16" else "torch"
 
 
 def run(F, log=print) -> dict:
