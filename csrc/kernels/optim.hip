@@ -174,11 +174,36 @@ struct FusedSgdArgs {
   long wc2_off;
   int c1, c2;
   StepAdvance adv;
+  // Adam variant only: moment arenas and the step counter of this update.  Every workgroup reads *adam_t, so it
+  // cannot be advanced inside this kernel: a "last workgroup to finish" counter was measured at ~35 ns per
+  // workgroup (3000 serialised same-address atomics = +100 us), so a 1-thread kernel bumps it BEFORE the launch.
+  float* m;
+  float* v;
+  const int64_t* adam_t;
 };
 
+// TF AdamOptimizer on one float4 (same arithmetic as adam_update)
+__device__ __forceinline__ void adam4(f32x4& wv, const f32x4& gv, f32x4& mv, f32x4& vv, float lr_t, float b1, float b2,
+                                      float eps, float gs) {
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    const float ge = gv[e] * gs;
+    mv[e] = fmaf(b1, mv[e], (1.f - b1) * ge);
+    vv[e] = fmaf(b2, vv[e], (1.f - b2) * ge * ge);
+    wv[e] -= lr_t * mv[e] / (sqrtf(vv[e]) + eps);
+  }
+}
+
+template <bool ADAM>
 __global__ __launch_bounds__(256) void fused_reduce_sgd(FusedSgdArgs a) {
   __shared__ f32x4 red[16][17];
   const float lr = a.hyper[0] * a.hyper[4];
+  float lr_t = 0.f, b1 = 0.f, b2 = 0.f, eps = 0.f, gsc = 0.f;
+  if (ADAM) {
+    b1 = a.hyper[1]; b2 = a.hyper[2]; eps = a.hyper[3]; gsc = a.hyper[4];
+    const float t = (float)*a.adam_t;   // already advanced for this update by the 1-thread kernel launched before
+    lr_t = a.hyper[0] * sqrtf(1.f - powf(b2, t)) / (1.f - powf(b1, t));
+  }
   if ((int)blockIdx.x < a.reduce_blocks) {
     int k = 0, blk = blockIdx.x;
 #pragma unroll
@@ -221,8 +246,15 @@ __global__ __launch_bounds__(256) void fused_reduce_sgd(FusedSgdArgs a) {
 #pragma unroll
       for (int t = 1; t < 16; ++t) gs += red[t][col];
       *reinterpret_cast<f32x4*>(a.g + e0) = gs;
+      if (ADAM) {
+        f32x4 mv = *reinterpret_cast<const f32x4*>(a.m + e0), vv = *reinterpret_cast<const f32x4*>(a.v + e0);
+        adam4(wv, gs, mv, vv, lr_t, b1, b2, eps, gsc);
+        *reinterpret_cast<f32x4*>(a.m + e0) = mv;
+        *reinterpret_cast<f32x4*>(a.v + e0) = vv;
+      } else {
 #pragma unroll
-      for (int e = 0; e < 4; ++e) wv[e] = fmaf(-lr, gs[e], wv[e]);
+        for (int e = 0; e < 4; ++e) wv[e] = fmaf(-lr, gs[e], wv[e]);
+      }
       *reinterpret_cast<f32x4*>(a.w + e0) = wv;
       store_bf16x4(a.shadow + e0, wv[0], wv[1], wv[2], wv[3]);
       const long ro = e0 - a.out_w_off;
@@ -249,13 +281,20 @@ __global__ __launch_bounds__(256) void fused_reduce_sgd(FusedSgdArgs a) {
     for (long i = a.dense_lo4 + (long)(blockIdx.x - a.reduce_blocks) * 256 + threadIdx.x; i < a.dense_hi4; i += nb * 256) {
       f32x4 wv = reinterpret_cast<const f32x4*>(a.w)[i];
       f32x4 gv = reinterpret_cast<const f32x4*>(a.g)[i];
+      if (ADAM) {
+        f32x4 mv = reinterpret_cast<const f32x4*>(a.m)[i], vv = reinterpret_cast<const f32x4*>(a.v)[i];
+        adam4(wv, gv, mv, vv, lr_t, b1, b2, eps, gsc);
+        reinterpret_cast<f32x4*>(a.m)[i] = mv;
+        reinterpret_cast<f32x4*>(a.v)[i] = vv;
+      } else {
 #pragma unroll
-      for (int e = 0; e < 4; ++e) wv[e] = fmaf(-lr, gv[e], wv[e]);
+        for (int e = 0; e < 4; ++e) wv[e] = fmaf(-lr, gv[e], wv[e]);
+      }
       reinterpret_cast<f32x4*>(a.w)[i] = wv;
       store_bf16x4(a.shadow + 4 * i, wv[0], wv[1], wv[2], wv[3]);
     }
   }
-  advance_state(a.adv);
+  advance_state(a.adv);   // cursor / global_step / dropout offset: nothing in this kernel reads them
 }
 
 }  // namespace dtf
@@ -330,11 +369,13 @@ int dtf_reduce_segments(int count, const void** part, void** out, const int* G, 
 // Fused single-GPU SGD tail (see fused_reduce_sgd).  Segments: part[k] is [G[k]][stride[k]] and
 // lands at arena float offset seg_off[k] (n[k] floats); [dense_lo, dense_hi) is the float range whose
 // gradient is already final.  wc2T and out_wT (fp32 [10][H] transpose of the H x 10 tensor at out_w_off) may be NULL.
-int dtf_fused_reduce_sgd(int count, const void** part, const int* G, const int* n, const long* stride,
-                         const long* seg_off, void* w, void* g, void* shadow, const void* hyper, long dense_lo,
-                         long dense_hi, void* wc2T, long wc2_off, int c1, int c2, void* out_wT, long out_w_off, int H,
-                         void* state, long cursor_inc, long step_inc, long drop_inc, hipStream_t s) {
+static int fused_tail_launch(bool adam, void* m, void* v, int adam_slot, int count, const void** part, const int* G,
+                             const int* n, const long* stride, const long* seg_off, void* w, void* g, void* shadow,
+                             const void* hyper, long dense_lo, long dense_hi, void* wc2T, long wc2_off, int c1, int c2,
+                             void* out_wT, long out_w_off, int H, void* state, long cursor_inc, long step_inc,
+                             long drop_inc, hipStream_t s) {
   if (count < 1 || count > 3 || (dense_lo & 3) || (dense_hi & 3) || (wc2_off & 3)) return -3;
+  if (adam && (!m || !v || !state || adam_slot < 3 || adam_slot > 6)) return -3;
   if (wc2T && ((c1 % 32) || (c2 % 32))) return -3;
   FusedSgdArgs a;
   int blocks = 0;
@@ -364,9 +405,33 @@ int dtf_fused_reduce_sgd(int count, const void** part, const int* G, const int* 
   a.c1 = c1;
   a.c2 = c2;
   a.adv = StepAdvance{(int64_t*)state, cursor_inc, step_inc, drop_inc, -1};
-  const int dense_blocks = grid_for((dense_hi - dense_lo) / 4);
-  hipLaunchKernelGGL(fused_reduce_sgd, dim3(blocks + dense_blocks), dim3(256), 0, s, a);
+  a.m = (float*)m;
+  a.v = (float*)v;
+  a.adam_t = adam ? (const int64_t*)state + adam_slot : nullptr;
+  if (adam) hipLaunchKernelGGL(advance_state_kernel, dim3(1), dim3(1), 0, s, StepAdvance{(int64_t*)state, 0, 0, 0, adam_slot});
+  const int dense_blocks = dense_hi > dense_lo ? grid_for((dense_hi - dense_lo) / 4) : 0;
+  if (adam) hipLaunchKernelGGL(fused_reduce_sgd<true>, dim3(blocks + dense_blocks), dim3(256), 0, s, a);
+  else hipLaunchKernelGGL(fused_reduce_sgd<false>, dim3(blocks + dense_blocks), dim3(256), 0, s, a);
   return (int)hipGetLastError();
+}
+
+int dtf_fused_reduce_sgd(int count, const void** part, const int* G, const int* n, const long* stride,
+                         const long* seg_off, void* w, void* g, void* shadow, const void* hyper, long dense_lo,
+                         long dense_hi, void* wc2T, long wc2_off, int c1, int c2, void* out_wT, long out_w_off, int H,
+                         void* state, long cursor_inc, long step_inc, long drop_inc, hipStream_t s) {
+  return fused_tail_launch(false, nullptr, nullptr, -1, count, part, G, n, stride, seg_off, w, g, shadow, hyper, dense_lo,
+                           dense_hi, wc2T, wc2_off, c1, c2, out_wT, out_w_off, H, state, cursor_inc, step_inc, drop_inc, s);
+}
+
+// The same tail with the Adam update (TF semantics, identical arithmetic to dtf_adam_update): two launches, a
+// 1-thread kernel that advances the step counter state[adam_slot] and the fused kernel.
+int dtf_fused_reduce_adam(int count, const void** part, const int* G, const int* n, const long* stride,
+                          const long* seg_off, void* w, void* g, void* m, void* v, void* shadow, const void* hyper,
+                          long dense_lo, long dense_hi, void* wc2T, long wc2_off, int c1, int c2, void* out_wT,
+                          long out_w_off, int H, void* state, int adam_slot, long cursor_inc, long step_inc,
+                          long drop_inc, hipStream_t s) {
+  return fused_tail_launch(true, m, v, adam_slot, count, part, G, n, stride, seg_off, w, g, shadow, hyper, dense_lo,
+                           dense_hi, wc2T, wc2_off, c1, c2, out_wT, out_w_off, H, state, cursor_inc, step_inc, drop_inc, s);
 }
 
 }  // extern "C"

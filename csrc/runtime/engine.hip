@@ -258,9 +258,15 @@ int dtf_engine_train_step(const DtfEngineDesc* e, long step_inc, hipStream_t s) 
   DTF_TRY(forward_conv_impl(e, e->ds_images, nullptr, 1, e->B, s));
   DTF_TRY(dtf_engine_forward_dense(e, e->ds_labels, e->idx, 1, e->B, 1, s));
   if (e->optimizer != 0) {
-    DTF_TRY(backward_impl(e, e->ds_images, e->idx, 1, s));
-    DTF_TRY(dtf_engine_update_range(e, 0, e->n_total, 1, 1, step_inc, 3, s));
-    return dtf_engine_transposes(e, 1, s);
+    // Adam: the same fused tail (slab sums + update of the whole arena + shadows + packs + state advance)
+    DTF_TRY(backward_impl(e, e->ds_images, e->idx, 0, s));
+    const void* part[3] = {e->head_part, e->c2_part, e->c1_part};
+    int G[3] = {e->head_ks, e->c2_g, e->c1_g}, n[3] = {(int)e->head_stride, (int)e->c2_stride, (int)e->c1_stride};
+    long st[3] = {e->head_stride, e->c2_stride, e->c1_stride};
+    long off[3] = {e->off_out_w, e->off_wc2, e->off_wc1};
+    return dtf_fused_reduce_adam(3, part, G, n, st, off, e->params, e->grads, e->adam_m, e->adam_v, e->shadow, e->hyper,
+                                 e->off_wd1, e->off_out_w, e->wc2T, e->off_wc2, e->c1, e->c2, e->out_wT, e->off_out_w,
+                                 e->hidden, e->state, 3, e->B, step_inc, 1, s);
   }
   if (e->fuse_dense_update) return train_tail_fused_dense(e, step_inc, s);
   DTF_TRY(backward_impl(e, e->ds_images, e->idx, 0, s));
@@ -328,8 +334,9 @@ int dtf_engine_dp_phase3(const DtfEngineDesc* e, long dense_hi, int tail_adam_sl
                                  e->off_wc2, e->wc2T, e->off_wc2, e->c1, e->c2, e->out_wT, e->off_out_w, e->hidden,
                                  e->state, e->B, step_inc, 1, s));
   } else {
+    // update_range refreshes out_wT on whichever stream updates out_w (here, or the dense range on comm)
     DTF_TRY(dtf_engine_update_range(e, dense_hi, e->n_total, 1, 1, step_inc, tail_adam_slot, s));
-    DTF_TRY(dtf_engine_transposes(e, 1, s));
+    DTF_TRY(dtf_conv2_pack_weights(bf16at(e->shadow, e->off_wc2), e->wc2T, e->c1, e->c2, s));
   }
   if (wait_dense) HIP_TRY(hipStreamWaitEvent(s, e->ev_dense_updated, 0));
   return 0;

@@ -65,6 +65,10 @@ _SIGS = {
                              ctypes.POINTER(c_long), ctypes.POINTER(c_long), c_void_p, c_void_p, c_void_p, c_void_p,
                              c_long, c_long, c_void_p, c_long, c_int, c_int, c_void_p, c_long, c_int, c_void_p, c_long, c_long,
                              c_long, c_void_p],
+    "dtf_fused_reduce_adam": [c_int, ctypes.POINTER(c_void_p), ctypes.POINTER(c_int), ctypes.POINTER(c_int),
+                              ctypes.POINTER(c_long), ctypes.POINTER(c_long), c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
+                              c_void_p, c_long, c_long, c_void_p, c_long, c_int, c_int, c_void_p, c_long, c_int, c_void_p,
+                              c_int, c_long, c_long, c_long, c_void_p],
     "dtf_sample_indices": [c_void_p, c_void_p, c_int, c_uint, c_uint, c_uint, c_int, c_void_p],
     "dtf_gen_synthetic": [c_void_p, c_void_p, c_long, c_uint, c_void_p],
     "dtf_init_truncated_normal": [c_void_p, c_long, c_float, c_uint64, c_uint64, c_void_p],

@@ -521,6 +521,51 @@ def test_fused_reduce_sgd(gpu_lib):
     assert state.tolist()[:3] == [100, 1, 1]
 
 
+def test_fused_reduce_adam(gpu_lib):
+    """One launch == reduce_segments + adam_update (whole arena) + wc2 packs + out_w transpose + state advance,
+    bitwise, over three consecutive steps (the step counter is advanced by the last workgroup to finish)."""
+    c1, c2 = 32, 64
+    H = 16
+    n_dense, n_head, n_c2, n_c1 = 40000, H * 10 + 12 + H, 25 * c1 * c2 + c2, 40
+    offs = [0, n_dense, n_dense + n_head, n_dense + n_head + n_c2]     # arena = [dense | head | conv2 | conv1]
+    total = offs[3] + n_c1
+    g = torch.Generator(device="cpu").manual_seed(4)
+    w0 = torch.randn(total, generator=g).to(DEV)
+    hyper = torch.tensor([0.01, 0.9, 0.999, 1e-8, 0.5, 0.0, 0.0, 0.0], device=DEV)
+    w_ref, w1 = w0.clone(), w0.clone()
+    m_ref, v_ref, m1, v1 = (torch.zeros(total, device=DEV) for _ in range(4))
+    sh_ref = torch.zeros(total, dtype=torch.bfloat16, device=DEV)
+    sh1 = torch.zeros(total, dtype=torch.bfloat16, device=DEV)
+    st_ref = torch.zeros(8, dtype=torch.int64, device=DEV)
+    st1 = torch.zeros(8, dtype=torch.int64, device=DEV)
+    wT = torch.zeros(2, 25 * c1 * c2, dtype=torch.bfloat16, device=DEV)
+    owT = torch.zeros(10, H, device=DEV)
+    for step in range(3):
+        grads = torch.randn(total, generator=g).to(DEV)
+        parts = [torch.randn(G, n, generator=g).to(DEV) for G, n in ((5, n_head), (33, n_c2), (7, n_c1))]
+        g_ref, g1 = grads.clone(), grads.clone()
+        for o, p in zip((offs[1], offs[2], offs[3]), parts):
+            pa = (ctypes.c_void_p * 1)(p.data_ptr()); oa = (ctypes.c_void_p * 1)(g_ref.data_ptr() + 4 * o)
+            check(gpu_lib.dtf_reduce_segments(1, pa, oa, (ctypes.c_int * 1)(p.shape[0]), (ctypes.c_int * 1)(p.shape[1]),
+                                              (ctypes.c_long * 1)(p.shape[1]), stream()), "reduce")
+        check(gpu_lib.dtf_adam_update(ptr(w_ref), ptr(g_ref), ptr(m_ref), ptr(v_ref), ptr(sh_ref), ptr(hyper), total,
+                                      ptr(st_ref), 3, ptr(st_ref), 100, 1, 1, stream()), "adam")
+        pa = (ctypes.c_void_p * 3)(*[p.data_ptr() for p in parts])
+        check(gpu_lib.dtf_fused_reduce_adam(3, pa, (ctypes.c_int * 3)(5, 33, 7), (ctypes.c_int * 3)(n_head, n_c2, n_c1),
+                                            (ctypes.c_long * 3)(n_head, n_c2, n_c1), (ctypes.c_long * 3)(offs[1], offs[2], offs[3]),
+                                            ptr(w1), ptr(g1), ptr(m1), ptr(v1), ptr(sh1), ptr(hyper), offs[0], offs[1],
+                                            ptr(wT), offs[2], c1, c2, ptr(owT), offs[1], H, ptr(st1), 3, 100, 1, 1, stream()),
+              "fused adam")
+        torch.cuda.synchronize()
+        assert torch.equal(g1, g_ref)
+        assert torch.equal(m1, m_ref) and torch.equal(v1, v_ref)
+        assert torch.equal(w1, w_ref) and torch.equal(sh1, sh_ref)
+        assert st1.tolist() == st_ref.tolist() == [100 * (step + 1), step + 1, step + 1, step + 1, 0, 0, 0, 0]
+    assert torch.equal(owT, w_ref[offs[1]:offs[1] + H * 10].reshape(H, 10).t().contiguous())
+    f_ref, d_ref = R.conv2_pack_reference(sh_ref[offs[2]:offs[2] + 25 * c1 * c2].reshape(25, c1, c2))
+    assert torch.equal(wT[0], f_ref) and torch.equal(wT[1], d_ref)
+
+
 def test_sgd_and_adam(gpu_lib):
     n = 4 * 1000 + 4
     w0 = torch.randn(n, device=DEV)
