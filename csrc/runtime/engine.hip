@@ -322,17 +322,22 @@ int dtf_engine_dp_phase3(const DtfEngineDesc* e, long dense_hi, int tail_adam_sl
     HIP_TRY(hipEventRecord(e->ev_tail_reduced, tail));
     HIP_TRY(hipStreamWaitEvent(s, e->ev_tail_reduced, 0));
   }
-  if (e->optimizer == 0 && dense_hi == e->off_out_w) {
-    // SGD: update + bf16 shadow + wc2 repack + out_w transpose of the (already all-reduced) tail
+  if (dense_hi == e->off_out_w) {
+    // update + bf16 shadow + wc2 repack + out_w transpose of the (already all-reduced) tail
     // (head | conv2 | conv1) in one launch -- the fused tail kernel with the gradient arena itself as
     // a single "slab" per segment
     const void* part[3] = {f32at(e->grads, e->off_out_w), f32at(e->grads, e->off_wc2), f32at(e->grads, e->off_wc1)};
     int G[3] = {1, 1, 1}, n[3] = {(int)e->head_stride, (int)e->c2_stride, (int)e->c1_stride};
     long st[3] = {e->head_stride, e->c2_stride, e->c1_stride};
     long off[3] = {e->off_out_w, e->off_wc2, e->off_wc1};
-    DTF_TRY(dtf_fused_reduce_sgd(3, part, G, n, st, off, e->params, e->grads, e->shadow, e->hyper, e->off_wc2,
-                                 e->off_wc2, e->wc2T, e->off_wc2, e->c1, e->c2, e->out_wT, e->off_out_w, e->hidden,
-                                 e->state, e->B, step_inc, 1, s));
+    if (e->optimizer == 0)
+      DTF_TRY(dtf_fused_reduce_sgd(3, part, G, n, st, off, e->params, e->grads, e->shadow, e->hyper, e->off_wc2,
+                                   e->off_wc2, e->wc2T, e->off_wc2, e->c1, e->c2, e->out_wT, e->off_out_w, e->hidden,
+                                   e->state, e->B, step_inc, 1, s));
+    else
+      DTF_TRY(dtf_fused_reduce_adam(3, part, G, n, st, off, e->params, e->grads, e->adam_m, e->adam_v, e->shadow,
+                                    e->hyper, e->off_wc2, e->off_wc2, e->wc2T, e->off_wc2, e->c1, e->c2, e->out_wT,
+                                    e->off_out_w, e->hidden, e->state, tail_adam_slot, e->B, step_inc, 1, s));
   } else {
     // update_range refreshes out_wT on whichever stream updates out_w (here, or the dense range on comm)
     DTF_TRY(dtf_engine_update_range(e, dense_hi, e->n_total, 1, 1, step_inc, tail_adam_slot, s));
