@@ -135,3 +135,31 @@ def test_chief_restart_resumes_from_checkpoint(tmp_path):
     steps = [int(m.group(2)) for m in DISPLAY.finditer(r2.stdout)]
     assert steps == [10, 15]                                  # continues at the restored global_step
     assert "model.ckpt-20.index" in os.listdir(logdir)
+
+
+def test_resumes_from_a_logdir_left_by_the_tf_0x_reference(tmp_path):
+    """The reference's Supervisor wrote Saver-V1 files (`model.ckpt-N`, one sstable, no .index) under the names
+    Variable..Variable_8.  Such a logdir must restore here, continue at its global_step, and the run may go on
+    writing either format next to it (reference .idea/MNISTDist.py:154-165)."""
+    import numpy as np
+    from distributed_tensorflow_amd.checkpoint import Saver, bundle, to_tf_names
+    from distributed_tensorflow_amd.models.spec import ModelSpec
+    logdir = str(tmp_path / "train_logs")
+    rng = np.random.RandomState(0)
+    shapes = ModelSpec().shapes()
+    params = {n: (rng.randn(*s) * 0.05).astype(np.float32) for n, s in shapes.items()}
+    Saver(write_version=1).save(to_tf_names(params, global_step=40), os.path.join(logdir, "model.ckpt"), global_step=40)
+    assert sorted(os.listdir(logdir)) == ["checkpoint", "model.ckpt-40"]
+    assert bundle.checkpoint_format(os.path.join(logdir, "model.ckpt-40")) == 1
+    args = ["--synthetic", "--backend=cpu", "--batch_size=16", "--learning_rate=0.01", "--display_step=5",
+            f"--logdir={logdir}", "--noeval"]
+    r = subprocess.run([sys.executable, CLI, "--steps=50", "--saver_write_version=1"] + args, capture_output=True,
+                       text=True, cwd=ROOT)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "Restored from checkpoint" in r.stdout and "model.ckpt-40" in r.stdout
+    assert [int(m.group(2)) for m in DISPLAY.finditer(r.stdout)] == [40, 45]
+    assert "model.ckpt-50" in os.listdir(logdir) and "model.ckpt-50.index" not in os.listdir(logdir)
+    got = bundle.read_bundle(os.path.join(logdir, "model.ckpt-50"))
+    assert int(got["Variable_8"]) == 50 and got["Variable_2"].shape == (3136, 1024)
+    assert not np.array_equal(got["Variable_1"], params["wc2"])          # it trained on from the restored weights
+    assert np.abs(got["Variable_1"] - params["wc2"]).max() < 0.05
