@@ -124,6 +124,16 @@ __global__ __launch_bounds__(256) void reduce_segments(ReduceSegs segs) {
   if (i4 * 4 < sg.n) {
     const float* p = sg.part + i4 * 4;
     int gI = grp;
+    for (; gI + 112 < sg.G; gI += 128) {   // eight loads in flight; same accumulation order as the loop below
+      f32x4 v[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) v[u] = *reinterpret_cast<const f32x4*>(p + (size_t)(gI + 16 * u) * sg.stride);
+#pragma unroll
+      for (int u = 0; u < 8; u += 2) {
+        a0 += v[u];
+        a1 += v[u + 1];
+      }
+    }
     for (; gI + 16 < sg.G; gI += 32) {
       f32x4 v0 = *reinterpret_cast<const f32x4*>(p + (size_t)gI * sg.stride);
       f32x4 v1 = *reinterpret_cast<const f32x4*>(p + (size_t)(gI + 16) * sg.stride);
@@ -220,7 +230,20 @@ __global__ __launch_bounds__(256) void fused_reduce_sgd(FusedSgdArgs a) {
       // the master weight is requested together with the slabs (not after the reduction)
       if (grp == 0) wv = *reinterpret_cast<const f32x4*>(a.w + e0);
       int gI = grp;
-      if (gI + 48 < sg.G) {   // common case (G >= 64): four loads in flight per thread
+      // eight, then four loads in flight per thread; the accumulation order (a0: gI, gI+32, ..; a1: gI+16, ..)
+      // is reduce_segments' order, so the sums stay bitwise identical.  (The conv1 segment has 512 slabs at
+      // 1024 images: two loads per trip made its 13 workgroups a chain of 15 dependent memory round trips.)
+      for (; gI + 112 < sg.G; gI += 128) {
+        f32x4 v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) v[u] = *reinterpret_cast<const f32x4*>(p + (size_t)(gI + 16 * u) * sg.stride);
+#pragma unroll
+        for (int u = 0; u < 8; u += 2) {
+          a0 += v[u];
+          a1 += v[u + 1];
+        }
+      }
+      if (gI + 48 < sg.G) {
         f32x4 v0 = *reinterpret_cast<const f32x4*>(p + (size_t)gI * sg.stride);
         f32x4 v1 = *reinterpret_cast<const f32x4*>(p + (size_t)(gI + 16) * sg.stride);
         f32x4 v2 = *reinterpret_cast<const f32x4*>(p + (size_t)(gI + 32) * sg.stride);
