@@ -459,6 +459,7 @@ __global__ __launch_bounds__(IMGS * 2 * NW * 64, MINW) void conv5x5_igemm(
 #pragma unroll
         for (int j = 0; j < 2; ++j) acc1[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
       __syncthreads();   // dx complete in ot, zero fill done
+      DTF_STAMP(4);
 #pragma unroll
       for (int im = 0; im < IMGS; ++im) {
         if (im < nimg) {   // uniform
@@ -487,6 +488,7 @@ __global__ __launch_bounds__(IMGS * 2 * NW * 64, MINW) void conv5x5_igemm(
       }
       conv1w_reduce_store(acc1, reinterpret_cast<float*>(smem + OT_BYTES), c1w.part + (size_t)blockIdx.x * 26 * 32, 32, 0,
                           wave, lane);
+      DTF_STAMP(5);
     } else {
       __syncthreads();
       if (!(DTF_ABLATE & 16)) {

@@ -61,6 +61,37 @@ else:
                 c = a[:, i] * 10.0
                 print(f"  {n:26s} median {c.median() / 1e3:6.2f}  max {c.max() / 1e3:6.2f} us")
         sys.exit(0)
+    if len(sys.argv) > 3 and sys.argv[3] == "fused_dgrad":
+        n = 60000
+        images = torch.rand(n, 784, device="cuda").bfloat16()
+        idx = torch.randint(0, n, (B,), device="cuda", dtype=torch.int32)
+        gp = torch.randn(B, 7, 7, 64, device="cuda").bfloat16()
+        arg2 = torch.randint(0, 5, (B, 7, 7, 64), device="cuda", dtype=torch.uint8)
+        arg1 = torch.randint(0, 5, (B, 14, 14, 32), device="cuda", dtype=torch.uint8)
+        part1 = torch.empty((B + 1) // 2, 26 * 32, device="cuda")
+        fd = lib.dtf_conv2_dgrad_conv1_wgrad
+        fd.argtypes = [P] * 7 + [ctypes.c_int, P]
+        call = lambda: fd(gp.data_ptr(), arg2.data_ptr(), w[1].data_ptr(), images.data_ptr(), idx.data_ptr(),
+                          arg1.data_ptr(), part1.data_ptr(), B, s)
+        lib.dtf_conv2_set_timing_buf(None)
+        for _ in range(5): assert call() == 0
+        torch.cuda.synchronize()
+        buf.zero_()
+        assert lib.dtf_conv2_set_timing_buf(buf.data_ptr()) == 0
+        call(); torch.cuda.synchronize()
+        t = buf.cpu().double()
+        t0 = t[:, 0].min()
+        order = [0, 1, 2, 3, 4, 5]
+        names = ["start", "gradient tile staged", "wave0 k-loop end", "all k-loops end", "dx in LDS + c1w loads", "conv1 wgrad slab written"]
+        ns = (t[:, order] - t0) * 10.0
+        print(f"fused conv2 dgrad + conv1 wgrad B={B}: {nblk} workgroups")
+        for i, nm in enumerate(names):
+            c = ns[:, i]
+            print(f"  {nm:26s} min {c.min() / 1e3:6.2f}  median {c.median() / 1e3:6.2f}  max {c.max() / 1e3:6.2f} us")
+        d = ns[:, 1:] - ns[:, :-1]
+        for i, nm in enumerate(["staging (pool/ReLU grad)", "k-loop (wave 0)", "k-loop skew", "dx -> LDS, zero fill", "conv1 wgrad (2 images)"]):
+            print(f"  phase {nm:26s} median {d[:, i].median() / 1e3:6.2f}  max {d[:, i].max() / 1e3:6.2f}   first half {d[: nblk // 2, i].median() / 1e3:5.2f}  second half {d[nblk // 2:, i].median() / 1e3:5.2f} us")
+        sys.exit(0)
     if len(sys.argv) > 3 and sys.argv[3] == "fused":
         n = 60000
         images = torch.rand(n, 784, device="cuda").bfloat16()
