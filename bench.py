@@ -67,7 +67,12 @@ def main():
 
     use_graph = False
     if world > 1:
-        dp = SyncDataParallel(eng, tail_group=torch.distributed.new_group())
+        try:   # second communicator: the small tail all-reduce must not queue behind the 12.8 MB one inside RCCL
+            tail_group = torch.distributed.new_group()
+        except Exception as e:   # still correct without it, only slower: the tail then rides the comm stream
+            print(f"[bench] rank {rank}: no second communicator ({e}); tail all-reduce shares the first", file=sys.stderr)
+            tail_group = None
+        dp = SyncDataParallel(eng, tail_group=tail_group)
         dp.broadcast_parameters()
         step = dp.train_step
     else:
