@@ -151,6 +151,17 @@ def test_sync_dp_world1_rccl_matches_plain_engine(gpu_lib, dataset):
         assert torch.equal(a.params, b.params)
         assert torch.equal(a.shadow, b.shadow) and torch.equal(a.wc2T, b.wc2T)
         assert a.global_step == b.global_step == 5
+        # one communicator only (bench.py's fallback): the tail collective rides the comm stream behind the dense one
+        c = HipEngine(ModelSpec(), 128, dataset, learning_rate=0.01, seed=4)
+        c.init_params(seed=2)
+        dp1 = SyncDataParallel(c)
+        assert dp1.tail_stream is dp1.comm_stream
+        dp1.broadcast_parameters()
+        for _ in range(5):
+            dp1.train_step()
+        dp1.flush()
+        torch.cuda.synchronize()
+        assert torch.equal(a.params, c.params) and torch.equal(a.wc2T, c.wc2T)
         # Adam: per-range step counters keep the deferred dense update and the tail update in step
         a2 = HipEngine(ModelSpec(), 64, dataset, optimizer="adam", learning_rate=1e-3, seed=4)
         b2 = HipEngine(ModelSpec(), 64, dataset, optimizer="adam", learning_rate=1e-3, seed=4)
