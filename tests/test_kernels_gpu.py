@@ -483,8 +483,10 @@ def test_reduce_segments(gpu_lib):
     assert float(out[1076:].abs().max()) == 0.0
 
 
-def test_fused_reduce_sgd(gpu_lib):
-    """One launch == reduce_segments + sgd_update + wc2 transpose, bitwise."""
+@pytest.mark.parametrize("Gs", [(5, 33, 7), (200, 129, 513)])
+def test_fused_reduce_sgd(gpu_lib, Gs):
+    """One launch == reduce_segments + sgd_update + wc2 transpose, bitwise (the second case runs the
+    eight-loads-in-flight loops of both reductions, which must keep the same summation order)."""
     c1, c2 = 32, 64
     H = 16
     n_head, n_dense, n_c2, n_c1 = H * 10 + 12 + H, 1000, 25 * c1 * c2 + c2, 40
@@ -493,7 +495,7 @@ def test_fused_reduce_sgd(gpu_lib):
     g = torch.Generator(device="cpu").manual_seed(3)
     w0 = torch.randn(total, generator=g).to(DEV)
     grads = torch.randn(total, generator=g).to(DEV)
-    parts = [torch.randn(G, n, generator=g).to(DEV) for G, n in ((5, n_head), (33, n_c2), (7, n_c1))]
+    parts = [torch.randn(G, n, generator=g).to(DEV) for G, n in zip(Gs, (n_head, n_c2, n_c1))]
     hyper = torch.tensor([0.1, 0.9, 0.999, 1e-8, 0.5, 0.0, 0.0, 0.0], device=DEV)
     # reference path
     w_ref, g_ref = w0.clone(), grads.clone()
@@ -510,10 +512,13 @@ def test_fused_reduce_sgd(gpu_lib):
     owT = torch.zeros(10, H, device=DEV)
     state = torch.zeros(8, dtype=torch.int64, device=DEV)
     pa = (ctypes.c_void_p * 3)(*[p.data_ptr() for p in parts])
-    check(gpu_lib.dtf_fused_reduce_sgd(3, pa, (ctypes.c_int * 3)(5, 33, 7), (ctypes.c_int * 3)(n_head, n_c2, n_c1),
+    check(gpu_lib.dtf_fused_reduce_sgd(3, pa, (ctypes.c_int * 3)(*Gs), (ctypes.c_int * 3)(n_head, n_c2, n_c1),
                                        (ctypes.c_long * 3)(n_head, n_c2, n_c1), (ctypes.c_long * 3)(offs[0], offs[2], offs[3]),
                                        ptr(w1), ptr(g1), ptr(sh1), ptr(hyper), offs[1], offs[2], ptr(wT), offs[2], c1, c2,
                                        ptr(owT), offs[0], H, ptr(state), 100, 1, 1, stream()), "fused")
+    for o, p_ in zip((offs[0], offs[2], offs[3]), parts):     # and both agree with an fp64 sum of the slabs
+        want = p_.double().sum(0)
+        assert float((g1[o:o + p_.shape[1]].double() - want).abs().max()) < 1e-4 * max(1.0, float(want.abs().max()))
     assert torch.equal(owT, w_ref[:H * 10].reshape(H, 10).t().contiguous())
     assert torch.equal(g1, g_ref) and torch.equal(w1, w_ref) and torch.equal(sh1, sh_ref)
     f_ref, d_ref = R.conv2_pack_reference(sh_ref[offs[2]:offs[2] + 25 * c1 * c2].reshape(25, c1, c2))
