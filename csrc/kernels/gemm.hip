@@ -319,6 +319,17 @@ __global__ __launch_bounds__(NW * 64) void gemm_tn_bf16(const bf16* A, const bf1
     static_assert(BM == 128 && BN == 128 && NW == 8, "SGD epilogue is written for the 128x128x8-wave tile");
     constexpr int GP = BN + 4;
     static_assert(64 * GP * 4 <= BK * PA * 2 * 2, "gradient half-tile must fit an operand's LDS buffers");
+    // All eight master-weight float4s of this thread are requested up front, before the gradient tile is
+    // even staged: C is loaded AND stored below, so the compiler keeps "load k+1" behind "store k" and the
+    // update was a chain of eight dependent memory round trips (clamped addresses: the loads are unconditional).
+    constexpr int NK = BM * BN / 4 / NT;
+    f32x4 wreg[NK];
+#pragma unroll
+    for (int k = 0; k < NK; ++k) {
+      const int c = tid + k * NT, row = c / (BN / 4), c4 = c % (BN / 4);
+      const int mrow = min(m0 + row, M - 1), n = min(n0 + c4 * 4, N - 4);
+      wreg[k] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(C + (size_t)mrow * ldc + n));
+    }
     float* gt = reinterpret_cast<float*>(wm == 0 ? &sA[0][0] : &sB[0][0]);
 #pragma unroll
     for (int i = 0; i < MT; ++i)
@@ -329,14 +340,14 @@ __global__ __launch_bounds__(NW * 64) void gemm_tn_bf16(const bf16* A, const bf1
     __syncthreads();
     const float lr = hyper[0] * hyper[4];
 #pragma unroll
-    for (int k = 0; k < BM * BN / 4 / NT; ++k) {
+    for (int k = 0; k < NK; ++k) {
       const int c = tid + k * NT, row = c / (BN / 4), c4 = c % (BN / 4);
       const int mrow = m0 + row, n = n0 + c4 * 4;
       if (mrow < M && n < N) {
         const float* gsrc = reinterpret_cast<const float*>(row < 64 ? &sA[0][0] : &sB[0][0]) + (row & 63) * GP + c4 * 4;
         const f32x4 gv = *reinterpret_cast<const f32x4*>(gsrc);
         const size_t o = (size_t)mrow * ldc + n;
-        f32x4 w = *reinterpret_cast<const f32x4*>(C + o);
+        f32x4 w = wreg[k];
 #pragma unroll
         for (int e = 0; e < 4; ++e) w[e] = fmaf(-lr, gv[e], w[e]);
         *reinterpret_cast<f32x4*>(C + o) = w;
