@@ -146,4 +146,20 @@ __device__ __forceinline__ float wave_max(float v) {
   return v;
 }
 
+// ---------------------------------------------------------------------------
+// Raw buffer loads: unconditional (out-of-range reads return 0), no per-load address VGPR pair, and --
+// unlike loads through a const __restrict__ pointer -- never sunk to their first use by the scheduler,
+// so a prefetch stays where it is written (pair with __builtin_amdgcn_sched_barrier(0)).
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void* p, size_t bytes) {
+  const uint32_t n = bytes > 0xfffffff0ull ? 0xfffffff0u : (uint32_t)bytes;
+  return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), 0, (int)n, 0x00020000);
+}
+__device__ __forceinline__ u32x4 buf_load16(__amdgpu_buffer_rsrc_t r, uint32_t voff, uint32_t soff) {
+  return __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(r, (int)voff, (int)soff, 0));
+}
+__device__ __forceinline__ u32x2 buf_load8(__amdgpu_buffer_rsrc_t r, uint32_t voff, uint32_t soff) {
+  return __builtin_bit_cast(u32x2, __builtin_amdgcn_raw_buffer_load_b64(r, (int)voff, (int)soff, 0));
+}
+
 }  // namespace dtf

@@ -197,6 +197,36 @@ __global__ __launch_bounds__(IMGS * 2 * NW * 64, MINW) void conv5x5_igemm(
 #pragma unroll
     for (int j = 0; j < NT; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
+  // MODE_DGRAD staging items: (image, pooled position, 8-channel chunk); thread t owns items t, t + NTHREADS, ..
+  // Their global loads are issued one K chunk AHEAD (before the k-loop of the previous chunk, before the zero
+  // fill for the first one): as two load -> expand -> write trips after the barrier they were two dependent
+  // memory round trips, 2 us per chunk with the matrix pipe idle (tools/conv_timeline.py run .. fused_dgrad).
+  constexpr int DG_NCHUNK = IMGS * 49 * CH8;
+  constexpr int DG_ROUNDS = (MODE == MODE_DGRAD) ? (DG_NCHUNK + NTHREADS - 1) / NTHREADS : 1;
+  u32x4 dg_g[DG_ROUNDS];
+  u32x2 dg_a[DG_ROUNDS];
+  const __amdgpu_buffer_rsrc_t dg_rg = make_rsrc(in, MODE == MODE_DGRAD ? (size_t)B * 49 * KTOT * 2 : 0);
+  const __amdgpu_buffer_rsrc_t dg_ra = make_rsrc(in_arg, MODE == MODE_DGRAD ? (size_t)B * 49 * KTOT : 0);
+  auto dgrad_prefetch = [&](int kc) {
+#pragma unroll
+    for (int r = 0; r < DG_ROUNDS; ++r) {
+      const int c = min(tid + r * NTHREADS, DG_NCHUNK - 1);
+      const int ch = c % CH8, pp = (c / CH8) % 49, im = c / (CH8 * 49);
+      const uint32_t off = (uint32_t)(((size_t)min(img0 + im, B - 1) * 49 + pp) * KTOT + kc + ch * 8);
+      if (DTF_ABLATE & 8) {
+        dg_g[r] = (u32x4){0u, 0u, 0u, 0u};
+        dg_a[r] = (u32x2){0x04040404u, 0x04040404u};
+      } else {
+        dg_g[r] = buf_load16(dg_rg, off * 2, 0);
+        dg_a[r] = buf_load8(dg_ra, off, 0);
+      }
+    }
+  };
+  if constexpr (MODE == MODE_DGRAD) {
+    dgrad_prefetch(0);
+    __builtin_amdgcn_sched_barrier(0);
+  }
+
 #pragma unroll 1
   for (int kc0 = 0; kc0 < KTOT; kc0 += KC) {
   __syncthreads();  // zero fill done / previous chunk fully consumed
@@ -277,26 +307,26 @@ __global__ __launch_bounds__(IMGS * 2 * NW * 64, MINW) void conv5x5_igemm(
         *reinterpret_cast<u32x4*>(tile + ((size_t)im * TPOS + tp) * KP + (SWZ ? (ch ^ ((tp >> 1) & 3)) : ch) * 8) = v[r];
     }
   } else {
-    // max-pool / ReLU gradient: route g to the saved argmax position.
-    constexpr int NCHUNK = IMGS * 49 * CH8;
-    for (int c = tid; c < NCHUNK; c += NTHREADS) {
-      int ch = c % CH8;
-      int pp = (c / CH8) % 49;
-      int im = c / (CH8 * 49);
-      int b = img0 + im;
-      if (b < B && !(DTF_ABLATE & 8)) {
-        size_t off = ((size_t)b * 49 + pp) * KTOT + kc0 + ch * 8;
-        u32x4 gq = *reinterpret_cast<const u32x4*>(in + off);
-        u32x2 a2 = *reinterpret_cast<const u32x2*>(in_arg + off);
-        int py = pp / 7, px = pp % 7;
+    // max-pool / ReLU gradient: route g (prefetched above) to the saved argmax position.
+#pragma unroll
+    for (int r = 0; r < DG_ROUNDS; ++r) {
+      const int c = tid + r * NTHREADS;
+      const int ch = c % CH8, pp = (c / CH8) % 49, im = c / (CH8 * 49);
+      if (c < DG_NCHUNK && img0 + im < B) {
+        const int py = pp / 7, px = pp % 7;
         u32x4 o[4];
-        expand_pool_grad(gq, a2, o);
+        expand_pool_grad(dg_g[r], dg_a[r], o);
 #pragma unroll
         for (int qq = 0; qq < 4; ++qq) {
           int tp = (2 * py + (qq >> 1) + 2) * TW + (2 * px + (qq & 1) + 2);
           *reinterpret_cast<u32x4*>(tile + ((size_t)im * TPOS + tp) * KP + (SWZ ? (ch ^ ((tp >> 1) & 3)) : ch) * 8) = o[qq];
         }
       }
+    }
+    // the next chunk's loads fly during this chunk's k-loop
+    if (kc0 + KC < KTOT) {
+      dgrad_prefetch(kc0 + KC);
+      __builtin_amdgcn_sched_barrier(0);
     }
   }
   __syncthreads();

@@ -64,14 +64,6 @@ __device__ __forceinline__ void xcd_tile(int gx, int gy, int& tx, int& ty) {
 // 128x128 tiles run 8 waves (2 per SIMD): while one wave waits on LDS or at the barrier the other
 // issues MFMAs.  A 4-wave tile measured ~1350 cycles per phase for 512 cycles of MFMA.
 // ---------------------------------------------------------------------------------------------
-__device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void* p, size_t bytes) {
-  const uint32_t n = bytes > 0xfffffff0ull ? 0xfffffff0u : (uint32_t)bytes;
-  return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), 0, (int)n, 0x00020000);
-}
-__device__ __forceinline__ u32x4 buf_load16(__amdgpu_buffer_rsrc_t r, uint32_t voff, uint32_t soff) {
-  return __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(r, (int)voff, (int)soff, 0));
-}
-
 template <int A_CH, int B_CH, class GL, class SW, class CP>
 __device__ __forceinline__ void gemm_pipeline(int T, GL&& gload, SW&& swrite, CP&& compute) {
   u32x4 ra0[A_CH], rb0[B_CH], ra1[A_CH], rb1[B_CH];
