@@ -77,7 +77,7 @@ def main():
         step = dp.train_step
     else:
         # The whole step is one foreign call into the native executor either way.  Measured A/B: with the
-        # single-stream 9-kernel step, eager launches run 2.5-5 % faster than replaying the captured graph up
+        # single-stream 8-kernel step, eager launches run 2.5-5 % faster than replaying the captured graph up
         # to 1024 images/GPU; from 2048 up the graph (with its backward fork/join) wins by ~6 %.
         use_graph = args.graph or (not args.no_graph and B > 1024)
         if use_graph:

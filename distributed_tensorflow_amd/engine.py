@@ -96,7 +96,7 @@ class HipEngine:
         self.step_inc = int(step_inc)
         self.dataset = dataset
         # fork/join side streams in backward (conv2 wgrad || dgrad chain || fc1 wgrad).  Measured A/B on the
-        # 9-kernel step: -5 % at batch 1024 (fork/join costs more than the overlap returns), +3..4 % from 2048 up.
+        # 8..9-kernel step: -5 % at batch 1024 (fork/join costs more than the overlap returns), +3..4 % from 2048 up.
         self.multi_stream = (batch > 1024) if multi_stream is None else bool(multi_stream)
         self.fuse_dense_update = bool(fuse_dense_update)
         dev, B, H, C1, C2, FLAT = self.device, self.B, spec.hidden, spec.c1, spec.c2, spec.flat
