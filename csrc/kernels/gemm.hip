@@ -89,8 +89,11 @@ __device__ __forceinline__ void gemm_pipeline(int T, GL&& gload, SW&& swrite, CP
 // HEADW: the launch is a 1-D grid of the GEMM's tiles FOLLOWED by hw.nbx * KS workgroups that compute the
 // output-layer weight gradient (head_wgrad_core.hpp) -- independent work that fills the CUs this GEMM
 // leaves idle (fc1 dgrad: 200 tiles on 256 CUs) instead of paying for a launch of its own.
+#ifndef DTF_GEMM_MINW
+#define DTF_GEMM_MINW 1   // diagnostic: minimum waves per SIMD the GEMM kernels are compiled for
+#endif
 template <int BM, int BN, int NW, int EPI, bool HEADW = false>
-__global__ __launch_bounds__(NW * 64) void gemm_nt_bf16(const bf16* A, const bf16* Bm, bf16* __restrict__ C,
+__global__ __launch_bounds__(NW * 64, DTF_GEMM_MINW) void gemm_nt_bf16(const bf16* A, const bf16* Bm, bf16* __restrict__ C,
                                                         const float* __restrict__ bias, int M, int N, int K,
                                                         int lda, int ldb, int ldc, DropoutArgs drop,
                                                         HeadWgradArgs hw = HeadWgradArgs{}) {
@@ -214,7 +217,7 @@ __global__ __launch_bounds__(NW * 64) void gemm_nt_bf16(const bf16* A, const bf1
 // model's gradient bytes) then never goes through memory.  Single-GPU SGD only: with data
 // parallelism the gradient has to exist for the all-reduce.
 template <int BM, int BN, int NW, bool SGD = false>
-__global__ __launch_bounds__(NW * 64) void gemm_tn_bf16(const bf16* A, const bf16* Bm, float* __restrict__ C,
+__global__ __launch_bounds__(NW * 64, DTF_GEMM_MINW) void gemm_tn_bf16(const bf16* A, const bf16* Bm, float* __restrict__ C,
                                                         int M, int N, int K, int lda, int ldb, int ldc,
                                                         bf16* __restrict__ shadow = nullptr,
                                                         const float* __restrict__ hyper = nullptr) {
@@ -371,7 +374,7 @@ __global__ __launch_bounds__(NW * 64) void gemm_tn_bf16(const bf16* A, const bf1
 // group g is k = 8g + j on BOTH operands; the two 128-byte halves of every row with bit 3 set are
 // swapped, which makes these transposed reads bank-conflict free (rows r and r+8 would collide).
 template <int BM, int BN, int NW>
-__global__ __launch_bounds__(NW * 64) void gemm_nn_splitk_bf16(const bf16* A, const bf16* Bm,
+__global__ __launch_bounds__(NW * 64, DTF_GEMM_MINW) void gemm_nn_splitk_bf16(const bf16* A, const bf16* Bm,
                                                                float* __restrict__ Cp, int M, int N, int K,
                                                                int lda, int ldb, int tiles_per_split) {
   static_assert(BN == 128, "the half-swap swizzle below assumes 256-byte B rows");

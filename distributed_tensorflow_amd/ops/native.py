@@ -119,7 +119,9 @@ _ENGINE_SIGS = {
 
 
 def lib_path() -> Path:
-    return _LIB_DIR / _LIB_NAME
+    # DTF_KERNELS_LIB: load a diagnostic build of the kernel library instead (A/B measurements)
+    override = os.environ.get("DTF_KERNELS_LIB")
+    return Path(override) if override else _LIB_DIR / _LIB_NAME
 
 
 def available() -> bool:
