@@ -133,11 +133,20 @@ __device__ __forceinline__ void expand_pool_grad(const u32x4& g, const u32x2& a,
   }
 }
 
-// Wave-level sum across all 64 lanes.
+// Wave-level sum across all 64 lanes, result in every lane (wave-uniform).  Six DPP adds on the VALU
+// (quad swaps, half-row / row mirrors, row broadcasts into the next rows; the total lands in lane 63 and is
+// read back as a scalar) instead of six __shfl_xor = ds_bpermute round trips through the LDS pipe: the ten
+// reductions of the head kernel were 2.4 us of a 7 us row (tools/conv_timeline.py run 1024 head).
+#define DTF_DPP_ADD(v, ctrl, row_mask) \
+  ((v) + __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, (v)), (ctrl), (row_mask), 0xf, false)))
 __device__ __forceinline__ float wave_sum(float v) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-  return v;
+  v = DTF_DPP_ADD(v, 0xB1, 0xf);    // quad_perm [1,0,3,2]
+  v = DTF_DPP_ADD(v, 0x4E, 0xf);    // quad_perm [2,3,0,1]
+  v = DTF_DPP_ADD(v, 0x141, 0xf);   // row_half_mirror: sums of 8
+  v = DTF_DPP_ADD(v, 0x140, 0xf);   // row_mirror: every lane holds its row's sum of 16
+  v = DTF_DPP_ADD(v, 0x142, 0xa);   // row_bcast15 into rows 1 and 3
+  v = DTF_DPP_ADD(v, 0x143, 0xc);   // row_bcast31 into rows 2 and 3: lane 63 holds the total
+  return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63));
 }
 
 __device__ __forceinline__ float wave_max(float v) {

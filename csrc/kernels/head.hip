@@ -17,7 +17,23 @@
 #include "common.hpp"
 #include "head_wgrad_core.hpp"
 
+// Diagnostic (-DDTF_TIMING=1, tools/conv_timeline.py run .. head): thread 0 of every workgroup stamps the 100 MHz
+// wall clock at the phase boundaries of its first row
+#ifndef DTF_TIMING
+#define DTF_TIMING 0
+#endif
+
 namespace dtf {
+
+#if DTF_TIMING
+__device__ long long* g_head_timing = nullptr;
+#define DTF_HSTAMP(slot)                                                                                     \
+  do {                                                                                                       \
+    if (threadIdx.x == 0 && g_head_timing && b == (int)blockIdx.x) g_head_timing[(size_t)blockIdx.x * 8 + (slot)] = wall_clock64(); \
+  } while (0)
+#else
+#define DTF_HSTAMP(slot) do {} while (0)
+#endif
 
 constexpr int kCls = 10;
 
@@ -44,13 +60,16 @@ __global__ __launch_bounds__(256) void head_fwd_bwd(
     const int* __restrict__ labels, const int* __restrict__ idx, float* __restrict__ logits_out,
     float* __restrict__ loss_rows, float* __restrict__ correct_rows, float* __restrict__ dlogits,
     bf16* __restrict__ da, int B, int H, float grad_scale, float inv_keep, int backward) {
-  __shared__ float zred[4][kCls];
+  __shared__ __attribute__((aligned(16))) float zred[kCls][4];   // [class][wave]: one 16-byte read per class
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const bool do_drop = epi.part && epi.drop.keep_prob < 1.0f;
   const uint64_t drop_off = (do_drop && epi.drop.state) ? (uint64_t)epi.drop.state[2] : 0;
   const size_t BH = (size_t)B * H;
 
   for (int b = blockIdx.x; b < B; b += gridDim.x) {
+    DTF_HSTAMP(0);
+    // two dependent loads (gather index, then label): requested first, needed only after the reductions
+    const int label = labels[idx ? idx[b] : b];
     bf16* hrow = h1 + (size_t)b * H;
     float z[kCls];
 #pragma unroll
@@ -83,19 +102,23 @@ __global__ __launch_bounds__(256) void head_fwd_bwd(
         for (int e = 0; e < 4; ++e) z[c] = fmaf(hf[e], wv[e], z[c]);
       }
     }
+    DTF_HSTAMP(1);   // h1 row produced + partial logits
     // fixed-order reduction: lanes (butterfly), then the four waves in index order
 #pragma unroll
     for (int c = 0; c < kCls; ++c) z[c] = wave_sum(z[c]);
     __syncthreads();   // zred free (previous row consumed)
     if (lane == 0) {
 #pragma unroll
-      for (int c = 0; c < kCls; ++c) zred[wave][c] = z[c];
+      for (int c = 0; c < kCls; ++c) zred[c][wave] = z[c];
     }
     __syncthreads();
 #pragma unroll
-    for (int c = 0; c < kCls; ++c) z[c] = ((zred[0][c] + zred[1][c]) + (zred[2][c] + zred[3][c])) + bias[c];
+    for (int c = 0; c < kCls; ++c) {
+      const f32x4 zw = *reinterpret_cast<const f32x4*>(&zred[c][0]);
+      z[c] = ((zw[0] + zw[1]) + (zw[2] + zw[3])) + bias[c];
+    }
 
-    const int label = labels[idx ? idx[b] : b];
+    DTF_HSTAMP(2);   // logits reduced
     float zmax = z[0];
     int amax = 0;
 #pragma unroll
@@ -122,6 +145,7 @@ __global__ __launch_bounds__(256) void head_fwd_bwd(
       for (int c = 0; c < kCls; ++c) v = (c == tid) ? z[c] : v;
       logits_out[(size_t)b * kCls + tid] = v;
     }
+    DTF_HSTAMP(3);   // softmax / loss
     if (!backward) continue;
     if (tid < kCls) {
       float v = 0.f;
@@ -144,6 +168,7 @@ __global__ __launch_bounds__(256) void head_fwd_bwd(
       for (int e = 0; e < 4; ++e) o[e] = (bf16)(((float)hv[e] > 0.f) ? sacc[e] * inv_keep : 0.f);
       *reinterpret_cast<bf16x4*>(drow + j0) = o;
     }
+    DTF_HSTAMP(4);   // da row stored
   }
 }
 
@@ -163,6 +188,13 @@ __global__ __launch_bounds__(256) void head_wgrad(HeadWgradArgs a) {
 }  // namespace dtf
 
 using namespace dtf;
+
+#if DTF_TIMING
+extern "C" int dtf_head_set_timing_buf(void* p) {
+  long long* q = (long long*)p;
+  return (int)hipMemcpyToSymbol(HIP_SYMBOL(dtf::g_head_timing), &q, sizeof(q));
+}
+#endif
 
 extern "C" {
 

@@ -12,7 +12,47 @@ if sys.argv[1] == "build":
     subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",
                            "-DDTF_TIMING=1", "-I", ROOT + "/csrc/kernels", ROOT + "/csrc/kernels/conv2.hip",
                            "-o", f"{OUT}/conv2_timing.so"])
+    subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",
+                           "-DDTF_TIMING=1", "-I", ROOT + "/csrc/kernels", ROOT + "/csrc/kernels/head.hip",
+                           "-o", f"{OUT}/head_timing.so"])
     print("built")
+elif len(sys.argv) > 3 and sys.argv[3] == "head":
+    import torch
+    B = int(sys.argv[2]); H, S = 1024, 3
+    lib = ctypes.CDLL(f"{OUT}/head_timing.so")
+    P, I, F = ctypes.c_void_p, ctypes.c_int, ctypes.c_float
+    part = torch.randn(S, B, H, device="cuda") * 0.3
+    bias1 = torch.randn(H, device="cuda") * 0.1
+    h1 = torch.empty(B, H, device="cuda", dtype=torch.bfloat16)
+    wT = torch.randn(10, H, device="cuda") * 0.05
+    bias = torch.zeros(10, device="cuda")
+    labels = torch.randint(0, 10, (B,), device="cuda", dtype=torch.int32)
+    logits = torch.empty(B, 10, device="cuda"); lrows = torch.empty(B, device="cuda"); crows = torch.empty(B, device="cuda")
+    dlog = torch.empty(B, 10, device="cuda"); da = torch.empty(B, H, device="cuda", dtype=torch.bfloat16)
+    state = torch.zeros(8, dtype=torch.int64, device="cuda")
+    f = lib.dtf_head_fused_fwd_bwd
+    f.argtypes = [P, I, P, F, ctypes.c_uint64, P, P, P, P, P, P, P, P, P, P, P, I, I, F, F, I, P]
+    s = torch.cuda.current_stream().cuda_stream
+    call = lambda: f(part.data_ptr(), S, bias1.data_ptr(), 1.0, 0, state.data_ptr(), h1.data_ptr(), wT.data_ptr(), bias.data_ptr(),
+                     labels.data_ptr(), None, logits.data_ptr(), lrows.data_ptr(), crows.data_ptr(), dlog.data_ptr(),
+                     da.data_ptr(), B, H, 1.0 / B, 1.0, 1, s)
+    lib.dtf_head_set_timing_buf.argtypes = [P]
+    for _ in range(5): assert call() == 0
+    torch.cuda.synchronize()
+    nblk = min(B, 4096)
+    buf = torch.zeros(nblk, 8, dtype=torch.int64, device="cuda")
+    assert lib.dtf_head_set_timing_buf(buf.data_ptr()) == 0
+    call(); torch.cuda.synchronize()
+    t = buf.cpu().double()
+    t0 = t[:, 0].min()
+    ns = (t[:, :5] - t0) * 10.0
+    print(f"head_fwd_bwd (fused fc1 epilogue) B={B}: {nblk} workgroups, first row of each")
+    for i, nm in enumerate(["start", "h1 row + partial logits", "logits reduced", "softmax/loss", "da row stored"]):
+        c = ns[:, i]
+        print(f"  {nm:26s} min {c.min() / 1e3:6.2f}  median {c.median() / 1e3:6.2f}  max {c.max() / 1e3:6.2f} us")
+    d = ns[:, 1:] - ns[:, :-1]
+    for i, nm in enumerate(["partials -> h1 -> dot", "reductions", "softmax", "backward (da)"]):
+        print(f"  phase {nm:24s} median {d[:, i].median() / 1e3:6.2f}  max {d[:, i].max() / 1e3:6.2f} us")
 else:
     import torch
     B = int(sys.argv[2]) if len(sys.argv) > 2 else 1024
