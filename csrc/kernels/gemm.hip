@@ -64,13 +64,31 @@ __device__ __forceinline__ void xcd_tile(int gx, int gy, int& tx, int& ty) {
 // 128x128 tiles run 8 waves (2 per SIMD): while one wave waits on LDS or at the barrier the other
 // issues MFMAs.  A 4-wave tile measured ~1350 cycles per phase for 512 cycles of MFMA.
 // ---------------------------------------------------------------------------------------------
+// Diagnostic (-DDTF_TIMING=1, tools/conv_timeline.py run .. gemm): thread 0 of every workgroup stamps the
+// 100 MHz wall clock: 0 start, 1 first tile in LDS, 2 main loop left, 3 epilogue done
+#ifndef DTF_TIMING
+#define DTF_TIMING 0
+#endif
+#if DTF_TIMING
+__device__ long long* g_gemm_timing = nullptr;
+#define DTF_GSTAMP(slot)                                                                          \
+  do {                                                                                            \
+    if (threadIdx.x == 0 && g_gemm_timing)                                                        \
+      g_gemm_timing[((size_t)(blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x) * 4 + (slot)] = wall_clock64(); \
+  } while (0)
+#else
+#define DTF_GSTAMP(slot) do {} while (0)
+#endif
+
 template <int A_CH, int B_CH, class GL, class SW, class CP>
 __device__ __forceinline__ void gemm_pipeline(int T, GL&& gload, SW&& swrite, CP&& compute) {
   u32x4 ra0[A_CH], rb0[B_CH], ra1[A_CH], rb1[B_CH];
+  DTF_GSTAMP(0);
   gload(ra0, rb0, 0);
   gload(ra1, rb1, 1);
   swrite(ra0, rb0, 0);
   __syncthreads();
+  DTF_GSTAMP(1);
   for (int t = 0; t < T; t += 2) {
     gload(ra0, rb0, t + 2);  // past the end: in-range garbage or zeros, written to LDS but never multiplied
     __builtin_amdgcn_sched_barrier(0);
@@ -184,6 +202,7 @@ __global__ __launch_bounds__(NW * 64, DTF_GEMM_MINW) void gemm_nt_bf16(const bf1
   };
 
   gemm_pipeline<A_CH, B_CH>(K / BK, gload, swrite, compute);
+  DTF_GSTAMP(2);
 
   uint64_t drop_off = 0;
   const bool do_drop = (EPI == EPI_BIAS_RELU_DROPOUT) && drop.keep_prob < 1.0f;
@@ -209,6 +228,7 @@ __global__ __launch_bounds__(NW * 64, DTF_GEMM_MINW) void gemm_nt_bf16(const bf1
         else C[(size_t)mrow * ldc + n] = (bf16)v;
       }
   }
+  DTF_GSTAMP(3);
 }
 
 // C[M,N] (fp32) = sum_k A[k][m] * B[k][n];  A: [K][lda], B: [K][ldb]
@@ -305,6 +325,7 @@ __global__ __launch_bounds__(NW * 64, DTF_GEMM_MINW) void gemm_tn_bf16(const bf1
   };
 
   gemm_pipeline<A_CH, B_CH>((K + BK - 1) / BK, gload, swrite, compute);
+  DTF_GSTAMP(2);
 
   if constexpr (SGD) {
     // Read-modify-write of the master weight straight from the C/D layout would be 4-byte accesses
@@ -364,6 +385,7 @@ __global__ __launch_bounds__(NW * 64, DTF_GEMM_MINW) void gemm_tn_bf16(const bf1
         }
     }
   }
+  DTF_GSTAMP(3);
 }
 
 // C_part[z][M,N] (fp32) = A[M, Kz] . B[Kz, N]  -- "NN": A K-contiguous (activations), B in its
@@ -469,6 +491,7 @@ __global__ __launch_bounds__(NW * 64, DTF_GEMM_MINW) void gemm_nn_splitk_bf16(co
   };
 
   if (T > 0) gemm_pipeline<A_CH, B_CH>(T, gload, swrite, compute);
+  DTF_GSTAMP(2);
 
   float* C = Cp + (size_t)blockIdx.z * M * N;
 #pragma unroll
@@ -483,6 +506,7 @@ __global__ __launch_bounds__(NW * 64, DTF_GEMM_MINW) void gemm_nn_splitk_bf16(co
         if (mrow < M) C[(size_t)mrow * N + n] = acc[i][j][r];
       }
   }
+  DTF_GSTAMP(3);
 }
 
 // out[M,N] bf16 = dropout(relu(sum_z part[z] + bias))  -- the fused epilogue of the split-K forward
@@ -531,6 +555,13 @@ __global__ __launch_bounds__(256) void transpose_bf16(const bf16* __restrict__ i
 }  // namespace dtf
 
 using namespace dtf;
+
+#if DTF_TIMING
+extern "C" int dtf_gemm_set_timing_buf(void* p) {
+  long long* q = (long long*)p;
+  return (int)hipMemcpyToSymbol(HIP_SYMBOL(dtf::g_gemm_timing), &q, sizeof(q));
+}
+#endif
 
 extern "C" {
 

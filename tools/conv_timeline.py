@@ -15,7 +15,47 @@ if sys.argv[1] == "build":
     subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",
                            "-DDTF_TIMING=1", "-I", ROOT + "/csrc/kernels", ROOT + "/csrc/kernels/head.hip",
                            "-o", f"{OUT}/head_timing.so"])
+    subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",
+                           "-DDTF_TIMING=1", "-I", ROOT + "/csrc/kernels", ROOT + "/csrc/kernels/gemm.hip",
+                           ROOT + "/csrc/kernels/head.hip", "-o", f"{OUT}/gemm_timing.so"])
     print("built")
+elif len(sys.argv) > 3 and sys.argv[3] == "gemm":
+    import torch
+    B = int(sys.argv[2]); F_, H = 3136, 1024
+    lib = ctypes.CDLL(f"{OUT}/gemm_timing.so")
+    P, I = ctypes.c_void_p, ctypes.c_int
+    a2 = (torch.randn(B, F_, device="cuda") * 0.3).bfloat16()       # pooled conv2 output (flat)
+    wd1 = (torch.randn(F_, H, device="cuda") * 0.03).bfloat16()
+    da = (torch.randn(B, H, device="cuda") * 0.1).bfloat16()
+    dflat = torch.empty(B, F_, device="cuda", dtype=torch.bfloat16)
+    part = torch.empty(8, B, H, device="cuda")
+    W = torch.randn(F_, H, device="cuda"); shadow = torch.empty(F_, H, device="cuda", dtype=torch.bfloat16)
+    hyper = torch.tensor([1e-3, 0.9, 0.999, 1e-8, 1.0, 0, 0, 0], device="cuda")
+    s = torch.cuda.current_stream().cuda_stream
+    lib.dtf_gemm_nn_partial.argtypes = [P, P, P, I, I, I, I, I, I, P]
+    lib.dtf_gemm_nt.argtypes = [P, P, P, P, I, I, I, I, I, I, I, ctypes.c_float, ctypes.c_uint64, P, I, P]
+    lib.dtf_gemm_tn_sgd.argtypes = [P, P, P, P, P, I, I, I, I, I, I, P]
+    lib.dtf_gemm_set_timing_buf.argtypes = [P]
+    calls = {
+        "nn  (fc1 fwd, split-K)": (lambda: lib.dtf_gemm_nn_partial(a2.data_ptr(), wd1.data_ptr(), part.data_ptr(), B, H, F_, F_, H, 0, s), None),
+        "nt  (fc1 dgrad)": (lambda: lib.dtf_gemm_nt(da.data_ptr(), wd1.data_ptr(), dflat.data_ptr(), None, B, F_, H, H, H, F_, 0, 1.0, 0, None, 0, s), None),
+        "tn  (fc1 wgrad + SGD)": (lambda: lib.dtf_gemm_tn_sgd(a2.data_ptr(), da.data_ptr(), W.data_ptr(), shadow.data_ptr(), hyper.data_ptr(), F_, H, B, F_, H, H, s), None),
+    }
+    for name, (call, _) in calls.items():
+        lib.dtf_gemm_set_timing_buf(None)
+        for _ in range(5): rc = call()
+        torch.cuda.synchronize()
+        buf = torch.zeros(4096, 4, dtype=torch.int64, device="cuda")
+        assert lib.dtf_gemm_set_timing_buf(buf.data_ptr()) == 0
+        call(); torch.cuda.synchronize()
+        t = buf.cpu().double()
+        t = t[t[:, 0] > 0]
+        t0 = t[:, 0].min()
+        ns = (t - t0) * 10.0
+        d = ns[:, 1:] - ns[:, :-1]
+        print(f"{name}: {t.shape[0]} workgroups; start median {ns[:, 0].median() / 1e3:5.2f} max {ns[:, 0].max() / 1e3:5.2f} | "
+              f"prologue {d[:, 0].median() / 1e3:5.2f} | main loop {d[:, 1].median() / 1e3:5.2f} (max {d[:, 1].max() / 1e3:5.2f}) | "
+              f"epilogue {d[:, 2].median() / 1e3:5.2f} (max {d[:, 2].max() / 1e3:5.2f}) | end median {ns[:, 3].median() / 1e3:5.2f} max {ns[:, 3].max() / 1e3:5.2f} us")
 elif len(sys.argv) > 3 and sys.argv[3] == "head":
     import torch
     B = int(sys.argv[2]); H, S = 1024, 3
