@@ -120,18 +120,24 @@ __global__ __launch_bounds__(NW * 64, DTF_GEMM_MINW) void gemm_nt_bf16(const bf1
   constexpr int WM = BM / 2, WN = BN / WAVES_N;
   constexpr int MT = WM / 16, NTL = WN / 16;
   constexpr int A_CH = BM * 8 / NT, B_CH = BN * 8 / NT;  // 16-byte chunks per thread
-  __shared__ __attribute__((aligned(16))) bf16 sA[2][BM * BK];
-  __shared__ __attribute__((aligned(16))) bf16 sB[2][BN * BK];
+  __shared__ __attribute__((aligned(16))) struct {   // one object: the head wgrad workgroups use it as one scratch area
+    bf16 a[2][BM * BK];
+    bf16 b[2][BN * BK];
+  } sm;
+  auto& sA = sm.a;
+  auto& sB = sm.b;
 
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wave / WAVES_N, wn = wave % WAVES_N;
   int tile_x, tile_y;
   if constexpr (HEADW) {
-    static_assert(sizeof(sA) >= sizeof(float) * head_wgrad_lds_floats<NW>(), "head wgrad scratch must fit in sA");
+    static_assert(sizeof(sm) >= sizeof(float) * head_wgrad_lds_floats<NW>(), "head wgrad scratch must fit in the tile buffers");
     const int gx = (N + BN - 1) / BN, gy = (M + BM - 1) / BM;
     const int extra = (int)blockIdx.x - gx * gy;
     if (extra >= 0) {
+      DTF_GSTAMP(0);
       head_wgrad_block<NW>(hw, extra % hw.nbx, extra / hw.nbx, reinterpret_cast<float*>(&sA[0][0]));
+      DTF_GSTAMP(3);
       return;
     }
     xcd_tile_linear((int)blockIdx.x, gx, gy, tile_x, tile_y);
@@ -606,8 +612,9 @@ int dtf_gemm_nt_head_wgrad(const void* A, const void* Bw, void* C, int M, int N,
     if (rc) return rc;
     return dtf_gemm_nt(A, Bw, C, nullptr, M, N, K, lda, ldb, ldc, 0, 1.0f, 0, nullptr, 0, s);
   }
+  if (H % 4) return -3;
   HeadWgradArgs hw{(const bf16*)h1, (const float*)dlogits, (const bf16*)da, (float*)part, Bsz, H, (Bsz + KS - 1) / KS,
-                   (H + 63) / 64};
+                   (H + kHeadCols - 1) / kHeadCols};
   DropoutArgs d{1.0f, 0, nullptr};
   hipLaunchKernelGGL((gemm_nt_bf16<128, 128, 8, EPI_STORE, true>), dim3((unsigned)(tiles + (long)hw.nbx * KS)), dim3(512),
                      0, s, (const bf16*)A, (const bf16*)Bw, (bf16*)C, (const float*)nullptr, M, N, K, lda, ldb, ldc, d,

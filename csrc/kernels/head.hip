@@ -178,10 +178,10 @@ __global__ __launch_bounds__(256) void transpose_head_w(const float* __restrict_
   if (i < H * kCls) out[i] = in[(size_t)(i % H) * kCls + i / H];
 }
 
-// grid = (H/64, KS).  slab layout per k-split: [H*10 dW_out][12: db_out padded][H db_d1]
+// grid = (H/256, KS).  slab layout per k-split: [H*10 dW_out][12: db_out padded][H db_d1]
 // (body in head_wgrad_core.hpp: the training step runs it inside the fc1 dgrad GEMM launch instead)
 __global__ __launch_bounds__(256) void head_wgrad(HeadWgradArgs a) {
-  __shared__ float red[head_wgrad_lds_floats<4>()];
+  __shared__ __attribute__((aligned(16))) float red[head_wgrad_lds_floats<4>()];
   head_wgrad_block<4>(a, blockIdx.x, blockIdx.y, red);
 }
 
@@ -241,8 +241,10 @@ int dtf_head_wgrad(const void* h1, const void* dlogits, const void* da, void* pa
                    hipStream_t s) {
   if (KS <= 0) return -2;
   int rps = (B + KS - 1) / KS;
-  HeadWgradArgs a{(const bf16*)h1, (const float*)dlogits, (const bf16*)da, (float*)part, B, H, rps, (H + 63) / 64};
-  hipLaunchKernelGGL(head_wgrad, dim3((H + 63) / 64, KS), dim3(256), 0, s, a);
+  if (H % 4) return -3;
+  HeadWgradArgs a{(const bf16*)h1, (const float*)dlogits, (const bf16*)da, (float*)part, B, H, rps,
+                  (H + kHeadCols - 1) / kHeadCols};
+  hipLaunchKernelGGL(head_wgrad, dim3(a.nbx, KS), dim3(256), 0, s, a);
   return (int)hipGetLastError();
 }
 

@@ -3,8 +3,10 @@
 // has 200 workgroups on 256 CUs, and this reduction is ~2 us of work that otherwise costs a whole
 // launch of its own).
 //   dW_out = h1^T . dlogits, db_out = sum_b dlogits, db_d1 = sum_b da   (reference .idea/MNISTDist.py:89,149)
-// Work split: block (bx, by) owns 64 hidden columns and one batch split; its NSUB waves take rows
-// b0 + sub, b0 + sub + NSUB, ...  Slab layout per split: [H*10 dW_out][12: db_out padded][H db_d1].
+// Work split: block (bx, by) owns 256 hidden columns (4 per lane: 8-byte loads) and one batch split; its NSUB
+// waves take rows b0 + sub, b0 + sub + NSUB, ... and are summed by a tree through LDS.  Slab layout per split:
+// [H*10 dW_out][12: db_out padded][H db_d1].  (64 columns per block meant 512 latency-bound workgroups of 2.4 us
+// for the 1024-image step -- more CU time than the fc1 dgrad launch leaves idle; tools/conv_timeline.py run .. gemm.)
 #pragma once
 #include "common.hpp"
 
@@ -16,75 +18,107 @@ struct HeadWgradArgs {
   const bf16* da;
   float* part;
   int B, H, rows_per_split;
-  int nbx;  // blocks along the hidden dimension = ceil(H / 64)
+  int nbx;  // blocks along the hidden dimension = ceil(H / 256)
 };
 
 constexpr int kHeadCls = 10;
+constexpr int kHeadCols = 256;   // hidden columns per workgroup
 template <int NSUB>
-constexpr int head_wgrad_lds_floats() { return NSUB * 64 * (kHeadCls + 1); }
+constexpr int head_wgrad_lds_floats() { return (NSUB / 2) * ((kHeadCls + 1) * kHeadCols + 16); }
 
-// red: NSUB * 64 * 11 floats of LDS
+// red: head_wgrad_lds_floats<NSUB>() floats of LDS.  H must be a multiple of 4.
 template <int NSUB>
-__device__ __forceinline__ void head_wgrad_block(const HeadWgradArgs& a, int bx, int by, float* red_raw) {
+__device__ __forceinline__ void head_wgrad_block(const HeadWgradArgs& a, int bx, int by, float* red) {
+  static_assert(NSUB == 4 || NSUB == 8, "tree reduction over 4 or 8 waves");
   constexpr int kCls = kHeadCls;
-  float (*red)[64][kCls + 1] = reinterpret_cast<float (*)[64][kCls + 1]>(red_raw);
+  constexpr int kWaveFloats = (kCls + 1) * kHeadCols + 16;   // per-wave slot in red: [11][256] + 16 for db_out
   const bf16* __restrict__ h1 = a.h1;
   const bf16* __restrict__ da = a.da;
   const float* __restrict__ dlogits = a.dlogits;
   const int B = a.B, H = a.H;
-  const int jc = threadIdx.x & 63, sub = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // wave-uniform row phase
-  const int j = bx * 64 + jc;
+  const int lane = threadIdx.x & 63, sub = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // wave-uniform row phase
+  const int j = bx * kHeadCols + 4 * lane;
+  const bool live = j < H;
+  const int jl = live ? j : 0;   // dead lanes load column 0 (unconditional loads) and never store
   const int b0 = by * a.rows_per_split;
   const int b1 = min(B, b0 + a.rows_per_split);
-  float acc[kCls + 1];
+  f32x4 acc[kCls + 1];
+  float dbo[kCls];   // wave-uniform: column sums of this wave's dlogits rows
 #pragma unroll
-  for (int c = 0; c <= kCls; ++c) acc[c] = 0.f;
-  if (j < H) {
-    // four rows per trip: their activation loads are issued together (a one-row loop was a chain of
-    // dependent-latency trips), and the dlogits row address is wave-uniform -> scalar loads
-    int b = b0 + sub;
-    for (; b + 3 * NSUB < b1; b += 4 * NSUB) {
-      float hf[4], dv[4];
+  for (int c = 0; c <= kCls; ++c) acc[c] = (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-      for (int u = 0; u < 4; ++u) {
-        hf[u] = (float)h1[(size_t)(b + NSUB * u) * H + j];
-        dv[u] = (float)da[(size_t)(b + NSUB * u) * H + j];
-      }
+  for (int c = 0; c < kCls; ++c) dbo[c] = 0.f;
+  auto row = [&](const bf16x4& hv, const bf16x4& dv, int b) {
+    const float* dl = dlogits + (size_t)b * kCls;   // wave-uniform address -> scalar loads
+    const f32x4 hf = {(float)hv[0], (float)hv[1], (float)hv[2], (float)hv[3]};
 #pragma unroll
-      for (int u = 0; u < 4; ++u) {
-        const float* dl = dlogits + (size_t)(b + NSUB * u) * kCls;
+    for (int c = 0; c < kCls; ++c) {
+      const float d = dl[c];
+      dbo[c] += d;
 #pragma unroll
-        for (int c = 0; c < kCls; ++c) acc[c] = fmaf(hf[u], dl[c], acc[c]);
-        acc[kCls] += dv[u];
-      }
+      for (int e = 0; e < 4; ++e) acc[c][e] = fmaf(hf[e], d, acc[c][e]);
     }
-    for (; b < b1; b += NSUB) {
-      const float hf = (float)h1[(size_t)b * H + j];
-      const float* dl = dlogits + (size_t)b * kCls;
 #pragma unroll
-      for (int c = 0; c < kCls; ++c) acc[c] = fmaf(hf, dl[c], acc[c]);
-      acc[kCls] += (float)da[(size_t)b * H + j];
+    for (int e = 0; e < 4; ++e) acc[kCls][e] += (float)dv[e];
+  };
+  // four rows per trip: their activation loads are issued together (a one-row loop was a chain of
+  // dependent-latency trips)
+  int b = b0 + sub;
+  for (; b + 3 * NSUB < b1; b += 4 * NSUB) {
+    bf16x4 hv[4], dv[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      hv[u] = *reinterpret_cast<const bf16x4*>(h1 + (size_t)(b + NSUB * u) * H + jl);
+      dv[u] = *reinterpret_cast<const bf16x4*>(da + (size_t)(b + NSUB * u) * H + jl);
     }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) row(hv[u], dv[u], b + NSUB * u);
   }
+  for (; b < b1; b += NSUB) {
+    const bf16x4 hv = *reinterpret_cast<const bf16x4*>(h1 + (size_t)b * H + jl);
+    const bf16x4 dv = *reinterpret_cast<const bf16x4*>(da + (size_t)b * H + jl);
+    row(hv, dv, b);
+  }
+  // tree over the waves: the upper half of the live waves writes, the lower half adds (fixed order)
 #pragma unroll
-  for (int c = 0; c <= kCls; ++c) red[sub][jc][c] = acc[c];
-  __syncthreads();
+  for (int half = NSUB / 2; half >= 1; half >>= 1) {
+    if (sub >= half && sub < 2 * half) {
+      float* w = red + (size_t)(sub - half) * kWaveFloats;
+#pragma unroll
+      for (int c = 0; c <= kCls; ++c) *reinterpret_cast<f32x4*>(w + c * kHeadCols + 4 * lane) = acc[c];
+      if (lane == 0) {
+#pragma unroll
+        for (int c = 0; c < kCls; ++c) w[(kCls + 1) * kHeadCols + c] = dbo[c];
+      }
+    }
+    __syncthreads();
+    if (sub < half) {
+      const float* w = red + (size_t)sub * kWaveFloats;
+#pragma unroll
+      for (int c = 0; c <= kCls; ++c) acc[c] += *reinterpret_cast<const f32x4*>(w + c * kHeadCols + 4 * lane);
+#pragma unroll
+      for (int c = 0; c < kCls; ++c) dbo[c] += w[(kCls + 1) * kHeadCols + c];
+    }
+    __syncthreads();
+  }
   float* slab = a.part + (size_t)by * ((size_t)H * kCls + 12 + H);
-  if (sub == 0 && j < H) {
+  if (sub == 0 && live) {
+    // dW_out rows j..j+3 are 40 consecutive floats: element 10*e + c
+    float* dst = slab + (size_t)j * kCls;
 #pragma unroll
-    for (int c = 0; c <= kCls; ++c) {
-      float s = 0.f;
+    for (int k = 0; k < kCls; ++k) {
+      f32x4 o;
 #pragma unroll
-      for (int u = 0; u < NSUB; ++u) s += red[u][jc][c];
-      if (c < kCls) slab[(size_t)j * kCls + c] = s;
-      else slab[(size_t)H * kCls + 12 + j] = s;
+      for (int m = 0; m < 4; ++m) o[m] = acc[(4 * k + m) % kCls][(4 * k + m) / kCls];
+      *reinterpret_cast<f32x4*>(dst + 4 * k) = o;
     }
+    *reinterpret_cast<f32x4*>(slab + (size_t)H * kCls + 12 + j) = acc[kCls];
   }
-  if (bx == 0 && threadIdx.x < 12) {
+  if (bx == 0 && sub == 0 && lane < 12) {
     float s = 0.f;
-    if (threadIdx.x < kCls)
-      for (int b = b0; b < b1; ++b) s += dlogits[(size_t)b * kCls + threadIdx.x];
-    slab[(size_t)H * kCls + threadIdx.x] = s;
+#pragma unroll
+    for (int c = 0; c < kCls; ++c) s = (lane == c) ? dbo[c] : s;
+    slab[(size_t)H * kCls + lane] = s;
   }
 }
 

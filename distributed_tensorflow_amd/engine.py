@@ -137,9 +137,10 @@ class HipEngine:
         self.dp1 = torch.empty((B, 14, 14, C1), **bf)
 
         # split-K geometry
-        # 32 rows per split: every wave of the reduction then makes at most two four-row trips (at 4096 images
-        # 32 splits meant 8 dependent trips per wave: 15 us instead of 6)
-        self.head_ks = max(1, min(int(os.environ.get("DTF_HEAD_KS", "128")), max(B // 32, min(32, B // 8))))
+        # output-layer wgrad: 256-column workgroups x head_ks batch splits (slabs summed by the fused tail)
+        self.head_ks = max(1, min(128, max(B // 64, min(8, B // 8))))   # 64 rows per split (measured: 8..16 splits best at 1024)
+        if os.environ.get("DTF_HEAD_KS"):                       # tuning override
+            self.head_ks = max(1, min(int(os.environ["DTF_HEAD_KS"]), B))
         self.head_stride = H * spec.classes + 12 + H
         self.head_part = torch.empty((self.head_ks, self.head_stride), **f32)
         # conv2 wgrad split-K over images: G slabs x (C1/16 * C2/32) output tiles workgroups.  64 slabs fill the

@@ -41,6 +41,26 @@ elif len(sys.argv) > 3 and sys.argv[3] == "gemm":
         "nt  (fc1 dgrad)": (lambda: lib.dtf_gemm_nt(da.data_ptr(), wd1.data_ptr(), dflat.data_ptr(), None, B, F_, H, H, H, F_, 0, 1.0, 0, None, 0, s), None),
         "tn  (fc1 wgrad + SGD)": (lambda: lib.dtf_gemm_tn_sgd(a2.data_ptr(), da.data_ptr(), W.data_ptr(), shadow.data_ptr(), hyper.data_ptr(), F_, H, B, F_, H, H, s), None),
     }
+    # the training step's launch: fc1 dgrad tiles followed by the head wgrad workgroups
+    KS = 32
+    h1 = (torch.rand(B, H, device="cuda")).bfloat16(); dlog = torch.randn(B, 10, device="cuda") / B
+    hpart = torch.empty(KS, H * 10 + 12 + H, device="cuda")
+    lib.dtf_gemm_nt_head_wgrad.argtypes = [P, P, P, I, I, I, I, I, I, P, P, P, P, I, I, I, P]
+    lib.dtf_gemm_set_timing_buf(None)
+    fused = lambda: lib.dtf_gemm_nt_head_wgrad(da.data_ptr(), wd1.data_ptr(), dflat.data_ptr(), B, F_, H, H, H, F_, h1.data_ptr(),
+                                               dlog.data_ptr(), da.data_ptr(), hpart.data_ptr(), B, H, KS, s)
+    for _ in range(5): fused()
+    torch.cuda.synchronize()
+    buf = torch.zeros(4096, 4, dtype=torch.int64, device="cuda")
+    lib.dtf_gemm_set_timing_buf(buf.data_ptr())
+    fused(); torch.cuda.synchronize()
+    t = buf.cpu().double()
+    ntiles = ((B + 127) // 128) * ((F_ + 127) // 128)
+    tt, th = t[:ntiles], t[ntiles:ntiles + 16 * KS]
+    t0 = min(tt[:, 0].min(), th[:, 0].min())
+    print(f"nt + head wgrad in one launch: {ntiles} tiles end median {(tt[:, 3].median() - t0) / 100:5.2f} max {(tt[:, 3].max() - t0) / 100:5.2f} us | "
+          f"{th.shape[0]} head workgroups: start median {(th[:, 0].median() - t0) / 100:5.2f} max {(th[:, 0].max() - t0) / 100:5.2f}, "
+          f"duration median {((th[:, 3] - th[:, 0]).median()) / 100:5.2f} max {((th[:, 3] - th[:, 0]).max()) / 100:5.2f}, end max {(th[:, 3].max() - t0) / 100:5.2f} us")
     for name, (call, _) in calls.items():
         lib.dtf_gemm_set_timing_buf(None)
         for _ in range(5): rc = call()
