@@ -7,11 +7,11 @@ out=gpurun_out/${tag}.log
 mkdir -p gpurun_out
 : > $out
 run() { echo "## $*" >> $out; timeout -k 10 150 "$@" >> $out 2>/dev/null || exit 1; }
-for b in 100 128 256 512 1024 2048 4096 8192; do run python bench.py --per_gpu_batch $b --steps 200 --warmup 20; done
-run python bench.py --graph --steps 200 --warmup 20
-run python bench.py --multi_stream --steps 200 --warmup 20
-run python bench.py --optimizer adam --steps 200 --warmup 20
-run python bench.py --keep_prob 0.5 --steps 200 --warmup 20
+for b in 100 128 256 512 1024 2048 4096 8192; do run python bench.py --per_gpu_batch $b --steps 1000 --warmup 100; done
+run python bench.py --graph --steps 1000 --warmup 100
+run python bench.py --multi_stream --steps 1000 --warmup 100
+run python bench.py --optimizer adam --steps 1000 --warmup 100
+run python bench.py --keep_prob 0.5 --steps 1000 --warmup 100
 run python bench.py --model wide --per_gpu_batch 256 --steps 50 --warmup 10
 run python bench.py --model wide --per_gpu_batch 1024 --steps 30 --warmup 5
 run python bench/torch_reference.py --batch 1024 --bf16 --channels_last
