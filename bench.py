@@ -39,6 +39,9 @@ def main():
     ap.add_argument("--multi_stream", action="store_true", help="force the fork/join side streams (default: by batch size)")
     ap.add_argument("--no_graph", action="store_true", help="eager launches instead of HIP-graph replay (1 GPU)")
     ap.add_argument("--graph", action="store_true", help="force HIP-graph replay (default: only above 1024 images/GPU)")
+    ap.add_argument("--force_dp", action="store_true",
+                    help="diagnostic: run the data-parallel schedule (process group, two communicators, comm_diag) "
+                         "even at --gpus 1, to exercise the N>1 code path on a one-GPU box")
     args = ap.parse_args()
 
     from distributed_tensorflow_amd.engine import DeviceDataset, HipEngine
@@ -52,7 +55,8 @@ def main():
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run for N>1")
     torch.cuda.set_device(local_rank)
-    if world > 1:
+    dp_path = world > 1 or args.force_dp
+    if dp_path:
         comm.init_process_group(backend="nccl", rank=rank, world_size=world, device=torch.device("cuda", local_rank))
 
     spec = ModelSpec.from_name(args.model)
@@ -61,12 +65,12 @@ def main():
     eng = HipEngine(spec, B, ds, optimizer=args.optimizer, learning_rate=1e-3, keep_prob=args.keep_prob,
                     seed=1000 + rank,
                     # None = engine default (by batch size); the data-parallel path measured faster without the fork/join
-                    multi_stream=False if (args.single_stream or world > 1) else (True if args.multi_stream else None),
-                    fuse_dense_update=(world == 1))
+                    multi_stream=False if (args.single_stream or dp_path) else (True if args.multi_stream else None),
+                    fuse_dense_update=not dp_path)
     eng.init_params(seed=7)
 
     use_graph = False
-    if world > 1:
+    if dp_path:
         try:   # second communicator: the small tail all-reduce must not queue behind the 12.8 MB one inside RCCL
             tail_group = torch.distributed.new_group()
         except Exception as e:   # still correct without it, only slower: the tail then rides the comm stream
@@ -85,7 +89,7 @@ def main():
         step = eng.train_step
 
     def barrier():
-        if world > 1:
+        if dp_path:
             torch.distributed.barrier()
         torch.cuda.synchronize()
 
@@ -98,11 +102,26 @@ def main():
     barrier()
     dt = time.perf_counter() - t0
 
-    if world > 1:
+    if dp_path:
         t = torch.tensor([dt], dtype=torch.float64, device="cuda")
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
         dt = float(t.item())
     loss, acc = eng.last_metrics()
+    comm_diag = None
+    if dp_path:
+        # Outside the timed region: stand-alone latency of the step's two all-reduces (the dense fc1 gradient
+        # and the small tail), i.e. the two communication terms of the scaling model in docs/ARCHITECTURE.md.
+        try:
+            dev = torch.device("cuda", local_rank)
+            n_dense = spec.flat * spec.hidden
+            n_tail = spec.num_params() - n_dense
+            comm_diag = {
+                "dense_allreduce_bytes": 4 * n_dense, "tail_allreduce_bytes": 4 * n_tail,
+                "dense_allreduce_us": round(comm.allreduce_latency_us(n_dense, device=dev), 1),
+                "tail_allreduce_us": round(comm.allreduce_latency_us(n_tail, group=tail_group, device=dev, iters=50), 1),
+            }
+        except Exception as e:   # a diagnostic must never cost the headline line
+            comm_diag = {"error": repr(e)}
     if rank == 0:
         global_batch = B * world
         value = global_batch * args.steps / dt
@@ -121,12 +140,13 @@ def main():
             "dtype": "bf16",
             "data": "synthetic (HBM-resident 28x28x1, random TF-style init)",
             "config": {"model": spec.name, "global_batch": global_batch, "per_gpu_batch": B, "seq_len": None,
-                       "parallelism": f"dp{world}", "optimizer": args.optimizer, "keep_prob": args.keep_prob,
-                       "graph": bool(world == 1 and use_graph)},
+                       "parallelism": f"dp{world}" + ("(forced dp schedule)" if args.force_dp and world == 1 else ""), "optimizer": args.optimizer, "keep_prob": args.keep_prob,
+                       "graph": bool(use_graph)},
             "model_tflops": round(value * fb / 1e12, 2),
             "final_loss": round(loss, 4),
+            **({"comm_diag": comm_diag} if comm_diag is not None else {}),
         }))
-    if world > 1:
+    if dp_path:
         torch.distributed.destroy_process_group()
 
 

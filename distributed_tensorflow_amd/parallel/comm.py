@@ -45,3 +45,35 @@ def rank() -> int:
 def shutdown():
     if dist.is_initialized():
         dist.destroy_process_group()
+
+
+def allreduce_latency_us(numel: int, group=None, device: Optional[torch.device] = None, iters: int = 20,
+                         warmup: int = 5, dtype: torch.dtype = torch.float32) -> float:
+    """Mean wall time (us) of one stand-alone SUM all-reduce of ``numel`` elements, max over ranks.
+
+    Every rank of ``group`` must call it with the same arguments.  bench.py reports it (outside the
+    timed region) for the two messages of a data-parallel step, so a scaling run also records the two
+    terms of the step model in docs/ARCHITECTURE.md: the exposed tail latency and the dense transfer
+    time that has to hide under backward.
+    """
+    import time
+
+    device = device or torch.device("cpu")
+    buf = torch.zeros(int(numel), dtype=dtype, device=device)
+
+    def sync():
+        if device.type == "cuda":
+            torch.cuda.synchronize(device)
+
+    for _ in range(warmup):
+        dist.all_reduce(buf, group=group)
+    sync()
+    dist.barrier(group=group)
+    sync()
+    t0 = time.perf_counter()
+    for _ in range(iters):
+        dist.all_reduce(buf, group=group)
+    sync()
+    us = torch.tensor([(time.perf_counter() - t0) * 1e6 / iters], dtype=torch.float64, device=device)
+    dist.all_reduce(us, op=dist.ReduceOp.MAX, group=group)
+    return float(us.item())
