@@ -33,6 +33,7 @@ import torch.distributed as dist
 
 from ..engine import HipEngine
 from ..ops.native import check
+from ..utils import trace
 
 
 def make_buckets(lo: int, hi: int, bucket_elems: int) -> List[Tuple[int, int]]:
@@ -108,21 +109,28 @@ class SyncDataParallel:
         the 180 us of GPU work it was feeding)."""
         eng = self.eng
         lib, d = eng.lib, eng._d()
+        tr = trace if trace.enabled() else None     # roctx ranges (utils/trace.py), off by default
         cur = torch.cuda.current_stream(eng.device).cuda_stream
         comm = self.comm_stream.cuda_stream
         tail = cur if self.tail_stream is None else self.tail_stream.cuda_stream
+        if tr: tr.push("dp_phase1: fwd + fc1 wgrad")
         check(lib.dtf_engine_dp_phase1(d, int(self._have_pending_dense), cur, comm), "dp_phase1")
+        if tr: tr.pop(); tr.push("allreduce dense (enqueue)")
         with torch.cuda.stream(self.comm_stream):
             for lo, hi in self.dense_buckets:
                 self._allreduce(lo, hi, self.group)
+        if tr: tr.pop(); tr.push("dp_phase2: conv backward")
         check(lib.dtf_engine_dp_phase2(d, self.n_dense, self.DENSE_SLOT, cur, comm, tail), "dp_phase2")
+        if tr: tr.pop(); tr.push("allreduce tail (enqueue)")
         if self.tail_stream is None:
             self._allreduce(*self.tail_bucket, self.tail_group)
         else:
             with torch.cuda.stream(self.tail_stream):
                 self._allreduce(*self.tail_bucket, self.tail_group)
+        if tr: tr.pop(); tr.push("dp_phase3: update")
         check(lib.dtf_engine_dp_phase3(d, self.n_dense, self.TAIL_SLOT, eng.step_inc, int(not self.defer), cur, tail),
               "dp_phase3")
+        if tr: tr.pop()
         self._have_pending_dense = self.defer
 
     def flush(self):

@@ -31,6 +31,7 @@ from .parallel import comm
 from .parallel.strategies import (AsyncP2PServer, AsyncP2PWorker, AsyncRounds, LocalStrategy, SyncAllReduce)
 from .checkpoint import Saver
 from .supervisor import Supervisor
+from .utils import trace
 from .utils.metrics import MetricsLogger, StepTimer, format_display_line
 
 
@@ -142,6 +143,7 @@ def run(F, log=print) -> dict:
     sv = Supervisor(backend, is_chief=task.is_chief, logdir=F.logdir or None, save_model_secs=F.save_model_secs,
                     saver=Saver(write_version=getattr(F, "saver_write_version", 2)), init_seed=F.seed, log=log)
     timer = StepTimer()
+    tracing = trace.set_enabled(True) if getattr(F, "trace", False) else trace.enabled()
     images_per_step = F.batch_size * (task.num_workers if mode == "sync" else 1)
     t_start = time.perf_counter()
     with sv.managed_session(strategy):
@@ -150,7 +152,9 @@ def run(F, log=print) -> dict:
         local_steps = 0
         while not sv.should_stop() and step < F.training_iter:
             prev = step
+            if tracing: trace.push(f"step {prev}")
             step = strategy.step()
+            if tracing: trace.pop()
             local_steps += 1
             timer.add(images_per_step)
             if F.fault_inject_step >= 0 and local_steps == F.fault_inject_step and \
@@ -164,7 +168,9 @@ def run(F, log=print) -> dict:
                 log(format_display_line(task.job_name, task.task_index, prev, loss, acc))
                 lap = timer.lap()
                 metrics.log(step=prev, loss=loss, accuracy=acc, role=result["role"], **lap)
+            if tracing: trace.push("supervisor.maybe_save")
             sv.maybe_save()
+            if tracing: trace.pop()
         strategy.finish()
         backend.synchronize()
         result["global_step"] = step
@@ -173,7 +179,8 @@ def run(F, log=print) -> dict:
         loss, acc = backend.last_metrics() if local_steps else (float("nan"), float("nan"))
         result["final_loss"], result["final_train_accuracy"] = loss, acc
         if F.eval and task.is_chief:
-            tl, ta = backend.evaluate("test")
+            with trace.range("evaluate test"):
+                tl, ta = backend.evaluate("test")
             result["test_loss"], result["test_accuracy"] = tl, ta
             log(f"test accuracy: {ta:.4f}  test loss: {tl:.4f}  (global_step {step})")
             metrics.log(step=step, test_loss=tl, test_accuracy=ta, role=result["role"])
