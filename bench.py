@@ -120,6 +120,31 @@ def main():
                 "dense_allreduce_us": round(comm.allreduce_latency_us(n_dense, device=dev), 1),
                 "tail_allreduce_us": round(comm.allreduce_latency_us(n_tail, group=tail_group, device=dev, iters=50), 1),
             }
+            # ... and the data-parallel step with one or both collectives left out (ranks then drift apart, which
+            # no longer matters here): which of the two is exposed, and what the schedule costs without either
+            real, tail_bucket = dp._allreduce, tuple(dp.tail_bucket)
+
+            def timed(skip_dense, skip_tail, n=200):
+                def ar(lo, hi, group):
+                    is_tail = (lo, hi) == tail_bucket
+                    if not (skip_tail if is_tail else skip_dense):
+                        real(lo, hi, group)
+                dp._allreduce = ar
+                for _ in range(20):
+                    step()
+                barrier()
+                t1 = time.perf_counter()
+                for _ in range(n):
+                    step()
+                barrier()
+                ms = torch.tensor([(time.perf_counter() - t1) * 1e3 / n], dtype=torch.float64, device=dev)
+                torch.distributed.all_reduce(ms, op=torch.distributed.ReduceOp.MAX)
+                dp._allreduce = real
+                return round(float(ms.item()), 4)
+
+            comm_diag["step_ms_no_allreduce"] = timed(True, True)
+            comm_diag["step_ms_dense_allreduce_only"] = timed(False, True)
+            comm_diag["step_ms_tail_allreduce_only"] = timed(True, False)
         except Exception as e:   # a diagnostic must never cost the headline line
             comm_diag = {"error": repr(e)}
     if rank == 0:

@@ -149,10 +149,13 @@ static int fc1_dgrad(const DtfEngineDesc* e, int head_w, hipStream_t s) {
                      e->hidden, e->flat, 0, 1.0f, 0, nullptr, 0, s);
 }
 
+#ifndef DTF_EXP_DP
+#define DTF_EXP_DP 0   // timing experiments only (break the step!): 1 = no ev_dgrad record/wait, 2 = no dense update, 4 = dense update on s
+#endif
 static int backward_conv_impl(const DtfEngineDesc* e, const void* images, const void* idx, int record_dgrad,
                               int reduce, int head_w, hipStream_t s) {
   DTF_TRY(fc1_dgrad(e, head_w, s));
-  if (record_dgrad) HIP_TRY(hipEventRecord(e->ev_dgrad, s));
+  if (record_dgrad && !(DTF_EXP_DP & 1)) HIP_TRY(hipEventRecord(e->ev_dgrad, s));
   hipStream_t s2 = s;
   if (e->multi_stream) {
     HIP_TRY(hipEventRecord(e->ev_fork, s));
@@ -304,8 +307,8 @@ int dtf_engine_dp_phase2(const DtfEngineDesc* e, long dense_hi, int dense_adam_s
                          hipStream_t tail) {
   DTF_TRY(backward_conv_impl(e, e->ds_images, e->idx, 1, 2, 1, s));
   // the dense update overwrites the bf16 wd1 that fc1 dgrad reads: order it after that kernel
-  HIP_TRY(hipStreamWaitEvent(comm, e->ev_dgrad, 0));
-  DTF_TRY(dtf_engine_update_range(e, 0, dense_hi, 0, 0, 0, dense_adam_slot, comm));
+  if (!(DTF_EXP_DP & 1)) HIP_TRY(hipStreamWaitEvent(comm, e->ev_dgrad, 0));
+  if (!(DTF_EXP_DP & 2)) DTF_TRY(dtf_engine_update_range(e, 0, dense_hi, 0, 0, 0, dense_adam_slot, (DTF_EXP_DP & 4) ? s : comm));
   HIP_TRY(hipEventRecord(e->ev_dense_updated, comm));
   // tail == s: the tail collective is issued on the compute stream itself (everything after it depends on
   // it anyway), which needs no events at all; a separate tail stream is ordered behind the conv backward
