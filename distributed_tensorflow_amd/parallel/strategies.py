@@ -54,6 +54,15 @@ def ps_shards(task: TaskInfo, backend: Backend) -> Tuple[Dict[int, List[Tuple[in
     return shards, placement["global_step"]
 
 
+def _fence(t: torch.Tensor):
+    """gloo carrying a GPU tensor (several tasks on one GPU, --comm_backend=gloo): drain the device first.
+    ProcessGroupGloo stages device tensors through pinned host memory on streams of its own; on MI355X,
+    letting it wait by itself for kernels still running on the caller's stream stretched a 13 MB all-reduce
+    from 3 ms to ~15 s (tests/test_distributed_gpu.py).  RCCL and CPU tensors need nothing."""
+    if t.is_cuda and dist.get_backend() == "gloo":
+        torch.cuda.synchronize(t.device)
+
+
 def _gather(flat: torch.Tensor, ranges, out: torch.Tensor):
     o = 0
     for lo, hi in ranges:
@@ -122,6 +131,7 @@ class SyncAllReduce:
             self._dp.train_step()
         else:
             self.b.compute_gradients()
+            _fence(self.b.grads)
             dist.all_reduce(self.b.grads, op=dist.ReduceOp.SUM, group=self.group)
             self.b.apply_gradients(scale=1.0 / self.world)
         self.step_count += 1
@@ -135,6 +145,7 @@ class SyncAllReduce:
 def broadcast_state(backend: Backend, src_rank: int, group=None):
     """Chief -> everyone: parameters + global_step (reference: chief runs init_op / restore while
     the other tasks wait for the variables to be initialised)."""
+    _fence(backend.params)
     dist.broadcast(backend.params, src=src_rank, group=group)
     dev = backend.params.device
     st = torch.tensor([backend.get_global_step()], dtype=torch.int64, device=dev)
@@ -169,6 +180,7 @@ class AsyncP2PWorker:
             if kind == KIND_GRAD:
                 _gather(b.grads, ranges, m)
             m[n] = kind
+            _fence(m)
             dist.send(m, dst=p)
         if kind == KIND_BYE:
             return
@@ -236,6 +248,7 @@ class AsyncP2PServer:
                         _gather(b.params, self.ranges, resp)
                         _set_int(resp, n, self._step)
                         _set_int(resp, n + 1, 1 if self._step >= self.training_iter else 0)
+                        _fence(resp)
                     dist.send(resp, dst=w)
                 except (RuntimeError, ValueError) as e:     # worker died: keep serving the others
                     self.log(f"ps/{self.task.task_index}: worker rank {w} lost ({type(e).__name__}); continuing")
@@ -282,6 +295,7 @@ class AsyncRounds:
             b.params.copy_(self._recv)
             b.params_changed()
             self._pending = None
+        _fence(self._send)
         dist.reduce(self._send, dst=self.ps_rank, op=dist.ReduceOp.SUM)
         if self.staleness == 0:
             dist.broadcast(b.params, src=self.ps_rank)
@@ -306,10 +320,12 @@ class AsyncRounds:
         is_owner = self.task.task_index == 0
         while step < training_iter:
             b.grads.zero_()
+            _fence(b.grads)
             dist.reduce(b.grads, dst=self.ps_rank, op=dist.ReduceOp.SUM)
             if is_owner:
                 # W sequential un-averaged SGD applications == one application of the sum
                 b.apply_gradients(scale=1.0, step_inc=self.W)
+            _fence(b.params)
             dist.broadcast(b.params, src=self.ps_rank)
             step += self.W
         b.set_global_step(step)

@@ -82,9 +82,14 @@ def run(F, log=print) -> dict:
 
     if world > 1:
         host, port = task.cluster.master()
-        backend_name = "gloo" if kind == "cpu" else "cpu:gloo,cuda:nccl"
+        cb = getattr(F, "comm_backend", "auto")
+        if cb not in ("auto", "gloo", "nccl"):
+            raise SystemExit(f"--comm_backend={cb!r}: expected auto, gloo or nccl")
+        # gloo moves GPU tensors through the host: slow, but it lets several tasks share one GPU (RCCL refuses
+        # duplicate devices), which is how the GPU suite runs the multi-process modes on a one-GPU box
+        backend_name = "gloo" if (kind == "cpu" or cb == "gloo") else ("nccl" if cb == "nccl" else "cpu:gloo,cuda:nccl")
         comm.init_process_group(backend_name, task.rank, world, master_addr=host, master_port=port,
-                                device=device if kind != "cpu" else None, timeout_s=F.comm_timeout)
+                                device=device if (kind != "cpu" and backend_name != "gloo") else None, timeout_s=F.comm_timeout)
 
     spec = ModelSpec.from_name(F.model)
     data = read_data_sets(F.data_dir, one_hot=(kind == "cpu"), synthetic=F.synthetic,

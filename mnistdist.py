@@ -50,6 +50,8 @@ flags.DEFINE_string("dtype", "bf16", "compute dtype with --backend auto on a GPU
 flags.DEFINE_integer("local_rank", -1, "GPU index for this process (default: LOCAL_RANK or rank % device_count)")
 flags.DEFINE_float("comm_timeout", 1800.0, "collective timeout in seconds (failure detection in sync mode)")
 flags.DEFINE_string("metrics_file", "", "append JSONL metrics here")
+flags.DEFINE_string("comm_backend", "auto", "auto (gloo for the cpu backend, RCCL for GPU tensors) | nccl | gloo "
+                    "(gloo also carries GPU tensors, staged through the host: several tasks sharing ONE GPU, which RCCL refuses)")
 flags.DEFINE_boolean("trace", False, "roctx ranges around steps/collectives/checkpoints (rocprofv3 --marker-trace)")
 flags.DEFINE_integer("fault_inject_step", -1, "test hook: crash this worker after N local steps")
 flags.DEFINE_integer("fault_inject_task", -1, "test hook: which worker task crashes (-1 = any)")

@@ -28,7 +28,7 @@ def free_ports(n):
     return ports
 
 
-def launch(n_ps, n_workers, extra, logdir, per_task_extra=None, timeout=240):
+def launch(n_ps, n_workers, extra, logdir, per_task_extra=None, timeout=240, backend="cpu"):
     ports = free_ports(n_ps + n_workers)
     ps_hosts = ",".join(f"127.0.0.1:{p}" for p in ports[:n_ps])
     wk_hosts = ",".join(f"127.0.0.1:{p}" for p in ports[n_ps:])
@@ -37,7 +37,7 @@ def launch(n_ps, n_workers, extra, logdir, per_task_extra=None, timeout=240):
     for job, n in (("ps", n_ps), ("worker", n_workers)):
         for i in range(n):
             cmd = [sys.executable, "-u", CLI, f"--job_name={job}", f"--task_index={i}", f"--ps_hosts={ps_hosts}",
-                   f"--worker_hosts={wk_hosts}", "--backend=cpu", "--synthetic", f"--logdir={logdir}",
+                   f"--worker_hosts={wk_hosts}", f"--backend={backend}", "--synthetic", f"--logdir={logdir}",
                    "--comm_timeout=120"] + list(extra) + list((per_task_extra or {}).get((job, i), []))
             procs.append(((job, i), subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True,
                                                      env=env, cwd=ROOT)))

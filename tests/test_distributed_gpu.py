@@ -1,0 +1,48 @@
+"""The multi-process modes of the CLI with the HIP backend, on ONE MI355X: RCCL refuses several ranks
+on one device, so the tasks talk over gloo (``--comm_backend=gloo``, GPU tensors staged through the
+host).  What this covers that the CPU suite cannot: the HIP engine behind the strategy interface
+(compute_gradients / flat gradient arena / apply_gradients / params_changed) in the sync, async-p2p
+and async-broadcast modes, the ps role holding a GPU engine, and the chief's checkpoint of
+device-resident parameters.  The RCCL schedule itself (parallel/sync_dp.py) is covered at world 1 in
+test_engine_gpu.py; 2/4/8-GPU runs need a multi-GPU box."""
+import os
+
+import pytest
+
+from test_distributed_cpu import DISPLAY, launch
+
+pytestmark = pytest.mark.gpu
+
+COMMON = ["--comm_backend=gloo", "--learning_rate=0.01", "--noeval", "--display_step=4"]
+
+
+def _ok(out):
+    for key, (rc, o) in out.items():
+        assert rc == 0, (key, o[-3000:])
+
+
+def test_sync_1ps_2workers_hip_backend_over_gloo(gpu_lib, tmp_path):
+    logdir = str(tmp_path / "logs")
+    out = launch(1, 2, ["--mode=sync", "--batch_size=128", "--steps=24"] + COMMON, logdir, backend="hip")
+    _ok(out)
+    w0, w1 = out[("worker", 0)][1], out[("worker", 1)][1]
+    for o in (w0, w1):
+        assert [int(m.group(2)) for m in DISPLAY.finditer(o)] == [0, 4, 8, 12, 16, 20], o
+    l0 = [float(m.group(3)) for m in DISPLAY.finditer(w0)]
+    assert l0[-1] < l0[0]
+    from distributed_tensorflow_amd.checkpoint import read_bundle
+    ck = read_bundle(os.path.join(logdir, "model.ckpt-24"))
+    assert int(ck["Variable_8"]) == 24 and ck["Variable_2"].shape == (3136, 1024)
+
+
+@pytest.mark.parametrize("impl", ["p2p", "broadcast"])
+def test_async_parameter_server_hip_backend_over_gloo(gpu_lib, tmp_path, impl):
+    logdir = str(tmp_path / "logs")
+    out = launch(1, 2, ["--mode=async", f"--async_impl={impl}", "--batch_size=128", "--steps=24"] + COMMON, logdir,
+                 backend="hip")
+    _ok(out)
+    assert "ps/0: done" in out[("ps", 0)][1]
+    for w in (0, 1):
+        assert "Optimization Finished!" in out[("worker", w)][1]
+    files = os.listdir(logdir)
+    assert "checkpoint" in files and any(f.endswith(".index") for f in files)
