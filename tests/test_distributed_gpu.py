@@ -46,3 +46,31 @@ def test_async_parameter_server_hip_backend_over_gloo(gpu_lib, tmp_path, impl):
         assert "Optimization Finished!" in out[("worker", w)][1]
     files = os.listdir(logdir)
     assert "checkpoint" in files and any(f.endswith(".index") for f in files)
+
+
+@pytest.mark.parametrize("optimizer", ["sgd", "adam"])
+def test_overlapped_dp_schedule_world2_over_gloo(gpu_lib, optimizer):
+    """parallel/sync_dp.py (the schedule bench.py runs on N GPUs: deferred dense update, two communicators,
+    1/world scaling in the optimizer kernels) with TWO ranks, each feeding different batches: against a replay
+    of both ranks with plain engines, and rank against rank.  gloo stands in for RCCL (one GPU)."""
+    import socket
+    import subprocess
+    import sys
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    worker = os.path.join(os.path.dirname(os.path.abspath(__file__)), "dp_world2_worker.py")
+    procs = [subprocess.Popen([sys.executable, "-u", worker, str(r), str(port), optimizer], stdout=subprocess.PIPE,
+                              stderr=subprocess.STDOUT, text=True) for r in range(2)]
+    outs = []
+    for p in procs:
+        try:
+            o, _ = p.communicate(timeout=120)
+        except subprocess.TimeoutExpired:
+            for q in procs:
+                q.kill()
+            raise AssertionError("timed out:\n" + p.communicate()[0][-3000:])
+        outs.append((p.returncode, o))
+    for r, (rc, o) in enumerate(outs):
+        assert rc == 0 and f"DPW2 rank {r} ok" in o, o[-3000:]
