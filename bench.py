@@ -42,6 +42,9 @@ def main():
     ap.add_argument("--force_dp", action="store_true",
                     help="diagnostic: run the data-parallel schedule (process group, two communicators, comm_diag) "
                          "even at --gpus 1, to exercise the N>1 code path on a one-GPU box")
+    ap.add_argument("--rehearse_one_gpu", action="store_true",
+                    help="diagnostic: every rank on cuda:0 over gloo -- rehearses the torchrun N>1 launch of this file "
+                         "on a one-GPU box (RCCL refuses ranks that share a device); the number means nothing")
     args = ap.parse_args()
 
     from distributed_tensorflow_amd.engine import DeviceDataset, HipEngine
@@ -54,10 +57,15 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run for N>1")
+    if args.rehearse_one_gpu:
+        import faulthandler
+        faulthandler.dump_traceback_later(45, exit=True)   # a rehearsal that stalls says where
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dp_path = world > 1 or args.force_dp
     if dp_path:
-        comm.init_process_group(backend="nccl", rank=rank, world_size=world, device=torch.device("cuda", local_rank))
+        comm.init_process_group(backend="gloo" if args.rehearse_one_gpu else "nccl", rank=rank, world_size=world,
+                                device=None if args.rehearse_one_gpu else torch.device("cuda", local_rank))
 
     spec = ModelSpec.from_name(args.model)
     B = args.per_gpu_batch
@@ -165,7 +173,7 @@ def main():
             "dtype": "bf16",
             "data": "synthetic (HBM-resident 28x28x1, random TF-style init)",
             "config": {"model": spec.name, "global_batch": global_batch, "per_gpu_batch": B, "seq_len": None,
-                       "parallelism": f"dp{world}" + ("(forced dp schedule)" if args.force_dp and world == 1 else ""), "optimizer": args.optimizer, "keep_prob": args.keep_prob,
+                       "parallelism": f"dp{world}" + ("(forced dp schedule)" if args.force_dp and world == 1 else "") + ("(rehearsal: gloo, one GPU)" if args.rehearse_one_gpu else ""), "optimizer": args.optimizer, "keep_prob": args.keep_prob,
                        "graph": bool(use_graph)},
             "model_tflops": round(value * fb / 1e12, 2),
             "final_loss": round(loss, 4),

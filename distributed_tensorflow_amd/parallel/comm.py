@@ -34,6 +34,60 @@ def init_process_group(backend: str, rank: int, world_size: int, master_addr: Op
     dist.init_process_group(**kwargs)
 
 
+# ---------------------------------------------------------------------------------------------
+# Collectives that also work for GPU tensors over gloo (--comm_backend=gloo: several tasks sharing ONE GPU,
+# which RCCL refuses -- how the GPU suite runs the multi-process modes on a one-GPU box).  ProcessGroupGloo's
+# own device-tensor path is not usable on this torch/ROCm build: with kernels in flight on the caller's stream a
+# collective stalls for seconds to forever, and even fenced with a device synchronize it stalled intermittently
+# under the data-parallel schedule.  So a device tensor is staged through host memory HERE and gloo only ever
+# sees CPU tensors.  RCCL ("nccl") and CPU tensors go straight through.
+# ---------------------------------------------------------------------------------------------
+def staged(t: torch.Tensor, group=None) -> bool:
+    return t.is_cuda and dist.get_backend(group) == "gloo"
+
+
+def all_reduce_sum(t: torch.Tensor, group=None):
+    if staged(t, group):
+        h = t.cpu()                      # blocking copy: also drains the producing kernels of the current stream
+        dist.all_reduce(h, op=dist.ReduceOp.SUM, group=group)
+        t.copy_(h)
+    else:
+        dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
+
+
+def broadcast(t: torch.Tensor, src: int, group=None):
+    if staged(t, group):
+        h = t.cpu()
+        dist.broadcast(h, src=src, group=group)
+        if dist.get_rank() != src:
+            t.copy_(h)
+    else:
+        dist.broadcast(t, src=src, group=group)
+
+
+def reduce_sum(t: torch.Tensor, dst: int, group=None):
+    if staged(t, group):
+        h = t.cpu()
+        dist.reduce(h, dst=dst, op=dist.ReduceOp.SUM, group=group)
+        if dist.get_rank() == dst:
+            t.copy_(h)
+    else:
+        dist.reduce(t, dst=dst, op=dist.ReduceOp.SUM, group=group)
+
+
+def send(t: torch.Tensor, dst: int):
+    dist.send(t.cpu() if staged(t) else t, dst=dst)
+
+
+def recv(t: torch.Tensor, src: int):
+    if staged(t):
+        h = torch.empty(t.shape, dtype=t.dtype)
+        dist.recv(h, src=src)
+        t.copy_(h)
+    else:
+        dist.recv(t, src=src)
+
+
 def world_size() -> int:
     return dist.get_world_size() if dist.is_initialized() else 1
 
@@ -65,15 +119,18 @@ def allreduce_latency_us(numel: int, group=None, device: Optional[torch.device] 
         if device.type == "cuda":
             torch.cuda.synchronize(device)
 
+    sync()
     for _ in range(warmup):
-        dist.all_reduce(buf, group=group)
+        all_reduce_sum(buf, group=group)
     sync()
     dist.barrier(group=group)
     sync()
     t0 = time.perf_counter()
     for _ in range(iters):
-        dist.all_reduce(buf, group=group)
+        all_reduce_sum(buf, group=group)
     sync()
-    us = torch.tensor([(time.perf_counter() - t0) * 1e6 / iters], dtype=torch.float64, device=device)
+    us = torch.tensor([(time.perf_counter() - t0) * 1e6 / iters], dtype=torch.float64)
+    if dist.get_backend(group) != "gloo":
+        us = us.to(device)
     dist.all_reduce(us, op=dist.ReduceOp.MAX, group=group)
     return float(us.item())

@@ -32,6 +32,7 @@ import torch.distributed as dist
 from ..backends import Backend
 from ..cluster import TaskInfo, replica_device_setter
 from ..models.spec import TF_VARIABLE_NAMES
+from . import comm
 
 KIND_GRAD, KIND_PULL, KIND_BYE = 0.0, 1.0, 2.0
 
@@ -52,15 +53,6 @@ def ps_shards(task: TaskInfo, backend: Backend) -> Tuple[Dict[int, List[Tuple[in
     for p in shards:
         shards[p].sort()
     return shards, placement["global_step"]
-
-
-def _fence(t: torch.Tensor):
-    """gloo carrying a GPU tensor (several tasks on one GPU, --comm_backend=gloo): drain the device first.
-    ProcessGroupGloo stages device tensors through pinned host memory on streams of its own; on MI355X,
-    letting it wait by itself for kernels still running on the caller's stream stretched a 13 MB all-reduce
-    from 3 ms to ~15 s (tests/test_distributed_gpu.py).  RCCL and CPU tensors need nothing."""
-    if t.is_cuda and dist.get_backend() == "gloo":
-        torch.cuda.synchronize(t.device)
 
 
 def _gather(flat: torch.Tensor, ranges, out: torch.Tensor):
@@ -131,8 +123,7 @@ class SyncAllReduce:
             self._dp.train_step()
         else:
             self.b.compute_gradients()
-            _fence(self.b.grads)
-            dist.all_reduce(self.b.grads, op=dist.ReduceOp.SUM, group=self.group)
+            comm.all_reduce_sum(self.b.grads, group=self.group)
             self.b.apply_gradients(scale=1.0 / self.world)
         self.step_count += 1
         return self.step_count
@@ -145,11 +136,10 @@ class SyncAllReduce:
 def broadcast_state(backend: Backend, src_rank: int, group=None):
     """Chief -> everyone: parameters + global_step (reference: chief runs init_op / restore while
     the other tasks wait for the variables to be initialised)."""
-    _fence(backend.params)
-    dist.broadcast(backend.params, src=src_rank, group=group)
+    comm.broadcast(backend.params, src_rank, group=group)
     dev = backend.params.device
     st = torch.tensor([backend.get_global_step()], dtype=torch.int64, device=dev)
-    dist.broadcast(st, src=src_rank, group=group)
+    comm.broadcast(st, src_rank, group=group)
     backend.set_global_step(int(st.item()))
     backend.params_changed()
 
@@ -180,14 +170,13 @@ class AsyncP2PWorker:
             if kind == KIND_GRAD:
                 _gather(b.grads, ranges, m)
             m[n] = kind
-            _fence(m)
-            dist.send(m, dst=p)
+            comm.send(m, p)
         if kind == KIND_BYE:
             return
         for p, ranges in self.shards.items():          # ... and pull the fresh shard back
             r = self.resp[p]
             n = r.numel() - 2
-            dist.recv(r, src=p)
+            comm.recv(r, p)
             _scatter(r, ranges, b.params)
             if p == self.step_owner:
                 self.step_count = _get_int(r, n)
@@ -235,7 +224,7 @@ class AsyncP2PServer:
             resp = torch.zeros(n + 2, dtype=torch.float32, device=dev)
             while True:
                 try:
-                    dist.recv(buf, src=w)
+                    comm.recv(buf, w)
                     kind = float(buf[n].item())
                     if kind == KIND_BYE:
                         return
@@ -248,8 +237,7 @@ class AsyncP2PServer:
                         _gather(b.params, self.ranges, resp)
                         _set_int(resp, n, self._step)
                         _set_int(resp, n + 1, 1 if self._step >= self.training_iter else 0)
-                        _fence(resp)
-                    dist.send(resp, dst=w)
+                    comm.send(resp, w)
                 except (RuntimeError, ValueError) as e:     # worker died: keep serving the others
                     self.log(f"ps/{self.task.task_index}: worker rank {w} lost ({type(e).__name__}); continuing")
                     self.dropped.append(w)
@@ -277,7 +265,8 @@ class AsyncRounds:
         self.ps_rank = 0
         self.W = task.num_workers
         self.step_count = backend.get_global_step()
-        self._recv = torch.zeros_like(backend.params)
+        # staleness 1 receives the next parameters in the background: into host memory when gloo carries a GPU model
+        self._recv = torch.zeros_like(backend.params, device="cpu" if comm.staged(backend.params) else None)
         self._send = torch.zeros_like(backend.grads)
         self._pending = None
 
@@ -295,10 +284,9 @@ class AsyncRounds:
             b.params.copy_(self._recv)
             b.params_changed()
             self._pending = None
-        _fence(self._send)
-        dist.reduce(self._send, dst=self.ps_rank, op=dist.ReduceOp.SUM)
+        comm.reduce_sum(self._send, self.ps_rank)
         if self.staleness == 0:
-            dist.broadcast(b.params, src=self.ps_rank)
+            comm.broadcast(b.params, self.ps_rank)
             b.params_changed()
         else:
             self._pending = dist.broadcast(self._recv, src=self.ps_rank, async_op=True)
@@ -320,13 +308,11 @@ class AsyncRounds:
         is_owner = self.task.task_index == 0
         while step < training_iter:
             b.grads.zero_()
-            _fence(b.grads)
-            dist.reduce(b.grads, dst=self.ps_rank, op=dist.ReduceOp.SUM)
+            comm.reduce_sum(b.grads, self.ps_rank)
             if is_owner:
                 # W sequential un-averaged SGD applications == one application of the sum
                 b.apply_gradients(scale=1.0, step_inc=self.W)
-            _fence(b.params)
-            dist.broadcast(b.params, src=self.ps_rank)
+            comm.broadcast(b.params, self.ps_rank)
             step += self.W
         b.set_global_step(step)
         return step

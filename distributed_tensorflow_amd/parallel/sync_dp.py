@@ -34,6 +34,7 @@ import torch.distributed as dist
 from ..engine import HipEngine
 from ..ops.native import check
 from ..utils import trace
+from . import comm as _pg
 
 
 def make_buckets(lo: int, hi: int, bucket_elems: int) -> List[Tuple[int, int]]:
@@ -74,7 +75,6 @@ class SyncDataParallel:
         self.group = group
         self.tail_group = tail_group if tail_group is not None else group
         self.world = dist.get_world_size(group)
-        self._gloo = dist.get_backend(group) == "gloo"
         self.comm_stream = torch.cuda.Stream(engine.device)
         # The tail collective runs on the COMPUTE stream by default: it sits at the very end of backward and
         # everything after it depends on it, so a stream of its own buys no overlap and costs four event calls
@@ -93,17 +93,16 @@ class SyncDataParallel:
 
     def broadcast_parameters(self, src: int = 0):
         """Chief initialises, everybody else receives (reference: chief runs init_op)."""
-        torch.cuda.synchronize(self.eng.device)
-        dist.broadcast(self.eng.params, src=src, group=self.group)
-        dist.broadcast(self.eng.state, src=src, group=self.group)
+        _pg.broadcast(self.eng.params, src, group=self.group)
+        _pg.broadcast(self.eng.state, src, group=self.group)
         self.eng.state[self.eng.STATE_CURSOR] = 0
         self.eng.refresh_shadows()
         torch.cuda.synchronize()
 
     def _allreduce(self, lo: int, hi: int, group):
-        if self._gloo:   # gloo staging GPU tensors (ranks sharing one GPU in tests): drain the device first, see
-            torch.cuda.synchronize(self.eng.device)   # strategies._fence -- correctness runs only, nothing overlaps
-        dist.all_reduce(self.eng.grads[lo:hi], op=dist.ReduceOp.SUM, group=group)
+        # RCCL reduces in place on the current stream; over gloo (ranks sharing one GPU in tests and rehearsals)
+        # parallel/comm.py stages the range through the host -- correct, nothing overlaps
+        _pg.all_reduce_sum(self.eng.grads[lo:hi], group=group)
 
     def train_step(self):
         """One synchronous step.  All launches, stream waits and event records of the schedule above

@@ -74,3 +74,50 @@ def test_overlapped_dp_schedule_world2_over_gloo(gpu_lib, optimizer):
         outs.append((p.returncode, o))
     for r, (rc, o) in enumerate(outs):
         assert rc == 0 and f"DPW2 rank {r} ok" in o, o[-3000:]
+
+
+def _bench(args, launcher=()):
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, *launcher, os.path.join(root, "bench.py"), *args], capture_output=True,
+                       text=True, cwd=root, timeout=150)
+    assert r.returncode == 0, (r.stdout + r.stderr)[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout          # the contract: ONE JSON line, from rank 0
+    return json.loads(lines[0])
+
+
+CONTRACT = ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+            "vs_baseline", "dtype", "data", "config")
+
+
+def test_bench_contract_single_gpu(gpu_lib):
+    d = _bench(["--steps", "30", "--warmup", "5"])
+    assert all(k in d for k in CONTRACT)
+    assert d["n_gpus"] == 1 and d["steps"] == 30 and d["warmup"] == 5 and d["dtype"] == "bf16"
+    assert d["config"]["global_batch"] == 1024 and d["config"]["parallelism"] == "dp1"
+    assert abs(d["value"] - 1024 * 30 / (d["ms_per_step"] * 30 / 1e3)) / d["value"] < 1e-3
+    assert d["value"] > 1e6                   # two orders of magnitude below that means a fallback path ran
+
+
+def test_bench_torchrun_launch_rehearsal_world2(gpu_lib):
+    """The driver's N>1 command line (torch.distributed.run, one rank per GPU) rehearsed with both ranks on the
+    one GPU over gloo: process-group bring-up from the torchrun environment, second communicator, the
+    data-parallel step, max-over-ranks timing, comm_diag, one JSON line from rank 0."""
+    import socket
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    d = _bench(["--gpus", "2", "--steps", "10", "--warmup", "3", "--rehearse_one_gpu"],
+               launcher=("-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
+                         "127.0.0.1", "--master-port", str(port)))
+    assert all(k in d for k in CONTRACT)
+    assert d["n_gpus"] == 2 and d["config"]["global_batch"] == 2048 and d["scaling"] == "weak"
+    assert d["config"]["parallelism"].startswith("dp2")
+    diag = d["comm_diag"]
+    assert "error" not in diag, diag
+    assert diag["dense_allreduce_bytes"] == 4 * 3136 * 1024 and diag["dense_allreduce_us"] > 0
+    assert diag["step_ms_no_allreduce"] < d["ms_per_step"]
