@@ -91,7 +91,7 @@ def run(F, log=print) -> dict:
         comm.init_process_group(backend_name, task.rank, world, master_addr=host, master_port=port,
                                 device=device if (kind != "cpu" and backend_name != "gloo") else None, timeout_s=F.comm_timeout)
 
-    spec = ModelSpec.from_name(F.model)
+    spec = ModelSpec.from_name(getattr(F, "width", "") or F.model)
     data = read_data_sets(F.data_dir, one_hot=(kind == "cpu"), synthetic=F.synthetic,
                           seed=F.seed + 1000 * task.rank)   # every worker shuffles independently (ref. item 9)
     backend = make_backend(kind, spec, F.batch_size, data, optimizer=F.optimizer, learning_rate=F.learning_rate,
@@ -148,6 +148,7 @@ def run(F, log=print) -> dict:
     sv = Supervisor(backend, is_chief=task.is_chief, logdir=F.logdir or None, save_model_secs=F.save_model_secs,
                     saver=Saver(write_version=getattr(F, "saver_write_version", 2)), init_seed=F.seed, log=log)
     timer = StepTimer()
+    eval_every = int(getattr(F, "eval_every", 0) or 0)
     tracing = trace.set_enabled(True) if getattr(F, "trace", False) else trace.enabled()
     images_per_step = F.batch_size * (task.num_workers if mode == "sync" else 1)
     t_start = time.perf_counter()
@@ -173,6 +174,13 @@ def run(F, log=print) -> dict:
                 log(format_display_line(task.job_name, task.task_index, prev, loss, acc))
                 lap = timer.lap()
                 metrics.log(step=prev, loss=loss, accuracy=acc, role=result["role"], **lap)
+            if eval_every > 0 and task.is_chief and step // eval_every != prev // eval_every \
+                    and not (F.eval and step >= F.training_iter):      # the final evaluation covers the last step
+                backend.synchronize()    # a deferred dense update (parallel/sync_dp.py) may still be on the comm stream
+                with trace.range("evaluate test"):
+                    tl, ta = backend.evaluate("test")    # other workers keep training in async mode, wait in sync mode
+                log(f"test accuracy: {ta:.4f}  test loss: {tl:.4f}  (global_step {step})")
+                metrics.log(step=step, test_loss=tl, test_accuracy=ta, role=result["role"])
             if tracing: trace.push("supervisor.maybe_save")
             sv.maybe_save()
             if tracing: trace.pop()

@@ -38,6 +38,8 @@ flags.DEFINE_integer("staleness", 1, "async broadcast rounds: gradient staleness
 flags.DEFINE_string("optimizer", "sgd", "sgd (reference) | adam (TF deep-MNIST tutorial recipe)")
 flags.DEFINE_float("keep_prob", 1.0, "dropout keep probability (the reference feeds 1.0)")
 flags.DEFINE_string("model", "deep_mnist", "deep_mnist | wide (conv 128/256, fc4096)")
+flags.DEFINE_string("width", "", "alias of --model: base | wide")
+flags.DEFINE_integer("eval_every", 0, "chief also evaluates the test split every N global steps (0 = only at the end)")
 flags.DEFINE_string("backend", "auto", "auto | hip (MI355X kernels) | cpu (PyTorch oracle, gloo) | torch / torch_bf16 (fp32 / autocast ATen reference on the GPU)")
 flags.DEFINE_string("logdir", "/tmp/train_logs", "checkpoint directory (reference hard-codes /tmp/train_logs); '' disables")
 flags.DEFINE_float("save_model_secs", 600.0, "seconds between chief checkpoints (reference: 600)")
