@@ -11,7 +11,7 @@ from __future__ import annotations
 
 import ctypes
 import os
-from ctypes import c_float, c_int, c_long, c_uint, c_uint64, c_void_p
+from ctypes import c_char_p, c_double, c_float, c_int, c_long, c_uint, c_uint64, c_void_p
 from pathlib import Path
 from typing import Optional
 
@@ -69,6 +69,14 @@ _SIGS = {
                               ctypes.POINTER(c_long), ctypes.POINTER(c_long), c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                               c_void_p, c_long, c_long, c_void_p, c_long, c_int, c_int, c_void_p, c_long, c_int, c_void_p,
                               c_int, c_long, c_long, c_long, c_void_p],
+    "dtf_p2p_bytes": [c_int, c_long],
+    "dtf_p2p_alloc": [c_long, ctypes.POINTER(c_void_p)],
+    "dtf_p2p_free": [c_void_p],
+    "dtf_p2p_export": [c_void_p, c_char_p],
+    "dtf_p2p_import": [c_char_p, ctypes.POINTER(c_void_p)],
+    "dtf_p2p_unmap": [c_void_p],
+    "dtf_p2p_allreduce": [c_void_p, ctypes.POINTER(c_void_p), c_int, c_int, c_long, c_long, c_uint, c_void_p, c_double,
+                          c_void_p],
     "dtf_sample_indices": [c_void_p, c_void_p, c_int, c_uint, c_uint, c_uint, c_int, c_void_p],
     "dtf_gen_synthetic": [c_void_p, c_void_p, c_long, c_uint, c_void_p],
     "dtf_init_truncated_normal": [c_void_p, c_long, c_float, c_uint64, c_uint64, c_void_p],
@@ -141,7 +149,7 @@ def load() -> ctypes.CDLL:
     for name, argtypes in list(_SIGS.items()) + list(_ENGINE_SIGS.items()):
         fn = getattr(lib, name)
         fn.argtypes = argtypes
-        fn.restype = c_int
+        fn.restype = c_long if name == "dtf_p2p_bytes" else c_int
     _lib = lib
     return lib
 
