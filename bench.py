@@ -42,6 +42,8 @@ def main():
     ap.add_argument("--force_dp", action="store_true",
                     help="diagnostic: run the data-parallel schedule (process group, two communicators, comm_diag) "
                          "even at --gpus 1, to exercise the N>1 code path on a one-GPU box")
+    ap.add_argument("--no_p2p_tail", action="store_true",
+                    help="N>1: keep the small tail all-reduce on RCCL instead of the one-shot peer-to-peer kernel")
     ap.add_argument("--rehearse_one_gpu", action="store_true",
                     help="diagnostic: every rank on cuda:0 over gloo -- rehearses the torchrun N>1 launch of this file "
                          "on a one-GPU box (RCCL refuses ranks that share a device); the number means nothing")
@@ -78,13 +80,30 @@ def main():
     eng.init_params(seed=7)
 
     use_graph = False
+    tail_p2p, tail_how = None, "n/a"
     if dp_path:
         try:   # second communicator: the small tail all-reduce must not queue behind the 12.8 MB one inside RCCL
             tail_group = torch.distributed.new_group()
         except Exception as e:   # still correct without it, only slower: the tail then rides the comm stream
             print(f"[bench] rank {rank}: no second communicator ({e}); tail all-reduce shares the first", file=sys.stderr)
             tail_group = None
-        dp = SyncDataParallel(eng, tail_group=tail_group)
+        # The latency-bound tail message (0.25 MB) goes through the one-shot peer-to-peer kernel (parallel/p2p.py) if
+        # its bring-up works on this node AND it reproduces the process group's sums on every rank; otherwise RCCL.
+        tail_p2p, tail_how = None, "rccl"
+        if not args.no_p2p_tail and world <= 8:
+            try:
+                from distributed_tensorflow_amd.parallel.p2p import P2PAllReduce
+                n_tail_arena = eng.layout.total - eng.layout.segment("wd1", "wd1")[1]
+                cand = P2PAllReduce(n_tail_arena, torch.device("cuda", local_rank), timeout_s=10.0)
+                if cand.self_check(n_tail_arena):
+                    tail_p2p, tail_how = cand, "p2p one-shot"
+                else:
+                    cand.close()
+                    tail_how = "rccl (p2p self-check failed)"
+            except Exception as e:      # bring-up votes are unanimous, so every rank lands here together
+                tail_how = f"rccl (p2p bring-up failed: {type(e).__name__})"
+                print(f"[bench] rank {rank}: {e}", file=sys.stderr)
+        dp = SyncDataParallel(eng, tail_group=tail_group, tail_p2p=tail_p2p)
         dp.broadcast_parameters()
         step = dp.train_step
     else:
@@ -115,6 +134,8 @@ def main():
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
         dt = float(t.item())
     loss, acc = eng.last_metrics()
+    if tail_p2p is not None and tail_p2p.status():
+        tail_how += " (a wait TIMED OUT inside the timed region: sums invalid)"
     comm_diag = None
     if dp_path:
         # Outside the timed region: stand-alone latency of the step's two all-reduces (the dense fc1 gradient
@@ -138,6 +159,9 @@ def main():
                     if not (skip_tail if is_tail else skip_dense):
                         real(lo, hi, group)
                 dp._allreduce = ar
+                p2p_real = dp.tail_p2p
+                if skip_tail and p2p_real is not None:
+                    dp.tail_p2p = type("NoTail", (), {"allreduce": staticmethod(lambda t, s=None: None)})()
                 for _ in range(20):
                     step()
                 barrier()
@@ -147,9 +171,20 @@ def main():
                 barrier()
                 ms = torch.tensor([(time.perf_counter() - t1) * 1e3 / n], dtype=torch.float64, device=dev)
                 torch.distributed.all_reduce(ms, op=torch.distributed.ReduceOp.MAX)
-                dp._allreduce = real
+                dp._allreduce, dp.tail_p2p = real, p2p_real
                 return round(float(ms.item()), 4)
 
+            if tail_p2p is not None:
+                xt = torch.zeros(n_tail_arena, device=dev)
+                for _ in range(10):
+                    tail_p2p.allreduce(xt)
+                barrier()
+                t1 = time.perf_counter()
+                for _ in range(100):
+                    tail_p2p.allreduce(xt)
+                torch.cuda.synchronize()
+                comm_diag["tail_p2p_us"] = round((time.perf_counter() - t1) * 1e4, 1)
+                comm_diag["tail_p2p_timeouts"] = tail_p2p.status()
             comm_diag["step_ms_no_allreduce"] = timed(True, True)
             comm_diag["step_ms_dense_allreduce_only"] = timed(False, True)
             comm_diag["step_ms_tail_allreduce_only"] = timed(True, False)
@@ -174,12 +209,16 @@ def main():
             "data": "synthetic (HBM-resident 28x28x1, random TF-style init)",
             "config": {"model": spec.name, "global_batch": global_batch, "per_gpu_batch": B, "seq_len": None,
                        "parallelism": f"dp{world}" + ("(forced dp schedule)" if args.force_dp and world == 1 else "") + ("(rehearsal: gloo, one GPU)" if args.rehearse_one_gpu else ""), "optimizer": args.optimizer, "keep_prob": args.keep_prob,
-                       "graph": bool(use_graph)},
+                       "graph": bool(use_graph),
+                       **({"tail_allreduce": tail_how} if dp_path else {})},
             "model_tflops": round(value * fb / 1e12, 2),
             "final_loss": round(loss, 4),
             **({"comm_diag": comm_diag} if comm_diag is not None else {}),
         }))
     if dp_path:
+        if tail_p2p is not None:
+            barrier()
+            tail_p2p.close()
         torch.distributed.destroy_process_group()
 
 

@@ -40,23 +40,38 @@ class P2PAllReduce:
         self._status = torch.zeros(1, dtype=torch.int32, device=self.device)
         self._mapped: List[int] = []
         self._own = ctypes.c_void_p()
+        err: Optional[str] = None
+        handle = ctypes.create_string_buffer(64)
         with torch.cuda.device(self.device):
-            nbytes = self.lib.dtf_p2p_bytes(self.world, self.n_max)
-            native.check(self.lib.dtf_p2p_alloc(nbytes, ctypes.byref(self._own)), "p2p alloc")
-            handle = ctypes.create_string_buffer(64)
-            native.check(self.lib.dtf_p2p_export(self._own, handle), "hipIpcGetMemHandle")
+            try:
+                nbytes = self.lib.dtf_p2p_bytes(self.world, self.n_max)
+                native.check(self.lib.dtf_p2p_alloc(nbytes, ctypes.byref(self._own)), "p2p alloc")
+                native.check(self.lib.dtf_p2p_export(self._own, handle), "hipIpcGetMemHandle")
+            except Exception as e:     # keep making the collective calls below: the peers are waiting in them
+                err = repr(e)
             handles: List[Optional[bytes]] = [None] * self.world
-            dist.all_gather_object(handles, handle.raw, group=group)
+            dist.all_gather_object(handles, None if err else handle.raw, group=group)
             bases = (ctypes.c_void_p * self.world)()
-            for r, h in enumerate(handles):
-                if r == self.rank:
-                    bases[r] = self._own.value
-                else:
-                    p = ctypes.c_void_p()
-                    native.check(self.lib.dtf_p2p_import(h, ctypes.byref(p)), f"hipIpcOpenMemHandle(rank {r})")
-                    bases[r] = p.value
-                    self._mapped.append(p.value)
+            if err is None and any(h is None for h in handles):
+                err = "a peer could not allocate/export its buffer"
+            if err is None:
+                try:
+                    for r, h in enumerate(handles):
+                        if r == self.rank:
+                            bases[r] = self._own.value
+                        else:
+                            p = ctypes.c_void_p()
+                            native.check(self.lib.dtf_p2p_import(h, ctypes.byref(p)), f"hipIpcOpenMemHandle(rank {r})")
+                            bases[r] = p.value
+                            self._mapped.append(p.value)
+                except Exception as e:
+                    err = repr(e)
             self._bases = bases
+        oks: List[Optional[str]] = [None] * self.world
+        dist.all_gather_object(oks, err, group=group)     # unanimous: either every rank has every mapping or nobody goes on
+        if any(o is not None for o in oks):
+            self.close()
+            raise RuntimeError("P2PAllReduce bring-up failed: " + "; ".join(f"rank {r}: {o}" for r, o in enumerate(oks) if o))
         dist.barrier(group=group)     # nobody pushes before everybody has mapped (and zeroed) everything
 
     def allreduce(self, t: torch.Tensor, stream: Optional[int] = None):

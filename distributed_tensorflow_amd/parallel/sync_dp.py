@@ -70,7 +70,7 @@ class SyncDataParallel:
     DENSE_SLOT, TAIL_SLOT = 3, 4   # per-range Adam step counters in the device state
 
     def __init__(self, engine: HipEngine, bucket_mb: float = 64.0, group=None, tail_group=None,
-                 defer_dense_update: bool = True):
+                 defer_dense_update: bool = True, tail_p2p=None):
         self.eng = engine
         self.group = group
         self.tail_group = tail_group if tail_group is not None else group
@@ -81,7 +81,10 @@ class SyncDataParallel:
         # (5-8 us of host time each on this stack, and the step is host-bound).  What it does need is its own
         # communicator (tail_group), so that it is not ordered behind the long dense all-reduce inside RCCL.
         # Without a second communicator it has to queue on the comm stream behind the dense collective.
-        self.tail_stream = None if tail_group is not None else self.comm_stream
+        # tail_p2p (parallel/p2p.py): the tail goes through the one-shot peer-to-peer kernel instead of RCCL, also on
+        # the compute stream.
+        self.tail_p2p = tail_p2p
+        self.tail_stream = None if (tail_group is not None or tail_p2p is not None) else self.comm_stream
         self.defer = defer_dense_update
         lay = engine.layout
         self.n_dense = lay.segment("wd1", "wd1")[1]     # the dense collective covers wd1 only; head + conv form the tail
@@ -125,7 +128,9 @@ class SyncDataParallel:
         if tr: tr.pop(); tr.push("dp_phase2: conv backward")
         check(lib.dtf_engine_dp_phase2(d, self.n_dense, self.DENSE_SLOT, cur, comm, tail), "dp_phase2")
         if tr: tr.pop(); tr.push("allreduce tail (enqueue)")
-        if self.tail_stream is None:
+        if self.tail_p2p is not None:
+            self.tail_p2p.allreduce(eng.grads[self.tail_bucket[0]:self.tail_bucket[1]], cur)
+        elif self.tail_stream is None:
             self._allreduce(*self.tail_bucket, self.tail_group)
         else:
             with torch.cuda.stream(self.tail_stream):

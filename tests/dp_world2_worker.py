@@ -14,7 +14,7 @@ from distributed_tensorflow_amd.models.spec import ModelSpec  # noqa: E402
 from distributed_tensorflow_amd.parallel import comm  # noqa: E402
 from distributed_tensorflow_amd.parallel.sync_dp import SyncDataParallel  # noqa: E402
 
-rank, port, optimizer = int(sys.argv[1]), int(sys.argv[2]), sys.argv[3]
+rank, port, optimizer, tail = int(sys.argv[1]), int(sys.argv[2]), sys.argv[3], sys.argv[4]
 B, STEPS, LR = 64, 5, (0.01 if optimizer == "sgd" else 1e-3)
 torch.cuda.set_device(0)
 comm.init_process_group("gloo", rank, 2, "127.0.0.1", port, timeout_s=90)
@@ -28,7 +28,11 @@ def engine(seed):
 
 eng = engine(1000 + rank)
 eng.init_params(seed=7 + rank)            # rank 1 starts from other weights: the broadcast has to fix that
-dp = SyncDataParallel(eng, tail_group=dist.new_group())
+tail_p2p = None
+if tail == "p2p":     # the tail message through the one-shot peer-to-peer kernel instead of the process group
+    from distributed_tensorflow_amd.parallel.p2p import P2PAllReduce
+    tail_p2p = P2PAllReduce(eng.layout.total - eng.layout.segment("wd1", "wd1")[1], eng.device)
+dp = SyncDataParallel(eng, tail_group=dist.new_group(), tail_p2p=tail_p2p)
 dp.broadcast_parameters()
 
 refs = [engine(1000 + q) for q in (0, 1)]
@@ -62,5 +66,9 @@ assert eng.global_step == refs[rank].global_step == STEPS
 both = [torch.empty_like(eng.params) for _ in range(2)]
 dist.all_gather(both, eng.params)
 assert torch.equal(both[0], both[1]), "ranks diverged"
+if tail_p2p is not None:
+    assert tail_p2p.status() == 0
+    dist.barrier()
+    tail_p2p.close()
 print(f"DPW2 rank {rank} ok: max |dp - replay| = {err:.3g}, losses {losses[0][0]:.4f} -> {losses[-1][0]:.4f}", flush=True)
 comm.shutdown()

@@ -48,11 +48,12 @@ def test_async_parameter_server_hip_backend_over_gloo(gpu_lib, tmp_path, impl):
     assert "checkpoint" in files and any(f.endswith(".index") for f in files)
 
 
-@pytest.mark.parametrize("optimizer", ["sgd", "adam"])
-def test_overlapped_dp_schedule_world2_over_gloo(gpu_lib, optimizer):
+@pytest.mark.parametrize("optimizer,tail", [("sgd", "pg"), ("adam", "pg"), ("sgd", "p2p")])
+def test_overlapped_dp_schedule_world2_over_gloo(gpu_lib, optimizer, tail):
     """parallel/sync_dp.py (the schedule bench.py runs on N GPUs: deferred dense update, two communicators,
     1/world scaling in the optimizer kernels) with TWO ranks, each feeding different batches: against a replay
-    of both ranks with plain engines, and rank against rank.  gloo stands in for RCCL (one GPU)."""
+    of both ranks with plain engines, and rank against rank.  gloo stands in for RCCL (one GPU); tail = "p2p" sends
+    the tail message through the one-shot peer-to-peer kernel (parallel/p2p.py) as bench.py does."""
     import socket
     import subprocess
     import sys
@@ -61,7 +62,7 @@ def test_overlapped_dp_schedule_world2_over_gloo(gpu_lib, optimizer):
     port = s.getsockname()[1]
     s.close()
     worker = os.path.join(os.path.dirname(os.path.abspath(__file__)), "dp_world2_worker.py")
-    procs = [subprocess.Popen([sys.executable, "-u", worker, str(r), str(port), optimizer], stdout=subprocess.PIPE,
+    procs = [subprocess.Popen([sys.executable, "-u", worker, str(r), str(port), optimizer, tail], stdout=subprocess.PIPE,
                               stderr=subprocess.STDOUT, text=True) for r in range(2)]
     outs = []
     for p in procs:
