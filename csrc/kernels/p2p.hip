@@ -85,6 +85,101 @@ __global__ __launch_bounds__(kP2PThreads) void p2p_allreduce_oneshot(P2PArgs a) 
   }
 }
 
+// ---------------------------------------------------------------------------------------------
+// Two-shot variant for the large (12.8 MB) dense message: reduce-scatter + all-gather, both as peer pushes.
+// Rank r owns chunk r (n / world elements).  Block b works on slice b of EVERY chunk:
+//   A  push   my data[chunk p][slice b]        -> stageA(par, me) on rank p          flagA(par, me, b) on p
+//      wait   flagA(par, q, b) for all q ; sum stageA(par, q)[slice b] over q in rank order
+//   B  push   that sum                         -> stageB(par)[chunk me][slice b] on every rank   flagB(par, me, b)
+//      wait   flagB(par, q, b) for all q ; copy stageB(par)[chunk q][slice b] -> data, all q
+// Every rank pushes (world-1)/world of the vector in each phase over its world-1 links at once; the result
+// is assembled in uncached staging and copied into the (cached) gradient arena by its owner only, so no peer
+// ever stores into memory that the local L2 may hold.  Same parity argument and bounded waits as above.
+//   stageA [2][world][csz_max] | stageB [2][n_max] | flagA [2][world][kBlocks2] | flagB [2][world][kBlocks2]
+// ---------------------------------------------------------------------------------------------
+constexpr int kP2PBlocks2 = 64;
+constexpr int kP2PThreads2 = 512;
+
+struct P2P2Args {
+  float* data;
+  char* base[kP2PMaxWorld];
+  int* status;
+  int world, rank, n, n_max;
+  unsigned seq;
+  long long timeout_ticks;
+};
+
+__device__ __forceinline__ void p2p_wait_all(const unsigned* flags_row0, int stride, int world, unsigned seq,
+                                             long long timeout_ticks, int* status) {
+  if ((int)threadIdx.x < world) {
+    const unsigned* f = flags_row0 + (size_t)threadIdx.x * stride;
+    const long long t0 = wall_clock64();
+    while (__hip_atomic_load(f, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) != seq) {
+      if (wall_clock64() - t0 > timeout_ticks) {
+        *status = 1;
+        break;
+      }
+      __builtin_amdgcn_s_sleep(2);
+    }
+  }
+  __syncthreads();
+}
+
+__global__ __launch_bounds__(kP2PThreads2) void p2p_allreduce_twoshot(P2P2Args a) {
+  const int tid = threadIdx.x, b = blockIdx.x, W = a.world;
+  const int par = a.seq & 1u;
+  const int csz = a.n / W, csz_max = a.n_max / W;       // n, n_max: multiples of 4 * world
+  const int c4 = csz / 4;
+  const int per = (c4 + kP2PBlocks2 - 1) / kP2PBlocks2;
+  const int lo4 = b * per, hi4 = min(c4, lo4 + per);
+  auto stageA = [&](int r) { return reinterpret_cast<float*>(a.base[r]); };
+  auto stageB = [&](int r) { return reinterpret_cast<float*>(a.base[r]) + 2 * (size_t)a.n_max; };
+  auto flagA = [&](int r) { return reinterpret_cast<unsigned*>(a.base[r] + 16 * (size_t)a.n_max); };
+  auto flagB = [&](int r) { return flagA(r) + 2 * W * kP2PBlocks2; };
+
+  // ---- A: scatter my chunks to their owners ----
+#pragma unroll 1
+  for (int k = 0; k < W; ++k) {
+    const int p = (a.rank + k) % W;
+    const f32x4* src = reinterpret_cast<const f32x4*>(a.data + (size_t)p * csz);
+    f32x4* dst = reinterpret_cast<f32x4*>(stageA(p) + ((size_t)par * W + a.rank) * csz_max);
+    for (int i = lo4 + tid; i < hi4; i += kP2PThreads2) dst[i] = src[i];
+  }
+  __threadfence_system();
+  __syncthreads();
+  if (tid < W)
+    __hip_atomic_store(flagA(tid) + ((size_t)par * W + a.rank) * kP2PBlocks2 + b, a.seq, __ATOMIC_RELEASE,
+                       __HIP_MEMORY_SCOPE_SYSTEM);
+  p2p_wait_all(flagA(a.rank) + (size_t)par * W * kP2PBlocks2 + b, kP2PBlocks2, W, a.seq, a.timeout_ticks, a.status);
+
+  // ---- reduce my chunk (rank order) and B: broadcast it ----
+  {
+    const float* mine = stageA(a.rank) + (size_t)par * W * csz_max;
+    for (int i = lo4 + tid; i < hi4; i += kP2PThreads2) {
+      f32x4 s = reinterpret_cast<const f32x4*>(mine)[i];
+      for (int q = 1; q < W; ++q) s += reinterpret_cast<const f32x4*>(mine + (size_t)q * csz_max)[i];
+#pragma unroll 1
+      for (int k = 0; k < W; ++k) {
+        const int p = (a.rank + k) % W;
+        reinterpret_cast<f32x4*>(stageB(p) + (size_t)par * a.n_max + (size_t)a.rank * csz)[i] = s;
+      }
+    }
+  }
+  __threadfence_system();
+  __syncthreads();
+  if (tid < W)
+    __hip_atomic_store(flagB(tid) + ((size_t)par * W + a.rank) * kP2PBlocks2 + b, a.seq, __ATOMIC_RELEASE,
+                       __HIP_MEMORY_SCOPE_SYSTEM);
+  p2p_wait_all(flagB(a.rank) + (size_t)par * W * kP2PBlocks2 + b, kP2PBlocks2, W, a.seq, a.timeout_ticks, a.status);
+
+  // ---- gather: every chunk's slice b out of my staging into the arena ----
+  for (int q = 0; q < W; ++q) {
+    const f32x4* src = reinterpret_cast<const f32x4*>(stageB(a.rank) + (size_t)par * a.n_max + (size_t)q * csz);
+    f32x4* dst = reinterpret_cast<f32x4*>(a.data + (size_t)q * csz);
+    for (int i = lo4 + tid; i < hi4; i += kP2PThreads2) dst[i] = src[i];
+  }
+}
+
 }  // namespace dtf
 
 extern "C" {
@@ -149,6 +244,30 @@ int dtf_p2p_allreduce(void* data, void* const* bases, int world, int rank, long 
   a.seq = seq;
   a.timeout_ticks = (long long)(timeout_s * 1e8);
   hipLaunchKernelGGL(dtf::p2p_allreduce_oneshot, dim3(dtf::kP2PBlocks), dim3(dtf::kP2PThreads), 0, s, a);
+  return (int)hipGetLastError();
+}
+
+long dtf_p2p2_bytes(int world, long n_max) {
+  return 16L * n_max + 4L * world * dtf::kP2PBlocks2 * 4;
+}
+
+// Two-shot variant; n and n_max must be multiples of 4 * world.
+int dtf_p2p2_allreduce(void* data, void* const* bases, int world, int rank, long n, long n_max, unsigned seq,
+                       int* status, double timeout_s, hipStream_t s) {
+  if (world < 1 || world > dtf::kP2PMaxWorld || rank < 0 || rank >= world) return -2;
+  if (n < 0 || n > n_max || n % (4 * world) || n_max % (4 * world) || seq == 0) return -2;
+  if ((reinterpret_cast<uintptr_t>(data) & 15) != 0) return -3;
+  dtf::P2P2Args a;
+  a.data = static_cast<float*>(data);
+  for (int r = 0; r < dtf::kP2PMaxWorld; ++r) a.base[r] = static_cast<char*>(bases[r < world ? r : rank]);
+  a.status = status;
+  a.world = world;
+  a.rank = rank;
+  a.n = (int)n;
+  a.n_max = (int)n_max;
+  a.seq = seq;
+  a.timeout_ticks = (long long)(timeout_s * 1e8);
+  hipLaunchKernelGGL(dtf::p2p_allreduce_twoshot, dim3(dtf::kP2PBlocks2), dim3(dtf::kP2PThreads2), 0, s, a);
   return (int)hipGetLastError();
 }
 

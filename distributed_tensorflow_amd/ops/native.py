@@ -77,6 +77,9 @@ _SIGS = {
     "dtf_p2p_unmap": [c_void_p],
     "dtf_p2p_allreduce": [c_void_p, ctypes.POINTER(c_void_p), c_int, c_int, c_long, c_long, c_uint, c_void_p, c_double,
                           c_void_p],
+    "dtf_p2p2_bytes": [c_int, c_long],
+    "dtf_p2p2_allreduce": [c_void_p, ctypes.POINTER(c_void_p), c_int, c_int, c_long, c_long, c_uint, c_void_p, c_double,
+                           c_void_p],
     "dtf_sample_indices": [c_void_p, c_void_p, c_int, c_uint, c_uint, c_uint, c_int, c_void_p],
     "dtf_gen_synthetic": [c_void_p, c_void_p, c_long, c_uint, c_void_p],
     "dtf_init_truncated_normal": [c_void_p, c_long, c_float, c_uint64, c_uint64, c_void_p],
@@ -149,7 +152,7 @@ def load() -> ctypes.CDLL:
     for name, argtypes in list(_SIGS.items()) + list(_ENGINE_SIGS.items()):
         fn = getattr(lib, name)
         fn.argtypes = argtypes
-        fn.restype = c_long if name == "dtf_p2p_bytes" else c_int
+        fn.restype = c_long if name in ("dtf_p2p_bytes", "dtf_p2p2_bytes") else c_int
     _lib = lib
     return lib
 

@@ -28,13 +28,19 @@ from . import comm
 class P2PAllReduce:
     MAX_WORLD = 8
 
-    def __init__(self, n_max: int, device: torch.device, group=None, timeout_s: float = 2.0):
+    def __init__(self, n_max: int, device: torch.device, group=None, timeout_s: float = 2.0, two_shot: bool = False):
+        """two_shot=False: one-shot (every rank receives and sums all vectors -- latency-optimal, for small messages);
+        two_shot=True: reduce-scatter + all-gather as peer pushes (bandwidth-optimal, for the 12.8 MB dense message)."""
         self.lib = native.load()
+        self.two_shot = bool(two_shot)
         self.group, self.device = group, torch.device(device)
         self.world, self.rank = dist.get_world_size(group), dist.get_rank(group)
         if not 1 <= self.world <= self.MAX_WORLD:
             raise ValueError(f"P2PAllReduce supports up to {self.MAX_WORLD} ranks, got {self.world}")
-        self.n_max = (int(n_max) + 3) & ~3
+        self.quantum = 4 * self.world if self.two_shot else 4      # vector lengths must be multiples of this
+        self.n_max = -(-int(n_max) // self.quantum) * self.quantum
+        self._bytes_fn = self.lib.dtf_p2p2_bytes if self.two_shot else self.lib.dtf_p2p_bytes
+        self._launch = self.lib.dtf_p2p2_allreduce if self.two_shot else self.lib.dtf_p2p_allreduce
         self.timeout_s = float(timeout_s)
         self.seq = 0
         self._status = torch.zeros(1, dtype=torch.int32, device=self.device)
@@ -44,7 +50,7 @@ class P2PAllReduce:
         handle = ctypes.create_string_buffer(64)
         with torch.cuda.device(self.device):
             try:
-                nbytes = self.lib.dtf_p2p_bytes(self.world, self.n_max)
+                nbytes = self._bytes_fn(self.world, self.n_max)
                 native.check(self.lib.dtf_p2p_alloc(nbytes, ctypes.byref(self._own)), "p2p alloc")
                 native.check(self.lib.dtf_p2p_export(self._own, handle), "hipIpcGetMemHandle")
             except Exception as e:     # keep making the collective calls below: the peers are waiting in them
@@ -77,11 +83,11 @@ class P2PAllReduce:
     def allreduce(self, t: torch.Tensor, stream: Optional[int] = None):
         """SUM-all-reduce the fp32 vector ``t`` in place, on ``stream`` (raw handle; default: the current one)."""
         n = t.numel()
-        if t.dtype != torch.float32 or not t.is_contiguous() or n > self.n_max or n % 4:
-            raise ValueError("P2PAllReduce: fp32, contiguous, a multiple of 4 and at most n_max elements")
+        if t.dtype != torch.float32 or not t.is_contiguous() or n > self.n_max or n % self.quantum:
+            raise ValueError(f"P2PAllReduce: fp32, contiguous, a multiple of {self.quantum} and at most n_max elements")
         self.seq += 1
         s = torch.cuda.current_stream(self.device).cuda_stream if stream is None else stream
-        native.check(self.lib.dtf_p2p_allreduce(t.data_ptr(), self._bases, self.world, self.rank, n, self.n_max, self.seq,
+        native.check(self._launch(t.data_ptr(), self._bases, self.world, self.rank, n, self.n_max, self.seq,
                                                 self._status.data_ptr(), self.timeout_s, s), "p2p allreduce")
 
     def status(self) -> int:

@@ -10,12 +10,13 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from distributed_tensorflow_amd.parallel import comm  # noqa: E402
 from distributed_tensorflow_amd.parallel.p2p import P2PAllReduce  # noqa: E402
 
-rank, world, port = int(sys.argv[1]), int(sys.argv[2]), int(sys.argv[3])
+rank, world, port, mode = int(sys.argv[1]), int(sys.argv[2]), int(sys.argv[3]), sys.argv[4]
 torch.cuda.set_device(0)
 dev = torch.device("cuda", 0)
 comm.init_process_group("gloo", rank, world, "127.0.0.1", port, timeout_s=90)
-N = 63372
-p2p = P2PAllReduce(N, dev)
+two = mode == "twoshot"
+N = 3136 * 1024 if two else 63372          # the dense and the tail message of the deep-MNIST step
+p2p = P2PAllReduce(N, dev, two_shot=two)
 assert p2p.self_check(N, iters=6), "self check against the process group's all-reduce failed"
 
 # back-to-back launches without host synchronisation: exact integer sums, both parities, slot reuse
@@ -32,10 +33,11 @@ for k in range(1, 41):
 # a shorter vector, and bit-identical results on every rank for non-trivial data
 g = torch.Generator(device=dev)
 g.manual_seed(77 + rank)
-y = torch.randn(1000, device=dev, generator=g)
+M = 1024 * world if two else 1000
+y = torch.randn(M, device=dev, generator=g)
 p2p.allreduce(y)
 torch.cuda.synchronize()
-gathered = [torch.empty(1000) for _ in range(world)]
+gathered = [torch.empty(M) for _ in range(world)]
 dist.all_gather(gathered, y.cpu())
 assert all(torch.equal(gathered[0], t) for t in gathered), "ranks disagree bitwise"
 assert p2p.status() == 0

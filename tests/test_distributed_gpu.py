@@ -124,8 +124,8 @@ def test_bench_torchrun_launch_rehearsal_world2(gpu_lib):
     assert diag["step_ms_no_allreduce"] < d["ms_per_step"]
 
 
-@pytest.mark.parametrize("world", [2, 4])
-def test_p2p_oneshot_allreduce_between_processes(gpu_lib, world):
+@pytest.mark.parametrize("world,mode", [(2, "oneshot"), (4, "oneshot"), (2, "twoshot"), (4, "twoshot")])
+def test_p2p_allreduce_between_processes(gpu_lib, world, mode):
     """parallel/p2p.py + csrc/kernels/p2p.hip: hipIpc bring-up, flags/parity protocol, exact sums, bitwise agreement
     between ranks.  The ranks share the one GPU here, so the xGMI hop itself (peer stores, system-scope visibility
     across devices) is what this cannot cover -- bench.py keeps RCCL unless the same self-check passes on the node."""
@@ -137,7 +137,7 @@ def test_p2p_oneshot_allreduce_between_processes(gpu_lib, world):
     port = s.getsockname()[1]
     s.close()
     worker = os.path.join(os.path.dirname(os.path.abspath(__file__)), "p2p_worker.py")
-    procs = [subprocess.Popen([sys.executable, "-u", worker, str(r), str(world), str(port)], stdout=subprocess.PIPE,
+    procs = [subprocess.Popen([sys.executable, "-u", worker, str(r), str(world), str(port), mode], stdout=subprocess.PIPE,
                               stderr=subprocess.STDOUT, text=True) for r in range(world)]
     outs = []
     for p in procs:
