@@ -44,6 +44,8 @@ def main():
                          "even at --gpus 1, to exercise the N>1 code path on a one-GPU box")
     ap.add_argument("--no_p2p_tail", action="store_true",
                     help="N>1: keep the small tail all-reduce on RCCL instead of the one-shot peer-to-peer kernel")
+    ap.add_argument("--no_p2p_dense", action="store_true",
+                    help="N>1: keep the dense all-reduce on RCCL even if the two-shot peer-to-peer kernel measures faster")
     ap.add_argument("--rehearse_one_gpu", action="store_true",
                     help="diagnostic: every rank on cuda:0 over gloo -- rehearses the torchrun N>1 launch of this file "
                          "on a one-GPU box (RCCL refuses ranks that share a device); the number means nothing")
@@ -81,6 +83,7 @@ def main():
 
     use_graph = False
     tail_p2p, tail_how = None, "n/a"
+    dense_p2p, dense_how = None, "n/a"
     if dp_path:
         try:   # second communicator: the small tail all-reduce must not queue behind the 12.8 MB one inside RCCL
             tail_group = torch.distributed.new_group()
@@ -90,20 +93,45 @@ def main():
         # The latency-bound tail message (0.25 MB) goes through the one-shot peer-to-peer kernel (parallel/p2p.py) if
         # its bring-up works on this node AND it reproduces the process group's sums on every rank; otherwise RCCL.
         tail_p2p, tail_how = None, "rccl"
-        if not args.no_p2p_tail and world <= 8:
+        dense_p2p, dense_how = None, "rccl"
+        dev = torch.device("cuda", local_rank)
+        n_dense_arena = eng.layout.segment("wd1", "wd1")[1]
+        n_tail_arena = eng.layout.total - n_dense_arena
+
+        def bring_up(n, two_shot):
+            """-> (P2PAllReduce or None, why not)"""
             try:
                 from distributed_tensorflow_amd.parallel.p2p import P2PAllReduce
-                n_tail_arena = eng.layout.total - eng.layout.segment("wd1", "wd1")[1]
-                cand = P2PAllReduce(n_tail_arena, torch.device("cuda", local_rank), timeout_s=10.0)
-                if cand.self_check(n_tail_arena):
-                    tail_p2p, tail_how = cand, "p2p one-shot"
+                cand = P2PAllReduce(n, dev, timeout_s=2.0, two_shot=two_shot)   # bounded waits: a dead path costs seconds
+                if n % cand.quantum:
+                    cand.close()
+                    return None, "rccl (length not a multiple of 4 x world)"
+                if cand.self_check(n, iters=4):
+                    return cand, ""
+                cand.close()
+                return None, "rccl (p2p self-check failed)"
+            except Exception as e:      # bring-up votes are unanimous, so every rank lands here together
+                print(f"[bench] rank {rank}: {e}", file=sys.stderr)
+                return None, f"rccl (p2p bring-up failed: {type(e).__name__})"
+
+        if not args.no_p2p_tail and world <= 8:
+            tail_p2p, why = bring_up(n_tail_arena, False)
+            tail_how = "p2p one-shot" if tail_p2p is not None else why
+        # The dense message (12.8 MB, hidden under backward if it is fast enough) goes peer-to-peer only if the
+        # two-shot kernel is correct here AND clearly faster than RCCL stand-alone on this node.
+        if not args.no_p2p_dense and world > 1 and world <= 8:
+            cand, why = bring_up(n_dense_arena, True)
+            if cand is None:
+                dense_how = why
+            else:
+                t_p2p = cand.latency_us(n_dense_arena)
+                t_pg = comm.allreduce_latency_us(n_dense_arena, device=dev)
+                if t_p2p < 0.85 * t_pg:
+                    dense_p2p, dense_how = cand, f"p2p two-shot ({t_p2p:.0f} us vs rccl {t_pg:.0f} us stand-alone)"
                 else:
                     cand.close()
-                    tail_how = "rccl (p2p self-check failed)"
-            except Exception as e:      # bring-up votes are unanimous, so every rank lands here together
-                tail_how = f"rccl (p2p bring-up failed: {type(e).__name__})"
-                print(f"[bench] rank {rank}: {e}", file=sys.stderr)
-        dp = SyncDataParallel(eng, tail_group=tail_group, tail_p2p=tail_p2p)
+                    dense_how = f"rccl ({t_pg:.0f} us vs p2p two-shot {t_p2p:.0f} us stand-alone)"
+        dp = SyncDataParallel(eng, tail_group=tail_group, tail_p2p=tail_p2p, dense_p2p=dense_p2p)
         dp.broadcast_parameters()
         step = dp.train_step
     else:
@@ -136,6 +164,8 @@ def main():
     loss, acc = eng.last_metrics()
     if tail_p2p is not None and tail_p2p.status():
         tail_how += " (a wait TIMED OUT inside the timed region: sums invalid)"
+    if dense_p2p is not None and dense_p2p.status():
+        dense_how += " (a wait TIMED OUT inside the timed region: sums invalid)"
     comm_diag = None
     if dp_path:
         # Outside the timed region: stand-alone latency of the step's two all-reduces (the dense fc1 gradient
@@ -159,9 +189,11 @@ def main():
                     if not (skip_tail if is_tail else skip_dense):
                         real(lo, hi, group)
                 dp._allreduce = ar
-                p2p_real = dp.tail_p2p
-                if skip_tail and p2p_real is not None:
-                    dp.tail_p2p = type("NoTail", (), {"allreduce": staticmethod(lambda t, s=None: None)})()
+                p2p_real = (dp.tail_p2p, dp.dense_p2p)     # a skipped message must not go peer-to-peer either
+                if skip_tail:
+                    dp.tail_p2p = None
+                if skip_dense:
+                    dp.dense_p2p = None
                 for _ in range(20):
                     step()
                 barrier()
@@ -171,7 +203,7 @@ def main():
                 barrier()
                 ms = torch.tensor([(time.perf_counter() - t1) * 1e3 / n], dtype=torch.float64, device=dev)
                 torch.distributed.all_reduce(ms, op=torch.distributed.ReduceOp.MAX)
-                dp._allreduce, dp.tail_p2p = real, p2p_real
+                dp._allreduce, (dp.tail_p2p, dp.dense_p2p) = real, p2p_real
                 return round(float(ms.item()), 4)
 
             if tail_p2p is not None:
@@ -210,15 +242,16 @@ def main():
             "config": {"model": spec.name, "global_batch": global_batch, "per_gpu_batch": B, "seq_len": None,
                        "parallelism": f"dp{world}" + ("(forced dp schedule)" if args.force_dp and world == 1 else "") + ("(rehearsal: gloo, one GPU)" if args.rehearse_one_gpu else ""), "optimizer": args.optimizer, "keep_prob": args.keep_prob,
                        "graph": bool(use_graph),
-                       **({"tail_allreduce": tail_how} if dp_path else {})},
+                       **({"tail_allreduce": tail_how, "dense_allreduce": dense_how} if dp_path else {})},
             "model_tflops": round(value * fb / 1e12, 2),
             "final_loss": round(loss, 4),
             **({"comm_diag": comm_diag} if comm_diag is not None else {}),
         }))
     if dp_path:
-        if tail_p2p is not None:
-            barrier()
-            tail_p2p.close()
+        barrier()
+        for p2p in (tail_p2p, dense_p2p):
+            if p2p is not None:
+                p2p.close()
         torch.distributed.destroy_process_group()
 
 

@@ -117,6 +117,24 @@ class P2PAllReduce:
         dist.all_reduce(vote, op=dist.ReduceOp.MIN, group=self.group)
         return bool(vote.item())
 
+    def latency_us(self, n: int, iters: int = 20, warmup: int = 5) -> float:
+        """Collective: mean stand-alone time of one all-reduce of n elements, max over ranks."""
+        import time
+        x = torch.zeros(n, device=self.device)
+        for _ in range(warmup):
+            self.allreduce(x)
+        torch.cuda.synchronize(self.device)
+        dist.barrier(group=self.group)
+        t0 = time.perf_counter()
+        for _ in range(iters):
+            self.allreduce(x)
+        torch.cuda.synchronize(self.device)
+        us = torch.tensor([(time.perf_counter() - t0) * 1e6 / iters], dtype=torch.float64)
+        if dist.get_backend(self.group) != "gloo":
+            us = us.to(self.device)
+        dist.all_reduce(us, op=dist.ReduceOp.MAX, group=self.group)
+        return float(us.item())
+
     def close(self):
         for p in self._mapped:
             self.lib.dtf_p2p_unmap(p)

@@ -70,7 +70,7 @@ class SyncDataParallel:
     DENSE_SLOT, TAIL_SLOT = 3, 4   # per-range Adam step counters in the device state
 
     def __init__(self, engine: HipEngine, bucket_mb: float = 64.0, group=None, tail_group=None,
-                 defer_dense_update: bool = True, tail_p2p=None):
+                 defer_dense_update: bool = True, tail_p2p=None, dense_p2p=None):
         self.eng = engine
         self.group = group
         self.tail_group = tail_group if tail_group is not None else group
@@ -84,6 +84,8 @@ class SyncDataParallel:
         # tail_p2p (parallel/p2p.py): the tail goes through the one-shot peer-to-peer kernel instead of RCCL, also on
         # the compute stream.
         self.tail_p2p = tail_p2p
+        # dense_p2p: the 12.8 MB message through the two-shot peer-to-peer kernel (on the comm stream, like RCCL's)
+        self.dense_p2p = dense_p2p
         self.tail_stream = None if (tail_group is not None or tail_p2p is not None) else self.comm_stream
         self.defer = defer_dense_update
         lay = engine.layout
@@ -122,9 +124,12 @@ class SyncDataParallel:
         if tr: tr.push("dp_phase1: fwd + fc1 wgrad")
         check(lib.dtf_engine_dp_phase1(d, int(self._have_pending_dense), cur, comm), "dp_phase1")
         if tr: tr.pop(); tr.push("allreduce dense (enqueue)")
-        with torch.cuda.stream(self.comm_stream):
-            for lo, hi in self.dense_buckets:
-                self._allreduce(lo, hi, self.group)
+        if self.dense_p2p is not None:
+            self.dense_p2p.allreduce(eng.grads[0:self.n_dense], comm)
+        else:
+            with torch.cuda.stream(self.comm_stream):
+                for lo, hi in self.dense_buckets:
+                    self._allreduce(lo, hi, self.group)
         if tr: tr.pop(); tr.push("dp_phase2: conv backward")
         check(lib.dtf_engine_dp_phase2(d, self.n_dense, self.DENSE_SLOT, cur, comm, tail), "dp_phase2")
         if tr: tr.pop(); tr.push("allreduce tail (enqueue)")

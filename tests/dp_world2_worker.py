@@ -28,11 +28,13 @@ def engine(seed):
 
 eng = engine(1000 + rank)
 eng.init_params(seed=7 + rank)            # rank 1 starts from other weights: the broadcast has to fix that
-tail_p2p = None
-if tail == "p2p":     # the tail message through the one-shot peer-to-peer kernel instead of the process group
+tail_p2p = dense_p2p = None
+if tail == "p2p":     # both messages through the peer-to-peer kernels instead of the process group
     from distributed_tensorflow_amd.parallel.p2p import P2PAllReduce
-    tail_p2p = P2PAllReduce(eng.layout.total - eng.layout.segment("wd1", "wd1")[1], eng.device)
-dp = SyncDataParallel(eng, tail_group=dist.new_group(), tail_p2p=tail_p2p)
+    n_dense = eng.layout.segment("wd1", "wd1")[1]
+    tail_p2p = P2PAllReduce(eng.layout.total - n_dense, eng.device)
+    dense_p2p = P2PAllReduce(n_dense, eng.device, two_shot=True)
+dp = SyncDataParallel(eng, tail_group=dist.new_group(), tail_p2p=tail_p2p, dense_p2p=dense_p2p)
 dp.broadcast_parameters()
 
 refs = [engine(1000 + q) for q in (0, 1)]
@@ -67,8 +69,9 @@ both = [torch.empty_like(eng.params) for _ in range(2)]
 dist.all_gather(both, eng.params)
 assert torch.equal(both[0], both[1]), "ranks diverged"
 if tail_p2p is not None:
-    assert tail_p2p.status() == 0
+    assert tail_p2p.status() == 0 and dense_p2p.status() == 0
     dist.barrier()
     tail_p2p.close()
+    dense_p2p.close()
 print(f"DPW2 rank {rank} ok: max |dp - replay| = {err:.3g}, losses {losses[0][0]:.4f} -> {losses[-1][0]:.4f}", flush=True)
 comm.shutdown()
