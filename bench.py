@@ -151,6 +151,26 @@ def main():
     for _ in range(args.warmup):
         step()
     barrier()
+    if tail_p2p is not None or dense_p2p is not None:
+        # Last line of defence before the clock starts: a peer-to-peer wait that timed out during the warm-up steps
+        # (on any rank) sends both messages back to RCCL, and the warm-up is repeated on that path.
+        if os.environ.get("DTF_BENCH_FAKE_P2P_TIMEOUT") and rank == world - 1 and tail_p2p is not None:
+            tail_p2p._status.fill_(1)          # test hook for this fallback (tests/test_distributed_gpu.py)
+        bad = torch.tensor([sum(p.status() for p in (tail_p2p, dense_p2p) if p is not None)], dtype=torch.int32)
+        if torch.distributed.get_backend() != "gloo":
+            bad = bad.cuda()
+        torch.distributed.all_reduce(bad, op=torch.distributed.ReduceOp.MAX)
+        if int(bad.item()):
+            dp.tail_p2p = dp.dense_p2p = None
+            for p in (tail_p2p, dense_p2p):
+                if p is not None:
+                    p.close()
+            tail_p2p = dense_p2p = None
+            tail_how = dense_how = "rccl (p2p wait timed out during warm-up)"
+            dp.broadcast_parameters()          # the ranks may have drifted apart on the bad sums
+            for _ in range(args.warmup):
+                step()
+            barrier()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()

@@ -77,13 +77,13 @@ def test_overlapped_dp_schedule_world2_over_gloo(gpu_lib, optimizer, tail):
         assert rc == 0 and f"DPW2 rank {r} ok" in o, o[-3000:]
 
 
-def _bench(args, launcher=()):
+def _bench(args, launcher=(), env=None):
     import json
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     r = subprocess.run([sys.executable, *launcher, os.path.join(root, "bench.py"), *args], capture_output=True,
-                       text=True, cwd=root, timeout=150)
+                       text=True, cwd=root, timeout=150, env=dict(os.environ, **(env or {})))
     assert r.returncode == 0, (r.stdout + r.stderr)[-3000:]
     lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
     assert len(lines) == 1, r.stdout          # the contract: ONE JSON line, from rank 0
@@ -103,7 +103,8 @@ def test_bench_contract_single_gpu(gpu_lib):
     assert d["value"] > 1e6                   # two orders of magnitude below that means a fallback path ran
 
 
-def test_bench_torchrun_launch_rehearsal_world2(gpu_lib):
+@pytest.mark.parametrize("fake_timeout", [False, True])
+def test_bench_torchrun_launch_rehearsal_world2(gpu_lib, fake_timeout):
     """The driver's N>1 command line (torch.distributed.run, one rank per GPU) rehearsed with both ranks on the
     one GPU over gloo: process-group bring-up from the torchrun environment, second communicator, the
     data-parallel step, max-over-ranks timing, comm_diag, one JSON line from rank 0."""
@@ -114,8 +115,13 @@ def test_bench_torchrun_launch_rehearsal_world2(gpu_lib):
     s.close()
     d = _bench(["--gpus", "2", "--steps", "10", "--warmup", "3", "--rehearse_one_gpu"],
                launcher=("-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
-                         "127.0.0.1", "--master-port", str(port)))
+                         "127.0.0.1", "--master-port", str(port)),
+               env={"DTF_BENCH_FAKE_P2P_TIMEOUT": "1"} if fake_timeout else None)
     assert all(k in d for k in CONTRACT)
+    if fake_timeout:     # one rank reports a timed-out peer-to-peer wait after the warm-up: everybody back to the process group
+        assert d["config"]["tail_allreduce"] == d["config"]["dense_allreduce"] == "rccl (p2p wait timed out during warm-up)"
+    else:
+        assert d["config"]["tail_allreduce"] == "p2p one-shot" and d["config"]["dense_allreduce"].startswith("p2p two-shot")
     assert d["n_gpus"] == 2 and d["config"]["global_batch"] == 2048 and d["scaling"] == "weak"
     assert d["config"]["parallelism"].startswith("dp2")
     diag = d["comm_diag"]
