@@ -105,14 +105,53 @@ class SyncAllReduce:
 
     name = "sync"
 
-    def __init__(self, backend: Backend, task: TaskInfo, worker_group, chief_rank: int, tail_group=None):
+    def __init__(self, backend: Backend, task: TaskInfo, worker_group, chief_rank: int, tail_group=None,
+                 p2p: bool = False, log=None):
         self.b, self.task, self.group, self.chief_rank = backend, task, worker_group, chief_rank
         self.world = task.num_workers
         self.step_count = backend.get_global_step()
         self._dp = None
-        if backend.name == "hip" and dist.get_backend(worker_group) != "gloo":
+        self._p2p = []
+        # The overlapped schedule (parallel/sync_dp.py) needs collectives that run on streams: RCCL, or the
+        # peer-to-peer kernels (--p2p_allreduce; these also work between tasks that share one GPU over gloo).
+        if backend.name == "hip" and (dist.get_backend(worker_group) != "gloo" or p2p):
             from .sync_dp import SyncDataParallel
-            self._dp = SyncDataParallel(backend.engine, group=worker_group, tail_group=tail_group)
+            tail_p2p = dense_p2p = None
+            if p2p:
+                tail_p2p, dense_p2p = self._bring_up_p2p(backend.engine, worker_group, log or (lambda *a: None))
+            self._dp = SyncDataParallel(backend.engine, group=worker_group, tail_group=tail_group, tail_p2p=tail_p2p,
+                                        dense_p2p=dense_p2p)
+
+    def _bring_up_p2p(self, eng, group, log):
+        """Both messages through csrc/kernels/p2p.hip if the kernels reproduce the process group's sums here
+        (collective decisions: every worker ends up with the same pair)."""
+        from .p2p import P2PAllReduce
+        n_dense = eng.layout.segment("wd1", "wd1")[1]
+        out = []
+        for name, n, two_shot in (("tail", eng.layout.total - n_dense, False), ("dense", n_dense, True)):
+            obj = None
+            try:
+                if n % (4 * self.world if two_shot else 4) == 0:
+                    # generous bound: the chief's checkpoint writes and evaluations stall its peers inside the kernel
+                    obj = P2PAllReduce(n, eng.device, group=group, timeout_s=60.0, two_shot=two_shot)
+                    if not obj.self_check(n, iters=4):
+                        obj.close()
+                        obj = None
+            except RuntimeError as e:      # unanimous (see P2PAllReduce.__init__)
+                log(f"p2p all-reduce ({name}) unavailable: {e}")
+                obj = None
+            log(f"worker/{self.task.task_index}: {name} all-reduce: {'peer-to-peer kernel' if obj else 'process group'}")
+            if obj is not None:
+                self._p2p.append(obj)
+            out.append(obj)
+        return out
+
+    def check_health(self):
+        """Called where the trainer synchronises anyway (display steps, end): a timed-out peer-to-peer wait means
+        wrong sums, which must end the run rather than train on."""
+        for obj in self._p2p:
+            if obj.status():
+                raise RuntimeError("peer-to-peer all-reduce: a wait for a peer timed out (lost or stalled worker)")
 
     def broadcast_initial(self):
         broadcast_state(self.b, self.chief_rank)
@@ -131,6 +170,7 @@ class SyncAllReduce:
     def finish(self):
         if self._dp is not None:
             self._dp.flush()
+        self.check_health()
 
 
 def broadcast_state(backend: Backend, src_rank: int, group=None):

@@ -139,7 +139,8 @@ def run(F, log=print) -> dict:
     if mode == "local":
         strategy = LocalStrategy(backend)
     elif mode == "sync":
-        strategy = SyncAllReduce(backend, task, worker_group, chief_rank, tail_group=tail_group)
+        strategy = SyncAllReduce(backend, task, worker_group, chief_rank, tail_group=tail_group,
+                                 p2p=bool(getattr(F, "p2p_allreduce", False)), log=log)
     elif async_impl == "p2p":
         strategy = AsyncP2PWorker(backend, task, chief_rank)
     else:
@@ -174,6 +175,9 @@ def run(F, log=print) -> dict:
                 log(format_display_line(task.job_name, task.task_index, prev, loss, acc))
                 lap = timer.lap()
                 metrics.log(step=prev, loss=loss, accuracy=acc, role=result["role"], **lap)
+                health = getattr(strategy, "check_health", None)
+                if health is not None:
+                    health()
             if eval_every > 0 and task.is_chief and step // eval_every != prev // eval_every \
                     and not (F.eval and step >= F.training_iter):      # the final evaluation covers the last step
                 backend.synchronize()    # a deferred dense update (parallel/sync_dp.py) may still be on the comm stream

@@ -54,6 +54,8 @@ flags.DEFINE_float("comm_timeout", 1800.0, "collective timeout in seconds (failu
 flags.DEFINE_string("metrics_file", "", "append JSONL metrics here")
 flags.DEFINE_string("comm_backend", "auto", "auto (gloo for the cpu backend, RCCL for GPU tensors) | nccl | gloo "
                     "(gloo also carries GPU tensors, staged through the host: several tasks sharing ONE GPU, which RCCL refuses)")
+flags.DEFINE_boolean("p2p_allreduce", False, "sync mode, hip backend: both gradient messages through the peer-to-peer "
+                     "push kernels (one-shot tail, two-shot dense) instead of RCCL, after a self-check")
 flags.DEFINE_boolean("trace", False, "roctx ranges around steps/collectives/checkpoints (rocprofv3 --marker-trace)")
 flags.DEFINE_integer("fault_inject_step", -1, "test hook: crash this worker after N local steps")
 flags.DEFINE_integer("fault_inject_task", -1, "test hook: which worker task crashes (-1 = any)")

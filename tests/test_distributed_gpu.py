@@ -21,11 +21,16 @@ def _ok(out):
         assert rc == 0, (key, o[-3000:])
 
 
-def test_sync_1ps_2workers_hip_backend_over_gloo(gpu_lib, tmp_path):
+@pytest.mark.parametrize("p2p", [False, True])
+def test_sync_1ps_2workers_hip_backend_over_gloo(gpu_lib, tmp_path, p2p):
     logdir = str(tmp_path / "logs")
-    out = launch(1, 2, ["--mode=sync", "--batch_size=128", "--steps=24"] + COMMON, logdir, backend="hip")
+    out = launch(1, 2, ["--mode=sync", "--batch_size=128", "--steps=24"] + (["--p2p_allreduce"] if p2p else []) + COMMON,
+                 logdir, backend="hip")
     _ok(out)
     w0, w1 = out[("worker", 0)][1], out[("worker", 1)][1]
+    if p2p:     # the overlapped schedule with both messages through the peer-to-peer kernels
+        for o in (w0, w1):
+            assert "tail all-reduce: peer-to-peer kernel" in o and "dense all-reduce: peer-to-peer kernel" in o, o
     for o in (w0, w1):
         assert [int(m.group(2)) for m in DISPLAY.finditer(o)] == [0, 4, 8, 12, 16, 20], o
     l0 = [float(m.group(3)) for m in DISPLAY.finditer(w0)]
