@@ -84,6 +84,7 @@ def main():
     use_graph = False
     tail_p2p, tail_how = None, "n/a"
     dense_p2p, dense_how = None, "n/a"
+    p2p_blocks_us = None
     if dp_path:
         try:   # second communicator: the small tail all-reduce must not queue behind the 12.8 MB one inside RCCL
             tail_group = torch.distributed.new_group()
@@ -124,10 +125,18 @@ def main():
             if cand is None:
                 dense_how = why
             else:
-                t_p2p = cand.latency_us(n_dense_arena)
+                # workgroups per launch: the fewest that come within 10 % of the best stand-alone time (the collective
+                # overlaps with backward kernels that want the CUs); latencies are max-over-ranks, so all ranks agree
+                times = {}
+                for nb in (32, 64, 128, 256):
+                    cand.blocks = nb
+                    times[nb] = cand.latency_us(n_dense_arena, iters=10, warmup=3)
+                cand.blocks = min(nb for nb, t in times.items() if t <= 1.10 * min(times.values()))
+                t_p2p = times[cand.blocks]
+                p2p_blocks_us = {str(k): round(v, 1) for k, v in times.items()}
                 t_pg = comm.allreduce_latency_us(n_dense_arena, device=dev)
                 if t_p2p < 0.85 * t_pg:
-                    dense_p2p, dense_how = cand, f"p2p two-shot ({t_p2p:.0f} us vs rccl {t_pg:.0f} us stand-alone)"
+                    dense_p2p, dense_how = cand, f"p2p two-shot, {cand.blocks} workgroups ({t_p2p:.0f} us vs rccl {t_pg:.0f} us stand-alone)"
                 else:
                     cand.close()
                     dense_how = f"rccl ({t_pg:.0f} us vs p2p two-shot {t_p2p:.0f} us stand-alone)"
@@ -237,6 +246,8 @@ def main():
                 torch.cuda.synchronize()
                 comm_diag["tail_p2p_us"] = round((time.perf_counter() - t1) * 1e4, 1)
                 comm_diag["tail_p2p_timeouts"] = tail_p2p.status()
+            if p2p_blocks_us is not None:
+                comm_diag["dense_p2p_us_by_workgroups"] = p2p_blocks_us
             comm_diag["step_ms_no_allreduce"] = timed(True, True)
             comm_diag["step_ms_dense_allreduce_only"] = timed(False, True)
             comm_diag["step_ms_tail_allreduce_only"] = timed(True, False)

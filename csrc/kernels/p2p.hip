@@ -96,8 +96,10 @@ __global__ __launch_bounds__(kP2PThreads) void p2p_allreduce_oneshot(P2PArgs a) 
 // is assembled in uncached staging and copied into the (cached) gradient arena by its owner only, so no peer
 // ever stores into memory that the local L2 may hold.  Same parity argument and bounded waits as above.
 //   stageA [2][world][csz_max] | stageB [2][n_max] | flagA [2][world][kBlocks2] | flagB [2][world][kBlocks2]
+// The block count is a launch parameter (<= kBlocks2, identical on all ranks): more blocks drive the links and the
+// uncached staging harder but take CUs from the backward kernels this collective overlaps with.
 // ---------------------------------------------------------------------------------------------
-constexpr int kP2PBlocks2 = 64;
+constexpr int kP2PBlocks2 = 256;   // flag slots per (parity, rank): the launch may use any block count up to this
 constexpr int kP2PThreads2 = 512;
 
 struct P2P2Args {
@@ -130,7 +132,8 @@ __global__ __launch_bounds__(kP2PThreads2) void p2p_allreduce_twoshot(P2P2Args a
   const int par = a.seq & 1u;
   const int csz = a.n / W, csz_max = a.n_max / W;       // n, n_max: multiples of 4 * world
   const int c4 = csz / 4;
-  const int per = (c4 + kP2PBlocks2 - 1) / kP2PBlocks2;
+  const int nblk = gridDim.x;                            // the same on every rank (host contract)
+  const int per = (c4 + nblk - 1) / nblk;
   const int lo4 = b * per, hi4 = min(c4, lo4 + per);
   auto stageA = [&](int r) { return reinterpret_cast<float*>(a.base[r]); };
   auto stageB = [&](int r) { return reinterpret_cast<float*>(a.base[r]) + 2 * (size_t)a.n_max; };
@@ -253,7 +256,8 @@ long dtf_p2p2_bytes(int world, long n_max) {
 
 // Two-shot variant; n and n_max must be multiples of 4 * world.
 int dtf_p2p2_allreduce(void* data, void* const* bases, int world, int rank, long n, long n_max, unsigned seq,
-                       int* status, double timeout_s, hipStream_t s) {
+                       int* status, double timeout_s, int blocks, hipStream_t s) {
+  if (blocks < 1 || blocks > dtf::kP2PBlocks2) return -2;
   if (world < 1 || world > dtf::kP2PMaxWorld || rank < 0 || rank >= world) return -2;
   if (n < 0 || n > n_max || n % (4 * world) || n_max % (4 * world) || seq == 0) return -2;
   if ((reinterpret_cast<uintptr_t>(data) & 15) != 0) return -3;
@@ -267,7 +271,7 @@ int dtf_p2p2_allreduce(void* data, void* const* bases, int world, int rank, long
   a.n_max = (int)n_max;
   a.seq = seq;
   a.timeout_ticks = (long long)(timeout_s * 1e8);
-  hipLaunchKernelGGL(dtf::p2p_allreduce_twoshot, dim3(dtf::kP2PBlocks2), dim3(dtf::kP2PThreads2), 0, s, a);
+  hipLaunchKernelGGL(dtf::p2p_allreduce_twoshot, dim3(blocks), dim3(dtf::kP2PThreads2), 0, s, a);
   return (int)hipGetLastError();
 }
 

@@ -79,7 +79,7 @@ _SIGS = {
                           c_void_p],
     "dtf_p2p2_bytes": [c_int, c_long],
     "dtf_p2p2_allreduce": [c_void_p, ctypes.POINTER(c_void_p), c_int, c_int, c_long, c_long, c_uint, c_void_p, c_double,
-                           c_void_p],
+                           c_int, c_void_p],
     "dtf_sample_indices": [c_void_p, c_void_p, c_int, c_uint, c_uint, c_uint, c_int, c_void_p],
     "dtf_gen_synthetic": [c_void_p, c_void_p, c_long, c_uint, c_void_p],
     "dtf_init_truncated_normal": [c_void_p, c_long, c_float, c_uint64, c_uint64, c_void_p],

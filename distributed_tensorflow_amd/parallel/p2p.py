@@ -40,7 +40,7 @@ class P2PAllReduce:
         self.quantum = 4 * self.world if self.two_shot else 4      # vector lengths must be multiples of this
         self.n_max = -(-int(n_max) // self.quantum) * self.quantum
         self._bytes_fn = self.lib.dtf_p2p2_bytes if self.two_shot else self.lib.dtf_p2p_bytes
-        self._launch = self.lib.dtf_p2p2_allreduce if self.two_shot else self.lib.dtf_p2p_allreduce
+        self.blocks = 64            # two-shot only: workgroups per launch (<= 256), the same on every rank
         self.timeout_s = float(timeout_s)
         self.seq = 0
         self._status = torch.zeros(1, dtype=torch.int32, device=self.device)
@@ -87,8 +87,13 @@ class P2PAllReduce:
             raise ValueError(f"P2PAllReduce: fp32, contiguous, a multiple of {self.quantum} and at most n_max elements")
         self.seq += 1
         s = torch.cuda.current_stream(self.device).cuda_stream if stream is None else stream
-        native.check(self._launch(t.data_ptr(), self._bases, self.world, self.rank, n, self.n_max, self.seq,
-                                                self._status.data_ptr(), self.timeout_s, s), "p2p allreduce")
+        if self.two_shot:
+            rc = self.lib.dtf_p2p2_allreduce(t.data_ptr(), self._bases, self.world, self.rank, n, self.n_max, self.seq,
+                                             self._status.data_ptr(), self.timeout_s, self.blocks, s)
+        else:
+            rc = self.lib.dtf_p2p_allreduce(t.data_ptr(), self._bases, self.world, self.rank, n, self.n_max, self.seq,
+                                            self._status.data_ptr(), self.timeout_s, s)
+        native.check(rc, "p2p allreduce")
 
     def status(self) -> int:
         """0 = fine; 1 = some wait timed out since the last call (synchronises the device)."""
