@@ -63,7 +63,7 @@ def main():
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run for N>1")
     if args.rehearse_one_gpu:
         import faulthandler
-        faulthandler.dump_traceback_later(45, exit=True)   # a rehearsal that stalls says where
+        faulthandler.dump_traceback_later(120, exit=True)   # a rehearsal that stalls says where
         local_rank = 0
     torch.cuda.set_device(local_rank)
     dp_path = world > 1 or args.force_dp
