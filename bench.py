@@ -171,6 +171,7 @@ def main():
         torch.distributed.all_reduce(bad, op=torch.distributed.ReduceOp.MAX)
         if int(bad.item()):
             dp.tail_p2p = dp.dense_p2p = None
+            dp.fuse_tail = False
             for p in (tail_p2p, dense_p2p):
                 if p is not None:
                     p.close()
@@ -218,9 +219,9 @@ def main():
                     if not (skip_tail if is_tail else skip_dense):
                         real(lo, hi, group)
                 dp._allreduce = ar
-                p2p_real = (dp.tail_p2p, dp.dense_p2p)     # a skipped message must not go peer-to-peer either
+                p2p_real = (dp.tail_p2p, dp.dense_p2p, dp.fuse_tail)     # a skipped message must not go peer-to-peer either
                 if skip_tail:
-                    dp.tail_p2p = None
+                    dp.tail_p2p, dp.fuse_tail = None, False
                 if skip_dense:
                     dp.dense_p2p = None
                 for _ in range(20):
@@ -232,7 +233,7 @@ def main():
                 barrier()
                 ms = torch.tensor([(time.perf_counter() - t1) * 1e3 / n], dtype=torch.float64, device=dev)
                 torch.distributed.all_reduce(ms, op=torch.distributed.ReduceOp.MAX)
-                dp._allreduce, (dp.tail_p2p, dp.dense_p2p) = real, p2p_real
+                dp._allreduce, (dp.tail_p2p, dp.dense_p2p, dp.fuse_tail) = real, p2p_real
                 return round(float(ms.item()), 4)
 
             if tail_p2p is not None:

@@ -188,8 +188,10 @@ __global__ __launch_bounds__(kP2PThreads2) void p2p_allreduce_twoshot(P2P2Args a
 extern "C" {
 
 // bytes needed by one rank for vectors of up to n_max floats (n_max rounded up to a multiple of 4 by the caller)
+// (the flag area is sized for the fused data-parallel tail of optim.hip, 1024 workgroups; the one-shot kernel here
+// uses the first kP2PBlocks slots per (parity, rank) with its own stride -- flags only ever match the current seq)
 long dtf_p2p_bytes(int world, long n_max) {
-  return 2L * world * n_max * 4 + 2L * world * dtf::kP2PBlocks * 4;
+  return 2L * world * n_max * 4 + 2L * world * 1024 * 4;
 }
 
 int dtf_p2p_alloc(long bytes, void** out) {

@@ -303,9 +303,10 @@ int dtf_engine_dp_phase1(const DtfEngineDesc* e, int wait_dense_updated, hipStre
   return (int)hipStreamWaitEvent(comm, e->ev_dense_ready, 0);
 }
 
-int dtf_engine_dp_phase2(const DtfEngineDesc* e, long dense_hi, int dense_adam_slot, hipStream_t s, hipStream_t comm,
-                         hipStream_t tail) {
-  DTF_TRY(backward_conv_impl(e, e->ds_images, e->idx, 1, 2, 1, s));
+// reduce_tail == 0: the head/conv slabs are left unreduced for dtf_engine_dp_phase3_p2p (which sums them itself)
+int dtf_engine_dp_phase2(const DtfEngineDesc* e, long dense_hi, int dense_adam_slot, int reduce_tail, hipStream_t s,
+                         hipStream_t comm, hipStream_t tail) {
+  DTF_TRY(backward_conv_impl(e, e->ds_images, e->idx, 1, reduce_tail ? 2 : 0, 1, s));
   // the dense update overwrites the bf16 wd1 that fc1 dgrad reads: order it after that kernel
   if (!(DTF_EXP_DP & 1)) HIP_TRY(hipStreamWaitEvent(comm, e->ev_dgrad, 0));
   if (!(DTF_EXP_DP & 2)) DTF_TRY(dtf_engine_update_range(e, 0, dense_hi, 0, 0, 0, dense_adam_slot, (DTF_EXP_DP & 4) ? s : comm));
@@ -346,6 +347,24 @@ int dtf_engine_dp_phase3(const DtfEngineDesc* e, long dense_hi, int tail_adam_sl
     DTF_TRY(dtf_engine_update_range(e, dense_hi, e->n_total, 1, 1, step_inc, tail_adam_slot, s));
     DTF_TRY(dtf_conv2_pack_weights(bf16at(e->shadow, e->off_wc2), e->wc2T, e->c1, e->c2, s));
   }
+  if (wait_dense) HIP_TRY(hipStreamWaitEvent(s, e->ev_dense_updated, 0));
+  return 0;
+}
+
+// phase 3 with the tail all-reduce INSIDE the fused tail kernel (optim.hip: fused_reduce_sgd<.., P2P>): slab sums ->
+// peer-to-peer exchange -> update + shadows + packs + state advance, one launch on the compute stream; replaces
+// {reduce_segments, tail collective, fused update}.  Needs phase 2 with reduce_tail == 0.
+int dtf_engine_dp_phase3_p2p(const DtfEngineDesc* e, int tail_adam_slot, long step_inc, int wait_dense, hipStream_t s,
+                             void* const* bases, int world, int rank, long n_max, unsigned seq, int* status,
+                             double timeout_s) {
+  const void* part[3] = {e->head_part, e->c2_part, e->c1_part};
+  int G[3] = {e->head_ks, e->c2_g, e->c1_g}, n[3] = {(int)e->head_stride, (int)e->c2_stride, (int)e->c1_stride};
+  long st[3] = {e->head_stride, e->c2_stride, e->c1_stride};
+  long off[3] = {e->off_out_w, e->off_wc2, e->off_wc1};
+  DTF_TRY(dtf_fused_reduce_p2p(e->optimizer != 0, 3, part, G, n, st, off, e->params, e->grads, e->adam_m, e->adam_v,
+                               e->shadow, e->hyper, e->wc2T, e->off_wc2, e->c1, e->c2, e->out_wT, e->off_out_w, e->hidden,
+                               e->state, tail_adam_slot, e->B, step_inc, 1, bases, world, rank, n_max, seq, status,
+                               timeout_s, e->off_out_w, s));
   if (wait_dense) HIP_TRY(hipStreamWaitEvent(s, e->ev_dense_updated, 0));
   return 0;
 }

@@ -29,12 +29,13 @@ def engine(seed):
 eng = engine(1000 + rank)
 eng.init_params(seed=7 + rank)            # rank 1 starts from other weights: the broadcast has to fix that
 tail_p2p = dense_p2p = None
-if tail == "p2p":     # both messages through the peer-to-peer kernels instead of the process group
+if tail.startswith("p2p"):     # both messages through the peer-to-peer kernels instead of the process group
     from distributed_tensorflow_amd.parallel.p2p import P2PAllReduce
     n_dense = eng.layout.segment("wd1", "wd1")[1]
     tail_p2p = P2PAllReduce(eng.layout.total - n_dense, eng.device)
     dense_p2p = P2PAllReduce(n_dense, eng.device, two_shot=True)
-dp = SyncDataParallel(eng, tail_group=dist.new_group(), tail_p2p=tail_p2p, dense_p2p=dense_p2p)
+dp = SyncDataParallel(eng, tail_group=dist.new_group(), tail_p2p=tail_p2p, dense_p2p=dense_p2p,
+                      fuse_tail_p2p=(tail == "p2p-fused"))
 dp.broadcast_parameters()
 
 refs = [engine(1000 + q) for q in (0, 1)]

@@ -53,7 +53,8 @@ def test_async_parameter_server_hip_backend_over_gloo(gpu_lib, tmp_path, impl):
     assert "checkpoint" in files and any(f.endswith(".index") for f in files)
 
 
-@pytest.mark.parametrize("optimizer,tail", [("sgd", "pg"), ("adam", "pg"), ("sgd", "p2p")])
+@pytest.mark.parametrize("optimizer,tail", [("sgd", "pg"), ("adam", "pg"), ("sgd", "p2p"), ("sgd", "p2p-fused"),
+                                            ("adam", "p2p-fused")])
 def test_overlapped_dp_schedule_world2_over_gloo(gpu_lib, optimizer, tail):
     """parallel/sync_dp.py (the schedule bench.py runs on N GPUs: deferred dense update, two communicators,
     1/world scaling in the optimizer kernels) with TWO ranks, each feeding different batches: against a replay
@@ -126,7 +127,7 @@ def test_bench_torchrun_launch_rehearsal_world2(gpu_lib, fake_timeout):
     if fake_timeout:     # one rank reports a timed-out peer-to-peer wait after the warm-up: everybody back to the process group
         assert d["config"]["tail_allreduce"] == d["config"]["dense_allreduce"] == "rccl (p2p wait timed out during warm-up)"
     else:
-        assert d["config"]["tail_allreduce"] == "p2p one-shot" and d["config"]["dense_allreduce"].startswith("p2p two-shot")
+        assert d["config"]["tail_allreduce"].startswith("p2p one-shot") and d["config"]["dense_allreduce"].startswith("p2p two-shot")
     assert d["n_gpus"] == 2 and d["config"]["global_batch"] == 2048 and d["scaling"] == "weak"
     assert d["config"]["parallelism"].startswith("dp2")
     diag = d["comm_diag"]
