@@ -65,6 +65,9 @@ def main():
         import faulthandler
         faulthandler.dump_traceback_later(120, exit=True)   # a rehearsal that stalls says where
         local_rank = 0
+    ndev = torch.cuda.device_count()
+    if ndev and local_rank >= ndev:      # launcher restricted this rank's visible devices (e.g. one GPU per process)
+        local_rank %= ndev
     torch.cuda.set_device(local_rank)
     dp_path = world > 1 or args.force_dp
     if dp_path:
