@@ -120,7 +120,7 @@ def main():
 
         if not args.no_p2p_tail and world <= 8:
             tail_p2p, why = bring_up(n_tail_arena, False)
-            tail_how = "p2p one-shot" if tail_p2p is not None else why
+            tail_how = "p2p one-shot + update in one launch" if tail_p2p is not None else why
         # The dense message (12.8 MB, hidden under backward if it is fast enough) goes peer-to-peer only if the
         # two-shot kernel is correct here AND clearly faster than RCCL stand-alone on this node.
         if not args.no_p2p_dense and world > 1 and world <= 8:
@@ -224,7 +224,7 @@ def main():
                 dp._allreduce = ar
                 p2p_real = (dp.tail_p2p, dp.dense_p2p, dp.fuse_tail)     # a skipped message must not go peer-to-peer either
                 if skip_tail:
-                    dp.tail_p2p, dp.fuse_tail = None, False
+                    dp.tail_p2p, dp.fuse_tail = None, False      # -> process-group path, where ar() drops the message
                 if skip_dense:
                     dp.dense_p2p = None
                 for _ in range(20):

@@ -221,6 +221,43 @@ __device__ __forceinline__ void adam4(f32x4& wv, const f32x4& gv, f32x4& mv, f32
   }
 }
 
+// Update of the four tail elements at arena offset e0 with the (final) gradient gs: gradient arena, optimizer,
+// master weight, bf16 shadow, and the derived copies (out_wT, the two conv2 packs).  Shared by the fused tails.
+template <bool ADAM>
+__device__ __forceinline__ void tail_update4(const FusedSgdArgs& a, long e0, f32x4 gs, f32x4 wv, float lr, float lr_t,
+                                             float b1, float b2, float eps, float gsc) {
+  *reinterpret_cast<f32x4*>(a.g + e0) = gs;
+  if (ADAM) {
+    f32x4 mv = *reinterpret_cast<const f32x4*>(a.m + e0), vv = *reinterpret_cast<const f32x4*>(a.v + e0);
+    adam4(wv, gs, mv, vv, lr_t, b1, b2, eps, gsc);
+    *reinterpret_cast<f32x4*>(a.m + e0) = mv;
+    *reinterpret_cast<f32x4*>(a.v + e0) = vv;
+  } else {
+#pragma unroll
+    for (int e = 0; e < 4; ++e) wv[e] = fmaf(-lr, gs[e], wv[e]);
+  }
+  *reinterpret_cast<f32x4*>(a.w + e0) = wv;
+  store_bf16x4(a.shadow + e0, wv[0], wv[1], wv[2], wv[3]);
+  const long ro = e0 - a.out_w_off;
+  if (a.out_wT && ro >= 0 && ro < 10L * a.H) {
+#pragma unroll
+    for (int e = 0; e < 4; ++e) a.out_wT[(size_t)((ro + e) % 10) * a.H + (ro + e) / 10] = wv[e];
+  }
+  const long r = e0 - a.wc2_off;
+  const long nw = 25L * a.c1 * a.c2;
+  if (a.wc2T && r >= 0 && r < nw) {
+    // HWIO element (tap, ci, co..co+3) -> the two fragment-ordered packs of conv2.hip
+    // (pack_conv2_weights): [fwd pack | dgrad pack]
+    const int tap = (int)(r / (a.c1 * a.c2)), rem = (int)(r % (a.c1 * a.c2));
+    const int ci = rem / a.c2, co = rem % a.c2;
+    const long f0 = (((long)tap * (a.c1 / 32) + ci / 32) * (a.c2 / 16) + co / 16) * 512 + (((ci % 32) / 8) * 16 + co % 16) * 8 + ci % 8;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) a.wc2T[f0 + 8 * e] = (bf16)wv[e];   // co+e -> next lane slot (co % 16 + e <= 15)
+    const long d0 = (((long)tap * (a.c2 / 32) + co / 32) * (a.c1 / 16) + ci / 16) * 512 + (((co % 32) / 8) * 16 + ci % 16) * 8 + co % 8;
+    store_bf16x4(a.wc2T + nw + d0, wv[0], wv[1], wv[2], wv[3]);       // 4 consecutive k of one lane slot
+  }
+}
+
 template <bool ADAM, bool P2P>
 __global__ __launch_bounds__(256) void fused_reduce_sgd(FusedSgdArgs a, TailP2P pp) {
   __shared__ f32x4 red[16][17];
@@ -317,36 +354,7 @@ __global__ __launch_bounds__(256) void fused_reduce_sgd(FusedSgdArgs a, TailP2P 
       }
     }
     if (grp == 0 && i4 * 4 < sg.n) {
-      *reinterpret_cast<f32x4*>(a.g + e0) = gs;
-      if (ADAM) {
-        f32x4 mv = *reinterpret_cast<const f32x4*>(a.m + e0), vv = *reinterpret_cast<const f32x4*>(a.v + e0);
-        adam4(wv, gs, mv, vv, lr_t, b1, b2, eps, gsc);
-        *reinterpret_cast<f32x4*>(a.m + e0) = mv;
-        *reinterpret_cast<f32x4*>(a.v + e0) = vv;
-      } else {
-#pragma unroll
-        for (int e = 0; e < 4; ++e) wv[e] = fmaf(-lr, gs[e], wv[e]);
-      }
-      *reinterpret_cast<f32x4*>(a.w + e0) = wv;
-      store_bf16x4(a.shadow + e0, wv[0], wv[1], wv[2], wv[3]);
-      const long ro = e0 - a.out_w_off;
-      if (a.out_wT && ro >= 0 && ro < 10L * a.H) {
-#pragma unroll
-        for (int e = 0; e < 4; ++e) a.out_wT[(size_t)((ro + e) % 10) * a.H + (ro + e) / 10] = wv[e];
-      }
-      const long r = e0 - a.wc2_off;
-      const long nw = 25L * a.c1 * a.c2;
-      if (a.wc2T && r >= 0 && r < nw) {
-        // HWIO element (tap, ci, co..co+3) -> the two fragment-ordered packs of conv2.hip
-        // (pack_conv2_weights): [fwd pack | dgrad pack]
-        const int tap = (int)(r / (a.c1 * a.c2)), rem = (int)(r % (a.c1 * a.c2));
-        const int ci = rem / a.c2, co = rem % a.c2;
-        const long f0 = (((long)tap * (a.c1 / 32) + ci / 32) * (a.c2 / 16) + co / 16) * 512 + (((ci % 32) / 8) * 16 + co % 16) * 8 + ci % 8;
-#pragma unroll
-        for (int e = 0; e < 4; ++e) a.wc2T[f0 + 8 * e] = (bf16)wv[e];   // co+e -> next lane slot (co % 16 + e <= 15)
-        const long d0 = (((long)tap * (a.c2 / 32) + co / 32) * (a.c1 / 16) + ci / 16) * 512 + (((co % 32) / 8) * 16 + ci % 16) * 8 + co % 8;
-        store_bf16x4(a.wc2T + nw + d0, wv[0], wv[1], wv[2], wv[3]);       // 4 consecutive k of one lane slot
-      }
+      tail_update4<ADAM>(a, e0, gs, wv, lr, lr_t, b1, b2, eps, gsc);
     }
   } else {
     const long nb = gridDim.x - a.reduce_blocks;
@@ -367,6 +375,61 @@ __global__ __launch_bounds__(256) void fused_reduce_sgd(FusedSgdArgs a, TailP2P 
     }
   }
   advance_state(a.adv);   // cursor / global_step / dropout offset: nothing in this kernel reads them
+}
+
+// ---------------------------------------------------------------------------------------------
+// Data-parallel tail, coarse-grained: the already slab-reduced tail of the gradient arena (reduce_segments) makes
+// the one-shot peer-to-peer round trip of p2p.hip in kTailXBlocks fat workgroups (64 system-scope fences instead of
+// one per 64 elements) and the SAME launch applies the update to what it has just summed: the separate update
+// launch of the data-parallel step (fused_reduce_sgd with G = 1) disappears.
+// ---------------------------------------------------------------------------------------------
+constexpr int kTailXBlocks = 64;
+
+template <bool ADAM>
+__global__ __launch_bounds__(256) void p2p_tail_allreduce_update(FusedSgdArgs a, TailP2P pp, int n) {
+  const int tid = threadIdx.x, b = blockIdx.x, W = pp.world;
+  const float lr = a.hyper[0] * a.hyper[4];
+  float lr_t = 0.f, b1 = 0.f, b2 = 0.f, eps = 0.f, gsc = 0.f;
+  if (ADAM) {
+    b1 = a.hyper[1]; b2 = a.hyper[2]; eps = a.hyper[3]; gsc = a.hyper[4];
+    const float t = (float)*a.adam_t;
+    lr_t = a.hyper[0] * sqrtf(1.f - powf(b2, t)) / (1.f - powf(b1, t));
+  }
+  const int par = pp.seq & 1u;
+  const int per = (n / 4 + kTailXBlocks - 1) / kTailXBlocks;
+  const int lo4 = b * per, hi4 = min(n / 4, lo4 + per);
+  const size_t slot = ((size_t)par * W + pp.rank) * pp.n_max;
+  const f32x4* src = reinterpret_cast<const f32x4*>(a.g + pp.tail_off);
+  for (int i = lo4 + tid; i < hi4; i += 256) {
+    const f32x4 v = src[i];
+#pragma unroll 1
+    for (int k = 0; k < W; ++k) reinterpret_cast<f32x4*>(pp.stage[(pp.rank + k) % W] + slot)[i] = v;
+  }
+  __threadfence_system();
+  __syncthreads();
+  if (tid < W) {
+    __hip_atomic_store(pp.flags[tid] + ((size_t)par * W + pp.rank) * kTailFlagSlots + b, pp.seq, __ATOMIC_RELEASE,
+                       __HIP_MEMORY_SCOPE_SYSTEM);
+    const unsigned* f = pp.flags[pp.rank] + ((size_t)par * W + tid) * kTailFlagSlots + b;
+    const long long t0 = wall_clock64();
+    while (__hip_atomic_load(f, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) != pp.seq) {
+      if (wall_clock64() - t0 > pp.timeout_ticks) {
+        *pp.status = 1;
+        break;
+      }
+      __builtin_amdgcn_s_sleep(2);
+    }
+  }
+  __syncthreads();
+  const float* mine = pp.stage[pp.rank] + (size_t)par * W * pp.n_max;
+  for (int i = lo4 + tid; i < hi4; i += 256) {
+    const long e0 = pp.tail_off + 4L * i;
+    const f32x4 wv = *reinterpret_cast<const f32x4*>(a.w + e0);
+    f32x4 gs = reinterpret_cast<const f32x4*>(mine)[i];
+    for (int q = 1; q < W; ++q) gs += reinterpret_cast<const f32x4*>(mine + (size_t)q * pp.n_max)[i];
+    tail_update4<ADAM>(a, e0, gs, wv, lr, lr_t, b1, b2, eps, gsc);
+  }
+  advance_state(a.adv);
 }
 
 }  // namespace dtf
@@ -539,6 +602,59 @@ int dtf_fused_reduce_p2p(int adam, int count, const void** part, const int* G, c
   pp.tail_off = tail_off;
   return fused_tail_launch(adam != 0, m, v, adam_slot, count, part, G, n, stride, seg_off, w, g, shadow, hyper, 0, 0, wc2T,
                            wc2_off, c1, c2, out_wT, out_w_off, H, state, cursor_inc, step_inc, drop_inc, s, &pp);
+}
+
+// Data-parallel tail, coarse-grained (p2p_tail_allreduce_update): g[tail_off, tail_off + n) holds this rank's reduced
+// tail gradient; after the launch it holds the sum over ranks and the update has been applied to those elements.
+int dtf_p2p_tail_update(int adam, void* w, void* g, void* m, void* v, void* shadow, const void* hyper, void* wc2T,
+                        long wc2_off, int c1, int c2, void* out_wT, long out_w_off, int H, void* state, int adam_slot,
+                        long cursor_inc, long step_inc, long drop_inc, void* const* bases, int world, int rank, long n,
+                        long n_max, unsigned seq, int* status, double timeout_s, long tail_off, hipStream_t s) {
+  if (world < 1 || world > 8 || rank < 0 || rank >= world || (n & 3) || (n_max & 3) || n > n_max || seq == 0 ||
+      (tail_off & 3) || (wc2_off & 3))
+    return -2;
+  if (adam && (!m || !v || !state || adam_slot < 3 || adam_slot > 6)) return -3;
+  if (wc2T && ((c1 % 32) || (c2 % 32))) return -3;
+  FusedSgdArgs a;
+  for (int k = 0; k < 3; ++k) {
+    a.s[k] = FusedSeg{nullptr, 0, 0, 0, 0};
+    a.blocks_end[k] = 0;
+  }
+  a.count = 0;
+  a.reduce_blocks = 0;
+  a.w = (float*)w;
+  a.g = (float*)g;
+  a.shadow = (bf16*)shadow;
+  a.hyper = (const float*)hyper;
+  a.dense_lo4 = a.dense_hi4 = 0;
+  a.out_wT = (float*)out_wT;
+  a.out_w_off = out_w_off;
+  a.H = H;
+  a.wc2T = (bf16*)wc2T;
+  a.wc2_off = wc2_off;
+  a.c1 = c1;
+  a.c2 = c2;
+  a.adv = StepAdvance{(int64_t*)state, cursor_inc, step_inc, drop_inc, -1};
+  a.m = (float*)m;
+  a.v = (float*)v;
+  a.adam_t = adam ? (const int64_t*)state + adam_slot : nullptr;
+  TailP2P pp;
+  for (int r = 0; r < 8; ++r) {
+    char* base = static_cast<char*>(bases[r < world ? r : rank]);
+    pp.stage[r] = reinterpret_cast<float*>(base);
+    pp.flags[r] = reinterpret_cast<unsigned*>(base + 2L * world * n_max * 4);
+  }
+  pp.status = status;
+  pp.world = world;
+  pp.rank = rank;
+  pp.n_max = (int)n_max;
+  pp.seq = seq;
+  pp.timeout_ticks = (long long)(timeout_s * 1e8);
+  pp.tail_off = tail_off;
+  if (adam) hipLaunchKernelGGL(advance_state_kernel, dim3(1), dim3(1), 0, s, StepAdvance{(int64_t*)state, 0, 0, 0, adam_slot});
+  if (adam) hipLaunchKernelGGL(p2p_tail_allreduce_update<true>, dim3(kTailXBlocks), dim3(256), 0, s, a, pp, (int)n);
+  else hipLaunchKernelGGL(p2p_tail_allreduce_update<false>, dim3(kTailXBlocks), dim3(256), 0, s, a, pp, (int)n);
+  return (int)hipGetLastError();
 }
 
 }  // extern "C"
