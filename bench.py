@@ -87,7 +87,7 @@ def main():
     use_graph = False
     tail_p2p, tail_how = None, "n/a"
     dense_p2p, dense_how = None, "n/a"
-    p2p_blocks_us = None
+    p2p_blocks_us = dense_cand = None
     if dp_path:
         try:   # second communicator: the small tail all-reduce must not queue behind the 12.8 MB one inside RCCL
             tail_group = torch.distributed.new_group()
@@ -123,26 +123,15 @@ def main():
             tail_how = "p2p one-shot + update in one launch" if tail_p2p is not None else why
         # The dense message (12.8 MB, hidden under backward if it is fast enough) goes peer-to-peer only if the
         # two-shot kernel is correct here AND clearly faster than RCCL stand-alone on this node.
-        if not args.no_p2p_dense and world > 1 and world <= 8:
-            cand, why = bring_up(n_dense_arena, True)
-            if cand is None:
+        # The dense message (12.8 MB, overlapped with backward) has a peer-to-peer candidate too (two-shot kernel); whether
+        # it is used is decided further down by timing the STEP with either path: stand-alone latency says little about
+        # a collective whose cost is what it takes from the kernels it overlaps with (world 1, 64 workgroups: 50 us
+        # stand-alone, +30 us on the step).  DTF_BENCH_DENSE_P2P_WORLD1 lets a one-rank --force_dp run try it as well.
+        dense_cand = None
+        if not args.no_p2p_dense and (world > 1 or os.environ.get("DTF_BENCH_DENSE_P2P_WORLD1")) and world <= 8:
+            dense_cand, why = bring_up(n_dense_arena, True)
+            if dense_cand is None:
                 dense_how = why
-            else:
-                # workgroups per launch: the fewest that come within 10 % of the best stand-alone time (the collective
-                # overlaps with backward kernels that want the CUs); latencies are max-over-ranks, so all ranks agree
-                times = {}
-                for nb in (32, 64, 128, 256):
-                    cand.blocks = nb
-                    times[nb] = cand.latency_us(n_dense_arena, iters=10, warmup=3)
-                cand.blocks = min(nb for nb, t in times.items() if t <= 1.10 * min(times.values()))
-                t_p2p = times[cand.blocks]
-                p2p_blocks_us = {str(k): round(v, 1) for k, v in times.items()}
-                t_pg = comm.allreduce_latency_us(n_dense_arena, device=dev)
-                if t_p2p < 0.85 * t_pg:
-                    dense_p2p, dense_how = cand, f"p2p two-shot, {cand.blocks} workgroups ({t_p2p:.0f} us vs rccl {t_pg:.0f} us stand-alone)"
-                else:
-                    cand.close()
-                    dense_how = f"rccl ({t_pg:.0f} us vs p2p two-shot {t_p2p:.0f} us stand-alone)"
         dp = SyncDataParallel(eng, tail_group=tail_group, tail_p2p=tail_p2p, dense_p2p=dense_p2p)
         dp.broadcast_parameters()
         step = dp.train_step
@@ -160,6 +149,42 @@ def main():
             torch.distributed.barrier()
         torch.cuda.synchronize()
 
+    if dp_path and dense_cand is not None:
+        def step_ms(n=60):
+            for _ in range(15):
+                step()
+            barrier()
+            t1 = time.perf_counter()
+            for _ in range(n):
+                step()
+            barrier()
+            ms = torch.tensor([(time.perf_counter() - t1) * 1e3 / n], dtype=torch.float64)
+            if torch.distributed.get_backend() != "gloo":
+                ms = ms.cuda()
+            torch.distributed.all_reduce(ms, op=torch.distributed.ReduceOp.MAX)     # the same number on every rank
+            return float(ms.item())
+
+        trials = {"rccl": step_ms()}
+        dp.dense_p2p = dense_cand
+        for nb in (16, 32, 64, 128):
+            dense_cand.blocks = nb
+            trials[f"p2p two-shot, {nb} workgroups"] = step_ms()
+        p2p_blocks_us = {k: round(v, 4) for k, v in trials.items()}
+        best = min(trials, key=trials.get)
+        st = torch.tensor([dense_cand.status()], dtype=torch.int32)      # a timed-out wait on ANY rank disqualifies it
+        if torch.distributed.get_backend() != "gloo":
+            st = st.cuda()
+        torch.distributed.all_reduce(st, op=torch.distributed.ReduceOp.MAX)
+        if best != "rccl" and trials[best] < 0.98 * trials["rccl"] and int(st.item()) == 0:
+            dense_cand.blocks = int(best.split(",")[1].split()[0])
+            dense_p2p, dense_how = dense_cand, f"{best} ({trials[best]:.4f} vs rccl {trials['rccl']:.4f} ms/step)"
+        else:
+            dp.dense_p2p = None
+            if int(st.item()):
+                dp.broadcast_parameters()      # sums may have been wrong on the way: re-align the ranks
+            dense_how = f"rccl ({trials['rccl']:.4f} ms/step vs best p2p two-shot {min(v for k, v in trials.items() if k != 'rccl'):.4f})"
+            barrier()
+            dense_cand.close()
     for _ in range(args.warmup):
         step()
     barrier()
@@ -251,7 +276,7 @@ def main():
                 comm_diag["tail_p2p_us"] = round((time.perf_counter() - t1) * 1e4, 1)
                 comm_diag["tail_p2p_timeouts"] = tail_p2p.status()
             if p2p_blocks_us is not None:
-                comm_diag["dense_p2p_us_by_workgroups"] = p2p_blocks_us
+                comm_diag["step_ms_by_dense_allreduce"] = p2p_blocks_us
             comm_diag["step_ms_no_allreduce"] = timed(True, True)
             comm_diag["step_ms_dense_allreduce_only"] = timed(False, True)
             comm_diag["step_ms_tail_allreduce_only"] = timed(True, False)
