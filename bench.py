@@ -87,7 +87,7 @@ def main():
     use_graph = False
     tail_p2p, tail_how = None, "n/a"
     dense_p2p, dense_how = None, "n/a"
-    p2p_blocks_us = dense_cand = None
+    p2p_blocks_us = dense_cand = tail_trials = None
     if dp_path:
         try:   # second communicator: the small tail all-reduce must not queue behind the 12.8 MB one inside RCCL
             tail_group = torch.distributed.new_group()
@@ -149,21 +149,24 @@ def main():
             torch.distributed.barrier()
         torch.cuda.synchronize()
 
-    if dp_path and dense_cand is not None:
-        def step_ms(n=60):
-            for _ in range(15):
-                step()
-            barrier()
-            t1 = time.perf_counter()
-            for _ in range(n):
-                step()
-            barrier()
-            ms = torch.tensor([(time.perf_counter() - t1) * 1e3 / n], dtype=torch.float64)
-            if torch.distributed.get_backend() != "gloo":
-                ms = ms.cuda()
-            torch.distributed.all_reduce(ms, op=torch.distributed.ReduceOp.MAX)     # the same number on every rank
-            return float(ms.item())
+    def step_ms(n=200):
+        for _ in range(15):
+            step()
+        barrier()
+        t1 = time.perf_counter()
+        for _ in range(n):
+            step()
+        barrier()
+        return max_over_ranks((time.perf_counter() - t1) * 1e3 / n)
 
+    def max_over_ranks(x):       # the same number on every rank, so that every rank takes the same decision
+        t = torch.tensor([x], dtype=torch.float64)
+        if torch.distributed.get_backend() != "gloo":
+            t = t.cuda()
+        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+        return float(t.item())
+
+    if dp_path and dense_cand is not None:
         trials = {"rccl": step_ms()}
         dp.dense_p2p = dense_cand
         for nb in (16, 32, 64, 128):
@@ -171,20 +174,34 @@ def main():
             trials[f"p2p two-shot, {nb} workgroups"] = step_ms()
         p2p_blocks_us = {k: round(v, 4) for k, v in trials.items()}
         best = min(trials, key=trials.get)
-        st = torch.tensor([dense_cand.status()], dtype=torch.int32)      # a timed-out wait on ANY rank disqualifies it
-        if torch.distributed.get_backend() != "gloo":
-            st = st.cuda()
-        torch.distributed.all_reduce(st, op=torch.distributed.ReduceOp.MAX)
-        if best != "rccl" and trials[best] < 0.98 * trials["rccl"] and int(st.item()) == 0:
+        st = max_over_ranks(dense_cand.status())      # a timed-out wait on ANY rank disqualifies it
+        if best != "rccl" and trials[best] < 0.98 * trials["rccl"] and st == 0:
             dense_cand.blocks = int(best.split(",")[1].split()[0])
             dense_p2p, dense_how = dense_cand, f"{best} ({trials[best]:.4f} vs rccl {trials['rccl']:.4f} ms/step)"
         else:
             dp.dense_p2p = None
-            if int(st.item()):
+            if st:
                 dp.broadcast_parameters()      # sums may have been wrong on the way: re-align the ranks
             dense_how = f"rccl ({trials['rccl']:.4f} ms/step vs best p2p two-shot {min(v for k, v in trials.items() if k != 'rccl'):.4f})"
             barrier()
             dense_cand.close()
+    if dp_path and tail_p2p is not None:
+        # the same question for the tail message: exchange + update kernel vs {RCCL all-reduce, update}, by step time
+        t_p2p = step_ms()
+        dp.tail_p2p = None
+        t_pg = step_ms()
+        st = max_over_ranks(tail_p2p.status())
+        tail_trials = {"p2p": round(t_p2p, 4), "rccl": round(t_pg, 4)}
+        if t_p2p <= t_pg and st == 0:
+            dp.tail_p2p = tail_p2p
+            tail_how += f" ({t_p2p:.4f} vs rccl {t_pg:.4f} ms/step)"
+        else:
+            if st:
+                dp.broadcast_parameters()
+            barrier()
+            tail_p2p.close()
+            tail_p2p = None
+            tail_how = f"rccl ({t_pg:.4f} vs p2p {t_p2p:.4f} ms/step{', p2p wait timed out' if st else ''})"
     for _ in range(args.warmup):
         step()
     barrier()
@@ -277,6 +294,8 @@ def main():
                 comm_diag["tail_p2p_timeouts"] = tail_p2p.status()
             if p2p_blocks_us is not None:
                 comm_diag["step_ms_by_dense_allreduce"] = p2p_blocks_us
+            if tail_trials is not None:
+                comm_diag["step_ms_by_tail_allreduce"] = tail_trials
             comm_diag["step_ms_no_allreduce"] = timed(True, True)
             comm_diag["step_ms_dense_allreduce_only"] = timed(False, True)
             comm_diag["step_ms_tail_allreduce_only"] = timed(True, False)
