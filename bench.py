@@ -166,11 +166,20 @@ def main():
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
         return float(t.item())
 
+    def probe_ok(p2p):           # five steps first: a path whose waits time out (2 s each) must not get a 200-step trial
+        for _ in range(5):
+            step()
+        barrier()
+        return max_over_ranks(p2p.status()) == 0
+
     if dp_path and dense_cand is not None:
         trials = {"rccl": step_ms()}
         dp.dense_p2p = dense_cand
         for nb in (16, 32, 64, 128):
             dense_cand.blocks = nb
+            if not probe_ok(dense_cand):
+                dense_cand._status.fill_(1)      # disqualified below (and the ranks re-aligned)
+                break
             trials[f"p2p two-shot, {nb} workgroups"] = step_ms()
         p2p_blocks_us = {k: round(v, 4) for k, v in trials.items()}
         best = min(trials, key=trials.get)
@@ -182,16 +191,20 @@ def main():
             dp.dense_p2p = None
             if st:
                 dp.broadcast_parameters()      # sums may have been wrong on the way: re-align the ranks
-            dense_how = f"rccl ({trials['rccl']:.4f} ms/step vs best p2p two-shot {min(v for k, v in trials.items() if k != 'rccl'):.4f})"
+            others = [v for k, v in trials.items() if k != "rccl"]
+            dense_how = f"rccl ({trials['rccl']:.4f} ms/step" + (f" vs best p2p two-shot {min(others):.4f})" if others else
+                                                                  "; p2p two-shot waits timed out)")
             barrier()
             dense_cand.close()
     if dp_path and tail_p2p is not None:
         # the same question for the tail message: exchange + update kernel vs {RCCL all-reduce, update}, by step time
-        t_p2p = step_ms()
+        t_p2p = step_ms() if probe_ok(tail_p2p) else float("inf")
+        if t_p2p == float("inf"):
+            tail_p2p._status.fill_(1)
         dp.tail_p2p = None
         t_pg = step_ms()
         st = max_over_ranks(tail_p2p.status())
-        tail_trials = {"p2p": round(t_p2p, 4), "rccl": round(t_pg, 4)}
+        tail_trials = {"p2p": round(t_p2p, 4) if t_p2p != float("inf") else None, "rccl": round(t_pg, 4)}
         if t_p2p <= t_pg and st == 0:
             dp.tail_p2p = tail_p2p
             tail_how += f" ({t_p2p:.4f} vs rccl {t_pg:.4f} ms/step)"
@@ -201,7 +214,7 @@ def main():
             barrier()
             tail_p2p.close()
             tail_p2p = None
-            tail_how = f"rccl ({t_pg:.4f} vs p2p {t_p2p:.4f} ms/step{', p2p wait timed out' if st else ''})"
+            tail_how = f"rccl ({t_pg:.4f} ms/step" + (", p2p waits timed out)" if st else f" vs p2p {t_p2p:.4f})")
     for _ in range(args.warmup):
         step()
     barrier()
