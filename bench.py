@@ -254,8 +254,45 @@ def main():
         tail_how += " (a wait TIMED OUT inside the timed region: sums invalid)"
     if dense_p2p is not None and dense_p2p.status():
         dense_how += " (a wait TIMED OUT inside the timed region: sums invalid)"
+    def emit(comm_diag):
+        if rank != 0:
+            return
+        global_batch = B * world
+        value = global_batch * args.steps / dt
+        _, fb = spec.flops_per_image()
+        print(json.dumps({
+            "metric": "train images/sec (whole node)",
+            "value": round(value, 1),
+            "unit": "images/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": round(1e3 * dt / args.steps, 4),
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "bf16",
+            "data": "synthetic (HBM-resident 28x28x1, random TF-style init)",
+            "config": {"model": spec.name, "global_batch": global_batch, "per_gpu_batch": B, "seq_len": None,
+                       "parallelism": f"dp{world}" + ("(forced dp schedule)" if args.force_dp and world == 1 else "") + ("(rehearsal: gloo, one GPU)" if args.rehearse_one_gpu else ""), "optimizer": args.optimizer, "keep_prob": args.keep_prob,
+                       "graph": bool(use_graph),
+                       **({"tail_allreduce": tail_how, "dense_allreduce": dense_how} if dp_path else {})},
+            "model_tflops": round(value * fb / 1e12, 2),
+            "final_loss": round(loss, 4),
+            **({"comm_diag": comm_diag} if comm_diag is not None else {}),
+        }), flush=True)
+    # The diagnostics below run collectives after the measurement is complete: if they stall (they never have), every
+    # rank gives up after 90 s, rank 0 still prints the headline line, and the processes exit.
+    def give_up():
+        emit({"error": "comm_diag stalled for 90 s and was abandoned"})
+        os._exit(0)
+
+    import threading
+    watchdog = threading.Timer(90.0, give_up)
+    watchdog.daemon = True
     comm_diag = None
     if dp_path:
+        watchdog.start()
         # Outside the timed region: stand-alone latency of the step's two all-reduces (the dense fc1 gradient
         # and the small tail), i.e. the two communication terms of the scaling model in docs/ARCHITECTURE.md.
         try:
@@ -314,31 +351,8 @@ def main():
             comm_diag["step_ms_tail_allreduce_only"] = timed(True, False)
         except Exception as e:   # a diagnostic must never cost the headline line
             comm_diag = {"error": repr(e)}
-    if rank == 0:
-        global_batch = B * world
-        value = global_batch * args.steps / dt
-        _, fb = spec.flops_per_image()
-        print(json.dumps({
-            "metric": "train images/sec (whole node)",
-            "value": round(value, 1),
-            "unit": "images/s",
-            "n_gpus": world,
-            "steps": args.steps,
-            "warmup": args.warmup,
-            "ms_per_step": round(1e3 * dt / args.steps, 4),
-            "higher_is_better": True,
-            "scaling": "weak",
-            "vs_baseline": None,
-            "dtype": "bf16",
-            "data": "synthetic (HBM-resident 28x28x1, random TF-style init)",
-            "config": {"model": spec.name, "global_batch": global_batch, "per_gpu_batch": B, "seq_len": None,
-                       "parallelism": f"dp{world}" + ("(forced dp schedule)" if args.force_dp and world == 1 else "") + ("(rehearsal: gloo, one GPU)" if args.rehearse_one_gpu else ""), "optimizer": args.optimizer, "keep_prob": args.keep_prob,
-                       "graph": bool(use_graph),
-                       **({"tail_allreduce": tail_how, "dense_allreduce": dense_how} if dp_path else {})},
-            "model_tflops": round(value * fb / 1e12, 2),
-            "final_loss": round(loss, 4),
-            **({"comm_diag": comm_diag} if comm_diag is not None else {}),
-        }))
+        watchdog.cancel()
+    emit(comm_diag)
     if dp_path:
         barrier()
         for p2p in (tail_p2p, dense_p2p):
