@@ -109,6 +109,7 @@ struct P2P2Args {
   int world, rank, n, n_max;
   unsigned seq;
   long long timeout_ticks;
+  int gather;   // 0: leave the result in stageB(parity) of this rank (the consumer reads it there) instead of copying it to data
 };
 
 __device__ __forceinline__ void p2p_wait_all(const unsigned* flags_row0, int stride, int world, unsigned seq,
@@ -176,6 +177,7 @@ __global__ __launch_bounds__(kP2PThreads2) void p2p_allreduce_twoshot(P2P2Args a
   p2p_wait_all(flagB(a.rank) + (size_t)par * W * kP2PBlocks2 + b, kP2PBlocks2, W, a.seq, a.timeout_ticks, a.status);
 
   // ---- gather: every chunk's slice b out of my staging into the arena ----
+  if (!a.gather) return;
   for (int q = 0; q < W; ++q) {
     const f32x4* src = reinterpret_cast<const f32x4*>(stageB(a.rank) + (size_t)par * a.n_max + (size_t)q * csz);
     f32x4* dst = reinterpret_cast<f32x4*>(a.data + (size_t)q * csz);
@@ -258,7 +260,7 @@ long dtf_p2p2_bytes(int world, long n_max) {
 
 // Two-shot variant; n and n_max must be multiples of 4 * world.
 int dtf_p2p2_allreduce(void* data, void* const* bases, int world, int rank, long n, long n_max, unsigned seq,
-                       int* status, double timeout_s, int blocks, hipStream_t s) {
+                       int* status, double timeout_s, int blocks, int gather, hipStream_t s) {
   if (blocks < 1 || blocks > dtf::kP2PBlocks2) return -2;
   if (world < 1 || world > dtf::kP2PMaxWorld || rank < 0 || rank >= world) return -2;
   if (n < 0 || n > n_max || n % (4 * world) || n_max % (4 * world) || seq == 0) return -2;
@@ -273,6 +275,7 @@ int dtf_p2p2_allreduce(void* data, void* const* bases, int world, int rank, long
   a.n_max = (int)n_max;
   a.seq = seq;
   a.timeout_ticks = (long long)(timeout_s * 1e8);
+  a.gather = gather;
   hipLaunchKernelGGL(dtf::p2p_allreduce_twoshot, dim3(blocks), dim3(dtf::kP2PThreads2), 0, s, a);
   return (int)hipGetLastError();
 }

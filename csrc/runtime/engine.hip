@@ -198,16 +198,25 @@ int dtf_engine_backward(const DtfEngineDesc* e, const void* images, const void* 
   return backward_impl(e, images, idx, 1, s);
 }
 
+static int update_range_src(const DtfEngineDesc* e, long lo, long hi, int advance, int advance_cursor, long step_inc,
+                            int adam_slot, const void* gsrc, hipStream_t s);
 int dtf_engine_update_range(const DtfEngineDesc* e, long lo, long hi, int advance, int advance_cursor, long step_inc,
                             int adam_slot, hipStream_t s) {
+  return update_range_src(e, lo, hi, advance, advance_cursor, step_inc, adam_slot, nullptr, s);
+}
+// gsrc != nullptr: the gradient of [lo, hi) is read there instead of from the gradient arena (the staging buffer of
+// the peer-to-peer all-reduce, which then does not have to copy its result into the arena)
+static int update_range_src(const DtfEngineDesc* e, long lo, long hi, int advance, int advance_cursor, long step_inc,
+                            int adam_slot, const void* gsrc, hipStream_t s) {
   const long n = hi - lo;
+  const void* g = gsrc ? gsrc : (const void*)f32at(e->grads, lo);
   void* st = advance ? e->state : nullptr;
   const long cinc = (advance && advance_cursor) ? e->B : 0;
   if (e->optimizer == 0)
-    DTF_TRY(dtf_sgd_update(f32at(e->params, lo), f32at(e->grads, lo), bf16at(e->shadow, lo), e->hyper, n, st, cinc,
+    DTF_TRY(dtf_sgd_update(f32at(e->params, lo), g, bf16at(e->shadow, lo), e->hyper, n, st, cinc,
                            step_inc, 1, s));
   else
-    DTF_TRY(dtf_adam_update(f32at(e->params, lo), f32at(e->grads, lo), f32at(e->adam_m, lo), f32at(e->adam_v, lo),
+    DTF_TRY(dtf_adam_update(f32at(e->params, lo), g, f32at(e->adam_m, lo), f32at(e->adam_v, lo),
                             bf16at(e->shadow, lo), e->hyper, n, e->state, adam_slot, st, cinc, step_inc, 1, s));
   // the head kernel reads the output weight transposed: keep that copy current
   if (lo <= e->off_out_w && e->off_out_w < hi)
@@ -304,12 +313,13 @@ int dtf_engine_dp_phase1(const DtfEngineDesc* e, int wait_dense_updated, hipStre
 }
 
 // reduce_tail == 0: the head/conv slabs are left unreduced for dtf_engine_dp_phase3_p2p (which sums them itself)
-int dtf_engine_dp_phase2(const DtfEngineDesc* e, long dense_hi, int dense_adam_slot, int reduce_tail, hipStream_t s,
-                         hipStream_t comm, hipStream_t tail) {
+int dtf_engine_dp_phase2(const DtfEngineDesc* e, long dense_hi, int dense_adam_slot, int reduce_tail,
+                         const void* dense_grad_src, hipStream_t s, hipStream_t comm, hipStream_t tail) {
   DTF_TRY(backward_conv_impl(e, e->ds_images, e->idx, 1, reduce_tail ? 2 : 0, 1, s));
   // the dense update overwrites the bf16 wd1 that fc1 dgrad reads: order it after that kernel
   if (!(DTF_EXP_DP & 1)) HIP_TRY(hipStreamWaitEvent(comm, e->ev_dgrad, 0));
-  if (!(DTF_EXP_DP & 2)) DTF_TRY(dtf_engine_update_range(e, 0, dense_hi, 0, 0, 0, dense_adam_slot, (DTF_EXP_DP & 4) ? s : comm));
+  if (!(DTF_EXP_DP & 2))
+    DTF_TRY(update_range_src(e, 0, dense_hi, 0, 0, 0, dense_adam_slot, dense_grad_src, (DTF_EXP_DP & 4) ? s : comm));
   HIP_TRY(hipEventRecord(e->ev_dense_updated, comm));
   // tail == s: the tail collective is issued on the compute stream itself (everything after it depends on
   // it anyway), which needs no events at all; a separate tail stream is ordered behind the conv backward

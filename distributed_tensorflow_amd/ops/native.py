@@ -79,7 +79,7 @@ _SIGS = {
                           c_void_p],
     "dtf_p2p2_bytes": [c_int, c_long],
     "dtf_p2p2_allreduce": [c_void_p, ctypes.POINTER(c_void_p), c_int, c_int, c_long, c_long, c_uint, c_void_p, c_double,
-                           c_int, c_void_p],
+                           c_int, c_int, c_void_p],
     "dtf_sample_indices": [c_void_p, c_void_p, c_int, c_uint, c_uint, c_uint, c_int, c_void_p],
     "dtf_gen_synthetic": [c_void_p, c_void_p, c_long, c_uint, c_void_p],
     "dtf_init_truncated_normal": [c_void_p, c_long, c_float, c_uint64, c_uint64, c_void_p],
@@ -123,7 +123,7 @@ _ENGINE_SIGS = {
     "dtf_engine_transposes": [_EP, c_int, c_void_p],
     "dtf_engine_train_step": [_EP, c_long, c_void_p],
     "dtf_engine_dp_phase1": [_EP, c_int, c_void_p, c_void_p],
-    "dtf_engine_dp_phase2": [_EP, c_long, c_int, c_int, c_void_p, c_void_p, c_void_p],
+    "dtf_engine_dp_phase2": [_EP, c_long, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p],
     "dtf_engine_dp_phase3_p2p": [_EP, c_int, c_long, c_int, c_void_p, ctypes.POINTER(c_void_p), c_int, c_int, c_long, c_uint,
                                  c_void_p, c_double, c_int],
     "dtf_engine_dp_phase3": [_EP, c_long, c_int, c_long, c_int, c_void_p, c_void_p],

@@ -80,8 +80,10 @@ class P2PAllReduce:
             raise RuntimeError("P2PAllReduce bring-up failed: " + "; ".join(f"rank {r}: {o}" for r, o in enumerate(oks) if o))
         dist.barrier(group=group)     # nobody pushes before everybody has mapped (and zeroed) everything
 
-    def allreduce(self, t: torch.Tensor, stream: Optional[int] = None):
-        """SUM-all-reduce the fp32 vector ``t`` in place, on ``stream`` (raw handle; default: the current one)."""
+    def allreduce(self, t: torch.Tensor, stream: Optional[int] = None, gather: bool = True) -> Optional[int]:
+        """SUM-all-reduce the fp32 vector ``t`` in place, on ``stream`` (raw handle; default: the current one).
+        two-shot with gather=False: ``t`` is left alone and the address of the result in this rank's (uncached)
+        staging buffer is returned -- valid until the all-reduce after the next one; the consumer reads it there."""
         n = t.numel()
         if t.dtype != torch.float32 or not t.is_contiguous() or n > self.n_max or n % self.quantum:
             raise ValueError(f"P2PAllReduce: fp32, contiguous, a multiple of {self.quantum} and at most n_max elements")
@@ -89,11 +91,14 @@ class P2PAllReduce:
         s = torch.cuda.current_stream(self.device).cuda_stream if stream is None else stream
         if self.two_shot:
             rc = self.lib.dtf_p2p2_allreduce(t.data_ptr(), self._bases, self.world, self.rank, n, self.n_max, self.seq,
-                                             self._status.data_ptr(), self.timeout_s, self.blocks, s)
+                                             self._status.data_ptr(), self.timeout_s, self.blocks, int(gather), s)
         else:
             rc = self.lib.dtf_p2p_allreduce(t.data_ptr(), self._bases, self.world, self.rank, n, self.n_max, self.seq,
                                             self._status.data_ptr(), self.timeout_s, s)
         native.check(rc, "p2p allreduce")
+        if self.two_shot and not gather:     # stageB(parity) of the own allocation: after stageA = [2][n_max] floats
+            return self._own.value + 4 * (2 * self.n_max + (self.seq & 1) * self.n_max)
+        return None
 
     def status(self) -> int:
         """0 = fine; 1 = some wait timed out since the last call (synchronises the device)."""

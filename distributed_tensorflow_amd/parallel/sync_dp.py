@@ -135,15 +135,17 @@ class SyncDataParallel:
         if tr: tr.push("dp_phase1: fwd + fc1 wgrad")
         check(lib.dtf_engine_dp_phase1(d, int(self._have_pending_dense), cur, comm), "dp_phase1")
         if tr: tr.pop(); tr.push("allreduce dense (enqueue)")
+        dense_src = None     # where the deferred dense update reads the summed gradient (None: the gradient arena)
         if self.dense_p2p is not None:
-            self.dense_p2p.allreduce(eng.grads[0:self.n_dense], comm)
+            # the result stays in the kernel's staging buffer: no copy back into the arena (a third of its local traffic)
+            dense_src = self.dense_p2p.allreduce(eng.grads[0:self.n_dense], comm, gather=False)
         else:
             with torch.cuda.stream(self.comm_stream):
                 for lo, hi in self.dense_buckets:
                     self._allreduce(lo, hi, self.group)
         if tr: tr.pop(); tr.push("dp_phase2: conv backward")
-        check(lib.dtf_engine_dp_phase2(d, self.n_dense, self.DENSE_SLOT, 0 if self.fuse_tail else 1, cur, comm, tail),
-              "dp_phase2")
+        check(lib.dtf_engine_dp_phase2(d, self.n_dense, self.DENSE_SLOT, 0 if self.fuse_tail else 1, dense_src, cur, comm,
+                                       tail), "dp_phase2")
         if self.tail_p2p is not None and (self.fuse_tail or self.p2p_tail_update):
             if tr: tr.pop(); tr.push("dp_phase3: p2p all-reduce + update (one launch)")
             p = self.tail_p2p

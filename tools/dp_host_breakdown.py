@@ -24,7 +24,7 @@ cur = torch.cuda.current_stream().cuda_stream
 comm_s = dp.comm_stream.cuda_stream
 tail_s = cur if dp.tail_stream is None else dp.tail_stream.cuda_stream
 def p1(): check(lib.dtf_engine_dp_phase1(d, 0, cur, comm_s), "p1")
-def p2(): check(lib.dtf_engine_dp_phase2(d, dp.n_dense, 3, 1, cur, comm_s, tail_s), "p2")
+def p2(): check(lib.dtf_engine_dp_phase2(d, dp.n_dense, 3, 1, None, cur, comm_s, tail_s), "p2")
 def p3(): check(lib.dtf_engine_dp_phase3(d, dp.n_dense, 4, 1, 0, cur, tail_s), "p3")
 def ar_dense():
     with torch.cuda.stream(dp.comm_stream): dp._allreduce(0, dp.n_dense, dp.group)
