@@ -35,6 +35,10 @@ def main():
     ap.add_argument("--optimizer", default="sgd")
     ap.add_argument("--keep_prob", type=float, default=1.0)
     ap.add_argument("--dataset_size", type=int, default=60000)
+    ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"],
+                    help="bf16: bf16 MFMA compute copies, fp32 accumulation and fp32 master weights (default; BASELINE.json "
+                         "config 2 names fp32/bf16).  fp32: the reference's precision end to end -- exact-fp32 MFMA kernels, "
+                         "fp32 activations, no shadow copies (reference .idea/MNISTDist.py:113-115)")
     ap.add_argument("--single_stream", action="store_true", help="disable the fork/join side streams in backward")
     ap.add_argument("--multi_stream", action="store_true", help="force the fork/join side streams (default: by batch size)")
     ap.add_argument("--no_graph", action="store_true", help="eager launches instead of HIP-graph replay (1 GPU)")
@@ -76,12 +80,12 @@ def main():
 
     spec = ModelSpec.from_name(args.model)
     B = args.per_gpu_batch
-    ds = DeviceDataset.synthetic(args.dataset_size, seed=1234)
+    ds = DeviceDataset.synthetic(args.dataset_size, seed=1234, dtype=args.dtype)
     eng = HipEngine(spec, B, ds, optimizer=args.optimizer, learning_rate=1e-3, keep_prob=args.keep_prob,
                     seed=1000 + rank,
                     # None = engine default (by batch size); the data-parallel path measured faster without the fork/join
                     multi_stream=False if (args.single_stream or dp_path) else (True if args.multi_stream else None),
-                    fuse_dense_update=not dp_path)
+                    fuse_dense_update=not dp_path, dtype=args.dtype)
     eng.init_params(seed=7)
 
     use_graph = False
@@ -139,7 +143,7 @@ def main():
         # The whole step is one foreign call into the native executor either way.  Measured A/B: with the
         # single-stream 8-kernel step, eager launches run 2.5-5 % faster than replaying the captured graph up
         # to 1024 images/GPU; from 2048 up the graph (with its backward fork/join) wins by ~6 %.
-        use_graph = args.graph or (not args.no_graph and B > 1024)
+        use_graph = args.graph or (not args.no_graph and B > 1024 and args.dtype == "bf16")
         if use_graph:
             eng.capture()
         step = eng.train_step
@@ -271,7 +275,7 @@ def main():
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
-            "dtype": "bf16",
+            "dtype": args.dtype,
             "data": "synthetic (HBM-resident 28x28x1, random TF-style init)",
             "config": {"model": spec.name, "global_batch": global_batch, "per_gpu_batch": B, "seq_len": None,
                        "parallelism": f"dp{world}" + ("(forced dp schedule)" if args.force_dp and world == 1 else "") + ("(rehearsal: gloo, one GPU)" if args.rehearse_one_gpu else ""), "optimizer": args.optimizer, "keep_prob": args.keep_prob,

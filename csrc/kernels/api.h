@@ -76,4 +76,35 @@ int dtf_p2p_tail_update(int adam, void* w, void* g, void* m, void* v, void* shad
                         long n_max, unsigned seq, int* status, double timeout_s, long tail_off, hipStream_t s);
 int dtf_sample_indices(const void* state, void* idx, int B, unsigned n, unsigned hb, unsigned seed, int shuffle,
                        hipStream_t s);
+
+// ---- exact-fp32 kernel set (--dtype fp32): fp32 activations / weights, f32-input MFMA (csrc/kernels/*_f32.hip) ----
+int dtf_conv1_f32_fwd(const void* images, const void* idx, const void* w, const void* bias, void* pooled, void* arg, int B,
+                      int cout, int grid, hipStream_t s);
+int dtf_conv1_f32_fwd_sampled(const void* images, void* idx_out, const void* state, unsigned n, unsigned hb, unsigned seed,
+                              int shuffle, const void* w, const void* bias, void* pooled, void* arg, int B, int cout,
+                              int grid, hipStream_t s);
+int dtf_conv1_f32_wgrad(const void* images, const void* idx, const void* gpool, const void* arg, void* part, int B, int cout,
+                        int grid, hipStream_t s);
+int dtf_u8_to_f32_unit(const void* src, void* dst, long n, hipStream_t s);
+int dtf_conv2_f32_pack_weights(const void* w, void* packed, int cin, int cout, hipStream_t s);
+int dtf_conv2_f32_fwd(const void* x, const void* wpack, const void* bias, void* pooled, void* arg, int B, int cin, int cout,
+                      hipStream_t s);
+int dtf_conv2_f32_dgrad(const void* gpool, const void* arg, const void* wpack, void* dx, int B, int cin, int cout,
+                        hipStream_t s);
+int dtf_conv2_f32_wgrad(const void* x, const void* gpool, const void* arg, void* part, int B, int cin, int cout, int G,
+                        hipStream_t s);
+int dtf_gemm_f32_nn_partial(const void* A, const void* B, void* part, int M, int N, int K, int lda, int ldb, int S,
+                            hipStream_t s);
+int dtf_gemm_f32_nt(const void* A, const void* B, void* C, int M, int N, int K, int lda, int ldb, int ldc, hipStream_t s);
+int dtf_gemm_f32_tn(const void* A, const void* B, void* C, int M, int N, int K, int lda, int ldb, int ldc,
+                    const void* hyper, hipStream_t s);
+int dtf_head_f32_fwd_bwd(const void* h1, const void* wT, const void* bias, const void* labels, const void* idx,
+                         void* logits_out, void* loss_rows, void* correct_rows, void* dlogits, void* da, int B, int H,
+                         float grad_scale, float inv_keep, int backward, hipStream_t s);
+int dtf_head_f32_fused_fwd_bwd(const void* part, int S, const void* bias1, float keep_prob, uint64_t seed,
+                               const void* state, void* h1, const void* wT, const void* bias, const void* labels,
+                               const void* idx, void* logits_out, void* loss_rows, void* correct_rows, void* dlogits,
+                               void* da, int B, int H, float grad_scale, float inv_keep, int backward, hipStream_t s);
+int dtf_head_f32_wgrad(const void* h1, const void* dlogits, const void* da, void* part, int B, int H, int KS,
+                       hipStream_t s);
 }

@@ -1,0 +1,470 @@
+// Second conv block in exact fp32 (--dtype fp32): 5x5 SAME stride-1 convolution over 14x14 maps as an
+// implicit GEMM on the f32-input matrix cores, NHWC fp32 activations, fp32 HWIO weights
+// (reference .idea/MNISTDist.py:52-62,76-78 and the Conv2DBackprop{Input,Filter} / MaxPoolGrad / ReluGrad /
+// BiasAddGrad ops autodiff generates for them).  Same decomposition ideas as the bf16 kernels of conv2.hip,
+// re-tiled for the fp32 instruction shapes and for a kernel whose bound is the (16x slower) matrix pipe:
+//
+// conv5x5_igemm_f32 (forward and dgrad), v_mfma_f32_16x16x4_f32, ONE image per 4-wave workgroup:
+//   M = the image's 49 pooling windows x 4 positions, rows ordered m = 4*window + q, so the four accumulator
+//   registers of a lane ARE one pooling window (bias + ReLU + max-pool + argmax in registers) -- 13 M tiles of
+//   4 windows (the last holds one real window: 6 % padding instead of the 12.5 % of row-shaped tiles).
+//   The zero-haloed 18x18 input tile sits in LDS as [pos][32 ch + 4 pad] floats; the A fragment of tap (ky,kx),
+//   k block kb is one ds_read_b128 of four consecutive channels at a shifted position -- no im2col.
+//   Weights come from a fragment-ordered fp32 pack (pack_conv2_weights_f32): the B fragment of (tap, 16-k block,
+//   16-wide n tile) is one coalesced 1 KiB read, prefetched one step ahead.  A wave owns one 16-channel n tile
+//   and all 13 M tiles: 52 MFMAs (1664 cycles) per k block against 13 LDS reads and one 16-byte load.
+//   Forward: 64 output channels = 4 waves.  Dgrad (N = 32 input channels): 2 n tiles x 2 K halves (the waves of a
+//   pair take alternate k blocks and are summed through LDS once); the tile is staged through the max-pool /
+//   ReLU gradient (pooled gradient scattered to the saved argmax position) and taps are read flipped.
+//
+// conv5x5_wgrad_f32, v_mfma_f32_32x32x2_f32: dW[tap][ci][co] = sum_pos X[pos + tap][ci] * dY[pos][co]
+//   M = 32 input channels, N = 32-wide halves of 64 output channels, K = positions (two per MFMA).  A workgroup
+//   owns ALL 25 taps x 32 ci x 64 co of its image range: 50 (tap, co half) accumulator tiles over 4 waves
+//   (13/13/12/12), 208 accumulator registers per wave, one wave per SIMD.  Per position pair a wave issues one
+//   B read (dY, shared by its 13 taps) and 13 A reads (X at 13 shifted positions), all conflict-free
+//   ds_read_b32, for 13 MFMAs (832 cycles).  The next image's global loads are in flight during the k-loop.
+//   Split-K over images into per-workgroup slabs, summed in fixed order by reduce_segments / the fused tail.
+#include <type_traits>
+
+#include "f32_common.hpp"
+
+namespace dtf {
+
+constexpr int kF32TileW = 18;
+constexpr int kF32TilePos = 18 * 18;
+constexpr int kF32Pitch = 36;   // floats per position in the igemm tile (32 channels + 4: spreads b128 reads over banks)
+constexpr int kF32TileBytes = kF32TilePos * kF32Pitch * 4;   // 46656
+
+enum { F32_MODE_FWD = 0, F32_MODE_DGRAD = 1 };
+
+// ----------------------------------------------------------------------------------------------------
+//   in   FWD  : x     [B,14,14,KTOT] fp32          DGRAD: gpool [B,7,7,KTOT] fp32 + in_arg [B,7,7,KTOT] u8
+//   wk   fragment-ordered pack for this direction (see pack_conv2_weights_f32)
+//   out  FWD  : pooled [B,7,7,NCTOT] fp32 + out_arg u8      DGRAD: dx [B,14,14,NCTOT] fp32
+// grid = (B, NCTOT / NCW)
+// ----------------------------------------------------------------------------------------------------
+template <int KTOT, int NCTOT, int MODE>
+__global__ __launch_bounds__(256) void conv5x5_igemm_f32(const float* __restrict__ in, const uint8_t* __restrict__ in_arg,
+                                                         const float* __restrict__ wk, const float* __restrict__ bias,
+                                                         float* __restrict__ out, uint8_t* __restrict__ out_arg, int B) {
+  constexpr int KC = 32;
+  constexpr int NCW = (MODE == F32_MODE_FWD) ? 64 : 32;   // output channels per workgroup
+  constexpr int NTN = NCW / 16;                           // n tiles (one per wave column)
+  constexpr int KSPLIT = 4 / NTN;                         // K halves (dgrad)
+  constexpr int NS = 25 * (KC / 16) / KSPLIT;             // k-block steps per wave and K chunk
+  static_assert(KTOT % KC == 0 && NCTOT % NCW == 0, "channel counts must be multiples of the tile");
+  extern __shared__ __attribute__((aligned(16))) float tile[];   // [324][36]
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int ntile = wave % NTN, ksp = wave / NTN;
+  const int b = blockIdx.x, ng = blockIdx.y;
+  const int l16 = lane & 15, g = lane >> 4;
+
+  // A row of this lane in M tile t: window 4t + (l16 >> 2), position q = l16 & 3 (windows past 48 are clamped
+  // and their results discarded)
+  int aoff[13];
+#pragma unroll
+  for (int t = 0; t < 13; ++t) {
+    const int wI = min(4 * t + (l16 >> 2), 48), q = l16 & 3;
+    const int pos = (2 * (wI / 7) + (q >> 1)) * kF32TileW + 2 * (wI % 7) + (q & 1);
+    aoff[t] = pos * kF32Pitch + 4 * g;
+  }
+  f32x4 acc[13];
+#pragma unroll
+  for (int t = 0; t < 13; ++t) acc[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  // zero once: the halo stays zero, the interior is completely rewritten by every K chunk
+  for (int i = tid; i < kF32TileBytes / 16; i += 256) reinterpret_cast<f32x4*>(tile)[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+#pragma unroll 1
+  for (int kc0 = 0; kc0 < KTOT; kc0 += KC) {
+    // ---- stage this chunk's 32 channels (all global loads first: one memory latency per chunk) ----
+    if (MODE == F32_MODE_FWD) {
+      constexpr int NCH = 196 * 8, ROUNDS = (NCH + 255) / 256;
+      f32x4 v[ROUNDS];
+#pragma unroll
+      for (int r = 0; r < ROUNDS; ++r) {
+        const int c = min(tid + r * 256, NCH - 1);
+        v[r] = *reinterpret_cast<const f32x4*>(in + ((size_t)b * 196 + (c >> 3)) * KTOT + kc0 + (c & 7) * 4);
+      }
+      __syncthreads();   // zero fill done / previous chunk consumed
+#pragma unroll
+      for (int r = 0; r < ROUNDS; ++r) {
+        const int c = tid + r * 256;
+        const int pos = c >> 3, ch = c & 7;
+        const int tp = (pos / 14 + 2) * kF32TileW + pos % 14 + 2;
+        if (c < NCH) *reinterpret_cast<f32x4*>(tile + tp * kF32Pitch + ch * 4) = v[r];
+      }
+    } else {
+      constexpr int NCH = 49 * 8, ROUNDS = (NCH + 255) / 256;
+      f32x4 v[ROUNDS];
+      unsigned cd[ROUNDS];
+#pragma unroll
+      for (int r = 0; r < ROUNDS; ++r) {
+        const int c = min(tid + r * 256, NCH - 1);
+        const size_t off = ((size_t)b * 49 + (c >> 3)) * KTOT + kc0 + (c & 7) * 4;
+        v[r] = *reinterpret_cast<const f32x4*>(in + off);
+        cd[r] = *reinterpret_cast<const unsigned*>(in_arg + off);
+      }
+      __syncthreads();
+#pragma unroll
+      for (int r = 0; r < ROUNDS; ++r) {
+        const int c = tid + r * 256;
+        const int pp = c >> 3, ch = c & 7;
+        if (c < NCH) {
+          f32x4 o[4];
+          expand_pool_grad_f32(v[r], cd[r], o);
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            const int tp = (2 * (pp / 7) + (q >> 1) + 2) * kF32TileW + 2 * (pp % 7) + (q & 1) + 2;
+            *reinterpret_cast<f32x4*>(tile + tp * kF32Pitch + ch * 4) = o[q];
+          }
+        }
+      }
+    }
+    __syncthreads();
+
+    // ---- k-loop: step s of this wave <-> (tap, 16-k block kb) ----
+    const float* bbase = wk + ((size_t)(kc0 / 16) * (NCTOT / 16) + ng * NTN + ntile) * 256 + lane * 4;
+    auto step_tap = [&](int s) { return KSPLIT == 1 ? (s >> 1) : s; };
+    auto step_kb = [&](int s) { return KSPLIT == 1 ? (s & 1) : ksp; };
+    auto load_b = [&](int s) -> f32x4 {
+      const int tap = step_tap(s), kb = step_kb(s);
+      const int wtap = (MODE == F32_MODE_DGRAD) ? 24 - tap : tap;
+      return *reinterpret_cast<const f32x4*>(bbase + ((size_t)wtap * (KTOT / 16) + kb) * (NCTOT / 16) * 256);
+    };
+    auto do_step = [&](int s, const f32x4& bf) {
+      const int tap = step_tap(s), kb = step_kb(s);
+      const float* ap = tile + ((tap / 5) * kF32TileW + tap % 5) * kF32Pitch + kb * 16;
+      f32x4 a[13];
+#pragma unroll
+      for (int t = 0; t < 13; ++t) a[t] = *reinterpret_cast<const f32x4*>(ap + aoff[t]);
+#pragma unroll
+      for (int e = 0; e < 4; ++e)
+#pragma unroll
+        for (int t = 0; t < 13; ++t) acc[t] = mfma16f(a[t][e], bf[e], acc[t]);
+    };
+    // B fragment of step s+1 requested before the MFMAs of step s; unconditional (the last step re-loads itself)
+    f32x4 b0 = load_b(0), b1;
+#pragma unroll 1
+    for (int s = 0; s < NS; s += 2) {
+      b1 = load_b(min(s + 1, NS - 1));
+      __builtin_amdgcn_sched_barrier(0);
+      do_step(s, b0);
+      if (s + 1 >= NS) break;
+      b0 = load_b(min(s + 2, NS - 1));
+      __builtin_amdgcn_sched_barrier(0);
+      do_step(s + 1, b1);
+    }
+  }
+
+  // ---- K halves summed through LDS (dgrad) ----
+  if (KSPLIT == 2) {
+    __syncthreads();   // every wave is done with the tile
+    f32x4* red = reinterpret_cast<f32x4*>(tile);   // [ntile][13][64 lanes]
+    if (ksp == 1) {
+#pragma unroll
+      for (int t = 0; t < 13; ++t) red[(ntile * 13 + t) * 64 + lane] = acc[t];
+    }
+    __syncthreads();
+    if (ksp == 1) return;
+#pragma unroll
+    for (int t = 0; t < 13; ++t) acc[t] += red[(ntile * 13 + t) * 64 + lane];
+  }
+
+  // ---- epilogue.  C/D map: lane holds rows 4g + r -> window 4t + g, q = r; column l16 ----
+  const int n = ng * NCW + ntile * 16 + l16;
+  if (MODE == F32_MODE_FWD) {
+    const float bv = bias[n];
+#pragma unroll
+    for (int t = 0; t < 13; ++t) {
+      const int wI = 4 * t + g;
+      if (wI < 49) {
+        const f32x4 v = acc[t];
+        float best = v[0];
+        int bi = 0;
+        if (v[1] > best) { best = v[1]; bi = 1; }
+        if (v[2] > best) { best = v[2]; bi = 2; }
+        if (v[3] > best) { best = v[3]; bi = 3; }
+        const float o = fmaxf(best + bv, 0.f);
+        const size_t off = ((size_t)b * 49 + wI) * NCTOT + n;
+        out[off] = o;
+        out_arg[off] = (uint8_t)(o > 0.f ? bi : (int)kPoolDead);
+      }
+    }
+  } else {
+#pragma unroll
+    for (int t = 0; t < 13; ++t) {
+      const int wI = 4 * t + g;
+      if (wI < 49) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int y = 2 * (wI / 7) + (r >> 1), x = 2 * (wI % 7) + (r & 1);
+          out[((size_t)b * 196 + y * 14 + x) * NCTOT + n] = acc[t][r];
+        }
+      }
+    }
+  }
+}
+
+// ----------------------------------------------------------------------------------------------------
+// Fragment-ordered fp32 packs of w = HWIO [25][cin][cout] for conv5x5_igemm_f32: one contiguous 1 KiB block per
+// (tap, 16-wide k block, 16-wide n tile); lane l = 16*g + n holds its four k = 4g .. 4g+3 consecutively.
+//   fwd   (k = ci, n = co): F[((tap*(cin/16)  + ci/16)*(cout/16) + co/16)*256 + (((ci%16)/4)*16 + co%16)*4 + ci%4]
+//   dgrad (k = co, n = ci): D[((tap*(cout/16) + co/16)*(cin/16)  + ci/16)*256 + (((co%16)/4)*16 + ci%16)*4 + co%4]
+// packed = [F | D], 25*cin*cout floats each.
+// ----------------------------------------------------------------------------------------------------
+__host__ __device__ __forceinline__ long conv2_f32_pack_fwd_index(int tap, int ci, int co, int cin, int cout) {
+  return (((long)tap * (cin / 16) + ci / 16) * (cout / 16) + co / 16) * 256 + (((ci % 16) / 4) * 16 + co % 16) * 4 + ci % 4;
+}
+__host__ __device__ __forceinline__ long conv2_f32_pack_dgrad_index(int tap, int ci, int co, int cin, int cout) {
+  return (((long)tap * (cout / 16) + co / 16) * (cin / 16) + ci / 16) * 256 + (((co % 16) / 4) * 16 + ci % 16) * 4 + co % 4;
+}
+
+__global__ __launch_bounds__(256) void pack_conv2_weights_f32(const float* __restrict__ w, float* __restrict__ packed,
+                                                              int cin, int cout) {
+  const long n = 25L * cin * cout;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+    const int tap = (int)(i / (cin * cout)), rem = (int)(i % (cin * cout));
+    const int ci = rem / cout, co = rem % cout;
+    const float v = w[i];
+    packed[conv2_f32_pack_fwd_index(tap, ci, co, cin, cout)] = v;
+    packed[n + conv2_f32_pack_dgrad_index(tap, ci, co, cin, cout)] = v;
+  }
+}
+
+// ----------------------------------------------------------------------------------------------------
+// wgrad.  grid = (G image ranges, (CIN/32) * (COUT/64) channel tiles)
+//   x [B,14,14,CIN] fp32, gpool [B,7,7,COUT] fp32, arg [B,7,7,COUT] u8
+//   part [G][25*CIN*COUT + COUT] fp32 slabs (HWIO order, then the bias gradient)
+// ----------------------------------------------------------------------------------------------------
+constexpr int kWgfXFloats = kF32TilePos * 32;   // zero-haloed input tile [324][32 ci]
+constexpr int kWgfDyFloats = 196 * 64;          // max-pool/ReLU-expanded output gradient [196][64 co]
+constexpr int kWgfBytes = (kWgfXFloats + kWgfDyFloats) * 4;   // 91648
+
+template <int CIN, int COUT>
+__global__ __launch_bounds__(256, 1) void conv5x5_wgrad_f32(const float* __restrict__ x, const float* __restrict__ gpool,
+                                                            const uint8_t* __restrict__ arg, float* __restrict__ part,
+                                                            int B, int imgs_per_block) {
+  extern __shared__ __attribute__((aligned(16))) float wsm[];
+  float* xt = wsm;
+  float* dyt = wsm + kWgfXFloats;
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int cohalf = wave & 1, tpar = wave >> 1;   // this wave's taps: tpar, tpar + 2, ...
+  const int cic = blockIdx.y % (CIN / 32), coc = blockIdx.y / (CIN / 32);
+  const int i32 = lane & 31, h = lane >> 5;
+  const int b_begin = blockIdx.x * imgs_per_block, b_end = min(B, b_begin + imgs_per_block);
+
+  f32x16 acc[13];
+#pragma unroll
+  for (int t = 0; t < 13; ++t)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+  f32x4 bsum = {0.f, 0.f, 0.f, 0.f};   // bias gradient of channels 4*(tid & 15) .. +3 over this thread's staging items
+
+  for (int i = tid; i < kWgfXFloats / 4; i += 256) reinterpret_cast<f32x4*>(xt)[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  constexpr int XCH = 196 * 8, XR = (XCH + 255) / 256;     // 16-byte chunks of the input tile / rounds per thread
+  constexpr int DCH = 49 * 16, DR = (DCH + 255) / 256;     // (pooled position, 4-channel chunk) items
+  f32x4 xr[XR], gr[DR];
+  unsigned cr[DR];
+  // raw buffer loads: one 32-bit per-thread offset per round (computed once) + a scalar per-image offset, instead of
+  // a 64-bit address pair per load -- this kernel has 208 accumulator registers per lane to keep out of scratch
+  const __amdgpu_buffer_rsrc_t rX = make_rsrc(x, (size_t)B * 196 * CIN * 4);
+  const __amdgpu_buffer_rsrc_t rG = make_rsrc(gpool, (size_t)B * 49 * COUT * 4);
+  const __amdgpu_buffer_rsrc_t rA = make_rsrc(arg, (size_t)B * 49 * COUT);
+  uint32_t vx[XR], vd[DR];
+#pragma unroll
+  for (int r = 0; r < XR; ++r) {
+    const int c = min(tid + r * 256, XCH - 1);
+    vx[r] = (uint32_t)((c >> 3) * CIN + cic * 32 + (c & 7) * 4) * 4u;
+  }
+#pragma unroll
+  for (int r = 0; r < DR; ++r) {
+    const int c = min(tid + r * 256, DCH - 1);
+    vd[r] = (uint32_t)((c >> 4) * COUT + coc * 64 + (c & 15) * 4);
+  }
+  auto prefetch = [&](int b) {
+#pragma unroll
+    for (int r = 0; r < XR; ++r) xr[r] = buf_load16f(rX, vx[r], (uint32_t)b * (196u * CIN * 4u));
+#pragma unroll
+    for (int r = 0; r < DR; ++r) {
+      gr[r] = buf_load16f(rG, vd[r] * 4u, (uint32_t)b * (49u * COUT * 4u));
+      cr[r] = (unsigned)__builtin_amdgcn_raw_buffer_load_b32(rA, (int)vd[r], (int)((uint32_t)b * (49u * COUT)), 0);
+    }
+  };
+  auto stage = [&]() {
+#pragma unroll
+    for (int r = 0; r < XR; ++r) {
+      const int c = tid + r * 256;
+      const int pos = c >> 3, ch = c & 7;
+      const int tp = (pos / 14 + 2) * kF32TileW + pos % 14 + 2;
+      if (c < XCH) *reinterpret_cast<f32x4*>(xt + tp * 32 + ch * 4) = xr[r];
+    }
+#pragma unroll
+    for (int r = 0; r < DR; ++r) {
+      const int c = tid + r * 256;
+      const int pp = c >> 4, c4 = c & 15;
+      if (c < DCH) {
+        f32x4 o[4];
+        expand_pool_grad_f32(gr[r], cr[r], o);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const int pos = (2 * (pp / 7) + (q >> 1)) * 14 + 2 * (pp % 7) + (q & 1);
+          *reinterpret_cast<f32x4*>(dyt + pos * 64 + c4 * 4) = o[q];
+        }
+        bsum += (o[0] + o[1]) + (o[2] + o[3]);
+      }
+    }
+  };
+  // one position pair (two k) per MFMA: lane half h takes position 2*xj + h of row y.  Two fragment sets: the 14
+  // LDS reads of pair xj+1 are issued before the 13 MFMAs of pair xj (one wave per SIMD: nothing else hides them).
+  auto kloop = [&](auto TP) {
+    constexpr int tp_ = decltype(TP)::value;
+    auto load = [&](const float* pa, const float* pb, int xj, float (&av)[13], float& bv) {
+      bv = pb[2 * xj * 64];
+#pragma unroll
+      for (int j = 0; j < 13; ++j) {
+        const int tap = (tp_ + 2 * j) < 25 ? (tp_ + 2 * j) : 23;   // the 13th tap of the odd group is a discarded repeat
+        av[j] = pa[(2 * xj + (tap / 5) * kF32TileW + tap % 5) * 32];
+      }
+    };
+    auto mma = [&](const float (&av)[13], float bv) {
+#pragma unroll
+      for (int j = 0; j < 13; ++j) acc[j] = mfma32f(av[j], bv, acc[j]);
+    };
+#pragma unroll 1
+    for (int y = 0; y < 14; ++y) {
+      const float* pa = xt + (y * kF32TileW + h) * 32 + i32;
+      const float* pb = dyt + (y * 14 + h) * 64 + cohalf * 32 + i32;
+      float a0[13], a1[13], b0, b1;
+      load(pa, pb, 0, a0, b0);
+#pragma unroll
+      for (int xj = 0; xj < 6; xj += 2) {
+        load(pa, pb, xj + 1, a1, b1);
+        __builtin_amdgcn_sched_barrier(0);
+        mma(a0, b0);
+        __builtin_amdgcn_sched_barrier(0);
+        load(pa, pb, xj + 2, a0, b0);
+        __builtin_amdgcn_sched_barrier(0);
+        mma(a1, b1);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      mma(a0, b0);
+    }
+  };
+
+  // The whole image loop and the slab write are instantiated per tap parity (wave-uniform branch taken once): with
+  // the branch around the k-loop only, the accumulators of the two instantiations met in phi nodes that the
+  // register allocator kept in VGPRs, i.e. 208 v_accvgpr moves each way per image and spills in the staging code.
+  float* slab = part + (size_t)blockIdx.x * (25 * CIN * COUT + COUT);
+  auto body = [&](auto TP) {
+    constexpr int tp_ = decltype(TP)::value;
+    if (b_begin < b_end) prefetch(b_begin);
+    for (int b = b_begin; b < b_end; ++b) {
+      __syncthreads();   // zero fill done / previous image's k-loop finished
+      stage();
+      __syncthreads();
+      if (b + 1 < b_end) prefetch(b + 1);   // in flight during this image's k-loop
+      __builtin_amdgcn_sched_barrier(0);
+      kloop(TP);
+    }
+    // ---- slab: dW rows ci = (r & 3) + 8 * (r >> 2) + 4 * h, column co = i32 of this wave's half ----
+#pragma unroll
+    for (int j = 0; j < 13; ++j) {
+      const int tap = tp_ + 2 * j;
+      if (tap < 25) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int ci = cic * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+          slab[((size_t)tap * CIN + ci) * COUT + coc * 64 + cohalf * 32 + i32] = acc[j][r];
+        }
+      }
+    }
+  };
+  if (tpar == 0) body(std::integral_constant<int, 0>{});
+  else body(std::integral_constant<int, 1>{});
+  // bias gradient: thread t holds channels 4 * (t & 15) .. +3; fixed-order sum of the 16 threads per chunk
+  __syncthreads();
+  f32x4* red = reinterpret_cast<f32x4*>(wsm);
+  red[tid] = bsum;
+  __syncthreads();
+  if (cic == 0 && tid < 64) {
+    float s = 0.f;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) s += red[k * 16 + (tid >> 2)][tid & 3];
+    slab[25 * CIN * COUT + coc * 64 + tid] = s;
+  }
+}
+
+}  // namespace dtf
+
+using namespace dtf;
+
+template <int KTOT, int NCTOT, int MODE>
+static int launch_igemm_f32(const void* in, const void* in_arg, const void* wk, const void* bias, void* out, void* out_arg,
+                            int B, hipStream_t s) {
+  auto kern = conv5x5_igemm_f32<KTOT, NCTOT, MODE>;
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, kF32TileBytes);
+    attr_set = true;
+  }
+  constexpr int NCW = (MODE == F32_MODE_FWD) ? 64 : 32;
+  hipLaunchKernelGGL(kern, dim3(B, NCTOT / NCW), dim3(256), kF32TileBytes, s, (const float*)in, (const uint8_t*)in_arg,
+                     (const float*)wk, (const float*)bias, (float*)out, (uint8_t*)out_arg, B);
+  return (int)hipGetLastError();
+}
+
+template <int CIN, int COUT>
+static int launch_wgrad_f32(const void* x, const void* gpool, const void* arg, void* part, int B, int G, hipStream_t s) {
+  auto kern = conv5x5_wgrad_f32<CIN, COUT>;
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, kWgfBytes);
+    attr_set = true;
+  }
+  const int ipb = (B + G - 1) / G;
+  hipLaunchKernelGGL(kern, dim3(G, (CIN / 32) * (COUT / 64)), dim3(256), kWgfBytes, s, (const float*)x, (const float*)gpool,
+                     (const uint8_t*)arg, (float*)part, B, ipb);
+  return (int)hipGetLastError();
+}
+
+extern "C" {
+
+// packed (2 * 25*cin*cout fp32) = [fwd pack | dgrad pack] of the fp32 HWIO weights w
+int dtf_conv2_f32_pack_weights(const void* w, void* packed, int cin, int cout, hipStream_t s) {
+  if ((cin % 16) || (cout % 16)) return -3;
+  hipLaunchKernelGGL(pack_conv2_weights_f32, dim3((25 * cin * cout + 255) / 256), dim3(256), 0, s, (const float*)w,
+                     (float*)packed, cin, cout);
+  return (int)hipGetLastError();
+}
+
+// x [B,14,14,cin] -> pooled [B,7,7,cout] fp32 + arg u8; wpack = fwd pack
+int dtf_conv2_f32_fwd(const void* x, const void* wpack, const void* bias, void* pooled, void* arg, int B, int cin, int cout,
+                      hipStream_t s) {
+  if (B <= 0) return -2;
+  if (cin == 32 && cout == 64) return launch_igemm_f32<32, 64, F32_MODE_FWD>(x, nullptr, wpack, bias, pooled, arg, B, s);
+  if (cin == 128 && cout == 256) return launch_igemm_f32<128, 256, F32_MODE_FWD>(x, nullptr, wpack, bias, pooled, arg, B, s);
+  return -1;
+}
+
+// gpool [B,7,7,cout] (+ arg code) -> dx [B,14,14,cin]; wpack = dgrad pack (second half of dtf_conv2_f32_pack_weights)
+int dtf_conv2_f32_dgrad(const void* gpool, const void* arg, const void* wpack, void* dx, int B, int cin, int cout,
+                        hipStream_t s) {
+  if (B <= 0) return -2;
+  if (cin == 32 && cout == 64) return launch_igemm_f32<64, 32, F32_MODE_DGRAD>(gpool, arg, wpack, nullptr, dx, nullptr, B, s);
+  if (cin == 128 && cout == 256) return launch_igemm_f32<256, 128, F32_MODE_DGRAD>(gpool, arg, wpack, nullptr, dx, nullptr, B, s);
+  return -1;
+}
+
+// part [G][25*cin*cout + cout] fp32 slabs
+int dtf_conv2_f32_wgrad(const void* x, const void* gpool, const void* arg, void* part, int B, int cin, int cout, int G,
+                        hipStream_t s) {
+  if (G <= 0 || B <= 0) return -2;
+  if (cin == 32 && cout == 64) return launch_wgrad_f32<32, 64>(x, gpool, arg, part, B, G, s);
+  if (cin == 128 && cout == 256) return launch_wgrad_f32<128, 256>(x, gpool, arg, part, B, G, s);
+  return -1;
+}
+
+}  // extern "C"

@@ -25,29 +25,6 @@ namespace dtf {
 
 enum { EPI_STORE = 0, EPI_BIAS_RELU_DROPOUT = 1, EPI_NOSTORE_DIAG = 2 };
 
-// XCD-aware tile assignment.  Workgroups are dealt round-robin over the 8 XCDs (private 4 MiB
-// L2 each), so linear ids L and L+8 share an L2.  These GEMMs are small enough that every tile is
-// resident at once and the whole grid marches through K in step; what bounds them is fabric/HBM
-// traffic (measured: ~11 B/clk/CU, i.e. operand panels re-fetched by every XCD).  Giving each XCD a
-// compact BH x (chunk/BH) rectangle of tiles makes its L2 fetch each A/B panel once per rectangle
-// instead of once per tile.  Bijective for any tile count (guide T1).
-__device__ __forceinline__ void xcd_tile_linear(int L, int gx, int gy, int& tx, int& ty) {
-  constexpr int NX = 8, BH = 4;
-  const int total = gx * gy;
-  const int xcd = L % NX, slot = L / NX;
-  const int q = total / NX, r = total % NX;
-  const int idx = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + slot;
-  // banded column-major order: bands of BH tile rows, walked column by column
-  const int band = idx / (BH * gx);
-  const int rem = idx - band * BH * gx;
-  const int h = min(BH, gy - band * BH);
-  tx = rem / h;
-  ty = band * BH + rem % h;
-}
-__device__ __forceinline__ void xcd_tile(int gx, int gy, int& tx, int& ty) {
-  xcd_tile_linear(blockIdx.x + gx * blockIdx.y, gx, gy, tx, ty);
-}
-
 // ---------------------------------------------------------------------------------------------
 // Shared software pipeline.  One K tile (BK = 64) per phase, double-buffered LDS, two register
 // sets: the global loads of tile t+2 are issued at the head of phase t and written to LDS at the

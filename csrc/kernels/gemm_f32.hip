@@ -1,0 +1,234 @@
+// Exact-fp32 GEMMs of the dense layers on the f32-input matrix cores (v_mfma_f32_32x32x2_f32), the
+// --dtype fp32 counterpart of gemm.hip (reference .idea/MNISTDist.py:83-84 fc1 MatMul and the MatMul
+// gradient ops autodiff generates from it).  Operands and results are fp32 in memory; no shadow copies.
+//
+//   nn (fc1 forward, split-K)  part[z][M,N] = A[M,Kz] . B[Kz,N]        A K-contiguous, B = wd1 [in,out] as TF stores it
+//   nt (fc1 dgrad)             C[M,N]       = A[M,K]  . B[N,K]^T       both K-contiguous (B = wd1 itself)
+//   tn (fc1 wgrad)             C[M,N]       = A[K,M]^T . B[K,N]        both K-slow (K = batch); optional fused SGD
+//
+// Tiling: 128x128x32, 512 threads = 8 waves as 2 (M) x 4 (N), wave tile 64x32 = two 32x32 accumulators.
+// Two waves per SIMD: one issues its 64-cycle MFMAs while the other reads fragments or waits at the barrier.
+// LDS keeps each operand in its global orientation (coalesced 16-byte staging, no transposes):
+//   K-contiguous: [row][32 + 4] floats -- a lane reads its row's four k (k = 8*kb + 4*h + e) with ONE
+//                 ds_read_b128; the 36-float pitch makes the 16-lane groups of that read conflict-free;
+//   K-slow:       [k][128] floats      -- the same four k are four ds_read_b32 (32 consecutive columns
+//                 per half-wave: conflict-free).
+// Register-prefetched double buffering, one barrier per K tile: a tile is 2048 cycles of MFMA per wave
+// against ~150 cycles of LDS traffic, so this simple pipeline already leaves the matrix pipe as the bound.
+#include "f32_common.hpp"
+
+namespace dtf {
+
+enum { F32_KCONTIG = 0, F32_KSLOW = 1 };
+enum { F32_EPI_STORE = 0, F32_EPI_SGD = 1 };
+
+template <int LA, int LB, int EPI>
+__global__ __launch_bounds__(512) void gemm_f32(const float* A, const float* Bm, float* __restrict__ C, int M, int N,
+                                                int K, int lda, int ldb, int ldc, int tiles_per_split,
+                                                const float* __restrict__ hyper) {
+  constexpr int BM = 128, BN = 128, BK = 32, NT = 512;
+  constexpr int PK = BK + 4;
+  constexpr int A_FLOATS = (LA == F32_KCONTIG) ? BM * PK : BK * BM;
+  constexpr int B_FLOATS = (LB == F32_KCONTIG) ? BN * PK : BK * BN;
+  extern __shared__ __attribute__((aligned(16))) float smem_f32[];
+  float* sA = smem_f32;                  // [2][A_FLOATS]
+  float* sB = smem_f32 + 2 * A_FLOATS;   // [2][B_FLOATS]
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave >> 2, wn = wave & 3;
+  const int i32 = lane & 31, h = lane >> 5;
+  int tile_x, tile_y;
+  xcd_tile(gridDim.x, gridDim.y, tile_x, tile_y);
+  const int m0 = tile_y * BM, n0 = tile_x * BN;
+  const int T_all = (K + BK - 1) / BK;
+  const int t_begin = blockIdx.z * tiles_per_split;
+  const int T = min(T_all, t_begin + tiles_per_split) - t_begin;
+
+  f32x16 acc[2];
+#pragma unroll
+  for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[mt][r] = 0.f;
+
+  // unconditional raw buffer loads: rows past the end of the matrix read as zero
+  const __amdgpu_buffer_rsrc_t rA = make_rsrc(A, (LA == F32_KCONTIG ? (size_t)M : (size_t)K) * lda * 4);
+  const __amdgpu_buffer_rsrc_t rB = make_rsrc(Bm, (LB == F32_KCONTIG ? (size_t)N : (size_t)K) * ldb * 4);
+  uint32_t va[2], vb[2];
+  int la[2], lb[2];   // LDS float offsets of this thread's two chunks per operand
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    const int c = tid + j * NT;
+    if (LA == F32_KCONTIG) {
+      const int row = c >> 3, slot = c & 7;
+      va[j] = (uint32_t)(m0 + row) * (uint32_t)(lda * 4) + slot * 16 + (uint32_t)t_begin * (BK * 4);
+      la[j] = row * PK + slot * 4;
+    } else {
+      const int row = c >> 5, slot = c & 31;
+      va[j] = (uint32_t)(t_begin * BK + row) * (uint32_t)(lda * 4) + (uint32_t)(m0 + slot * 4) * 4;
+      la[j] = row * BM + slot * 4;
+    }
+    if (LB == F32_KCONTIG) {
+      const int row = c >> 3, slot = c & 7;
+      vb[j] = (uint32_t)(n0 + row) * (uint32_t)(ldb * 4) + slot * 16 + (uint32_t)t_begin * (BK * 4);
+      lb[j] = row * PK + slot * 4;
+    } else {
+      const int row = c >> 5, slot = c & 31;
+      vb[j] = (uint32_t)(t_begin * BK + row) * (uint32_t)(ldb * 4) + (uint32_t)(n0 + slot * 4) * 4;
+      lb[j] = row * BN + slot * 4;
+    }
+  }
+  const uint32_t stepA = (LA == F32_KCONTIG) ? BK * 4 : (uint32_t)lda * (BK * 4);
+  const uint32_t stepB = (LB == F32_KCONTIG) ? BK * 4 : (uint32_t)ldb * (BK * 4);
+
+  f32x4 ra[2], rb[2];
+  auto gload = [&](int t) {
+#pragma unroll
+    for (int j = 0; j < 2; ++j) ra[j] = buf_load16f(rA, va[j], (uint32_t)t * stepA);
+#pragma unroll
+    for (int j = 0; j < 2; ++j) rb[j] = buf_load16f(rB, vb[j], (uint32_t)t * stepB);
+  };
+  auto swrite = [&](int buf) {
+#pragma unroll
+    for (int j = 0; j < 2; ++j) *reinterpret_cast<f32x4*>(sA + buf * A_FLOATS + la[j]) = ra[j];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) *reinterpret_cast<f32x4*>(sB + buf * B_FLOATS + lb[j]) = rb[j];
+  };
+  auto compute = [&](int buf) {
+    const float* a = sA + buf * A_FLOATS;
+    const float* b = sB + buf * B_FLOATS;
+#pragma unroll
+    for (int kb = 0; kb < BK / 8; ++kb) {
+      f32x4 av[2], bv;
+#pragma unroll
+      for (int mt = 0; mt < 2; ++mt) {
+        const int row = wm * 64 + mt * 32 + i32;
+        if (LA == F32_KCONTIG) {
+          av[mt] = *reinterpret_cast<const f32x4*>(a + row * PK + kb * 8 + 4 * h);
+        } else {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) av[mt][e] = a[(kb * 8 + 4 * h + e) * BM + row];
+        }
+      }
+      {
+        const int col = wn * 32 + i32;
+        if (LB == F32_KCONTIG) {
+          bv = *reinterpret_cast<const f32x4*>(b + col * PK + kb * 8 + 4 * h);
+        } else {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) bv[e] = b[(kb * 8 + 4 * h + e) * BN + col];
+        }
+      }
+#pragma unroll
+      for (int e = 0; e < 4; ++e)
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt) acc[mt] = mfma32f(av[mt][e], bv[e], acc[mt]);
+    }
+  };
+
+  if (T > 0) {
+    gload(0);
+    swrite(0);
+    __syncthreads();
+    for (int t = 0; t < T; ++t) {
+      // in flight during this tile's MFMAs.  Unconditional (exact wait counts): past the last tile the loads
+      // return in-range data or zeros that are written to the idle buffer and never multiplied
+      gload(t + 1);
+      __builtin_amdgcn_sched_barrier(0);
+      compute(t & 1);
+      swrite((t + 1) & 1);
+      __syncthreads();
+    }
+  }
+
+  // C/D map of the 32x32 tile: col = lane & 31, row = (r & 3) + 8 * (r >> 2) + 4 * h
+  float* Cz = C + (EPI == F32_EPI_STORE ? (size_t)blockIdx.z * M * ldc : 0);
+  const int col = n0 + wn * 32 + i32;
+  if (col < N) {
+    if (EPI == F32_EPI_SGD) {
+      // fused update of the fp32 weight: w -= lr * g straight from the accumulators (the gradient is never
+      // written).  All weights of the lane are requested before the first store (a load/store chain otherwise).
+      const float lr = hyper[0] * hyper[4];
+      float w[2][16];
+#pragma unroll
+      for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int row = min(m0 + wm * 64 + mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * h, M - 1);
+          w[mt][r] = __builtin_nontemporal_load(Cz + (size_t)row * ldc + col);
+        }
+#pragma unroll
+      for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int row = m0 + wm * 64 + mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+          if (row < M) Cz[(size_t)row * ldc + col] = fmaf(-lr, acc[mt][r], w[mt][r]);
+        }
+    } else {
+#pragma unroll
+      for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int row = m0 + wm * 64 + mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+          if (row < M) Cz[(size_t)row * ldc + col] = acc[mt][r];
+        }
+    }
+  }
+}
+
+template <int LA, int LB, int EPI>
+static int launch_gemm_f32(const void* A, const void* B, void* C, int M, int N, int K, int lda, int ldb, int ldc, int S,
+                           int tps, const void* hyper, hipStream_t s) {
+  constexpr int PK = 36;
+  constexpr size_t lds = (2 * ((LA == F32_KCONTIG) ? 128 * PK : 32 * 128) + 2 * ((LB == F32_KCONTIG) ? 128 * PK : 32 * 128)) * 4;
+  auto kern = gemm_f32<LA, LB, EPI>;
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    attr_set = true;
+  }
+  hipLaunchKernelGGL(kern, dim3((N + 127) / 128, (M + 127) / 128, S), dim3(512), lds, s, (const float*)A, (const float*)B,
+                     (float*)C, M, N, K, lda, ldb, ldc, tps, (const float*)hyper);
+  return (int)hipGetLastError();
+}
+
+}  // namespace dtf
+
+using namespace dtf;
+
+extern "C" {
+
+// fc1 forward, GEMM part: part[S][M][N] fp32 partial products of A[M,K] . B[K,N] (bias/ReLU/dropout run in the head
+// kernel).  Returns the number of splits used (> 0) or a negative error; S <= 0 picks ~256 workgroups.
+int dtf_gemm_f32_nn_partial(const void* A, const void* B, void* part, int M, int N, int K, int lda, int ldb, int S,
+                            hipStream_t s) {
+  if ((K & 31) || (lda & 3) || (ldb & 3) || (N & 3)) return -3;
+  const int T = K / 32;
+  const int tiles = ((M + 127) / 128) * ((N + 127) / 128);
+  if (S <= 0) {
+    S = (256 + tiles - 1) / tiles;
+    if (S > 8) S = 8;
+  }
+  if (S > T) S = T;
+  const int tps = (T + S - 1) / S;
+  S = (T + tps - 1) / tps;
+  const int rc = launch_gemm_f32<F32_KCONTIG, F32_KSLOW, F32_EPI_STORE>(A, B, part, M, N, K, lda, ldb, N, S, tps, nullptr, s);
+  return rc == 0 ? S : -1;
+}
+
+// C[M,N] = A[M,K] . B[N,K]^T  (fc1 dgrad: A = dh1, B = wd1)
+int dtf_gemm_f32_nt(const void* A, const void* B, void* C, int M, int N, int K, int lda, int ldb, int ldc, hipStream_t s) {
+  if ((K & 31) || (lda & 3) || (ldb & 3)) return -3;
+  return launch_gemm_f32<F32_KCONTIG, F32_KCONTIG, F32_EPI_STORE>(A, B, C, M, N, K, lda, ldb, ldc, 1, K / 32, nullptr, s);
+}
+
+// C[M,N] = A[K,M]^T . B[K,N]  (fc1 wgrad: A = flat, B = dh1, K = batch); hyper != NULL: C is the fp32 weight and the
+// product its gradient, applied in place as w -= hyper[0] * hyper[4] * g (single-GPU SGD; the gradient is not stored)
+int dtf_gemm_f32_tn(const void* A, const void* B, void* C, int M, int N, int K, int lda, int ldb, int ldc,
+                    const void* hyper, hipStream_t s) {
+  if ((lda & 3) || (ldb & 3) || (M & 3) || (N & 3)) return -3;
+  const int T = (K + 31) / 32;
+  if (hyper) return launch_gemm_f32<F32_KSLOW, F32_KSLOW, F32_EPI_SGD>(A, B, C, M, N, K, lda, ldb, ldc, 1, T, hyper, s);
+  return launch_gemm_f32<F32_KSLOW, F32_KSLOW, F32_EPI_STORE>(A, B, C, M, N, K, lda, ldb, ldc, 1, T, nullptr, s);
+}
+
+}  // extern "C"

@@ -55,11 +55,12 @@ struct Fc1Epilogue {
 // One 256-thread workgroup per batch row (grid-stride), thread t owns hidden units 4t..4t+3 of every
 // 1024-wide slice: 4 waves per row instead of one, so a CU holds 16+ independent load streams
 // (one wave per row left each SIMD with a single latency-bound wave).
+template <typename AT>
 __global__ __launch_bounds__(256) void head_fwd_bwd(
-    bf16* __restrict__ h1, Fc1Epilogue epi, const float* __restrict__ wT, const float* __restrict__ bias,
+    AT* __restrict__ h1, Fc1Epilogue epi, const float* __restrict__ wT, const float* __restrict__ bias,
     const int* __restrict__ labels, const int* __restrict__ idx, float* __restrict__ logits_out,
     float* __restrict__ loss_rows, float* __restrict__ correct_rows, float* __restrict__ dlogits,
-    bf16* __restrict__ da, int B, int H, float grad_scale, float inv_keep, int backward) {
+    AT* __restrict__ da, int B, int H, float grad_scale, float inv_keep, int backward) {
   __shared__ __attribute__((aligned(16))) float zred[kCls][4];   // [class][wave]: one 16-byte read per class
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const bool do_drop = epi.part && epi.drop.keep_prob < 1.0f;
@@ -70,7 +71,7 @@ __global__ __launch_bounds__(256) void head_fwd_bwd(
     DTF_HSTAMP(0);
     // two dependent loads (gather index, then label): requested first, needed only after the reductions
     const int label = labels[idx ? idx[b] : b];
-    bf16* hrow = h1 + (size_t)b * H;
+    AT* hrow = h1 + (size_t)b * H;
     float z[kCls];
 #pragma unroll
     for (int c = 0; c < kCls; ++c) z[c] = 0.f;
@@ -81,19 +82,15 @@ __global__ __launch_bounds__(256) void head_fwd_bwd(
         hf = *reinterpret_cast<const f32x4*>(p);
         for (int sI = 1; sI < epi.S; ++sI) hf += *reinterpret_cast<const f32x4*>(p + (size_t)sI * BH);
         const f32x4 bv = *reinterpret_cast<const f32x4*>(epi.bias1 + j0);
-        bf16x4 o;
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
           float v = fmaxf(hf[e] + bv[e], 0.f);
           if (do_drop) v *= dropout_scale(epi.drop, drop_off, (uint64_t)b * (uint64_t)H + j0 + e);
-          o[e] = (bf16)v;
-          hf[e] = (float)o[e];   // downstream math sees exactly the stored bf16 value
+          hf[e] = (float)(AT)v;   // downstream math sees exactly the stored value (bf16-rounded on the mixed path)
         }
-        *reinterpret_cast<bf16x4*>(hrow + j0) = o;
+        store_act4(hrow + j0, hf);
       } else {
-        const bf16x4 hv = *reinterpret_cast<const bf16x4*>(hrow + j0);
-#pragma unroll
-        for (int e = 0; e < 4; ++e) hf[e] = (float)hv[e];
+        hf = load_act4(hrow + j0);
       }
 #pragma unroll
       for (int c = 0; c < kCls; ++c) {
@@ -153,9 +150,9 @@ __global__ __launch_bounds__(256) void head_fwd_bwd(
       for (int c = 0; c < kCls; ++c) v = (c == tid) ? dl[c] : v;
       dlogits[(size_t)b * kCls + tid] = v;
     }
-    bf16* drow = da + (size_t)b * H;
+    AT* drow = da + (size_t)b * H;
     for (int j0 = tid * 4; j0 < H; j0 += 1024) {
-      const bf16x4 hv = *reinterpret_cast<const bf16x4*>(hrow + j0);   // own earlier store when fused
+      const f32x4 hv = load_act4(hrow + j0);   // own earlier store when fused
       f32x4 sacc = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
       for (int c = 0; c < kCls; ++c) {
@@ -163,10 +160,10 @@ __global__ __launch_bounds__(256) void head_fwd_bwd(
 #pragma unroll
         for (int e = 0; e < 4; ++e) sacc[e] = fmaf(dl[c], wv[e], sacc[e]);
       }
-      bf16x4 o;
+      f32x4 o;
 #pragma unroll
-      for (int e = 0; e < 4; ++e) o[e] = (bf16)(((float)hv[e] > 0.f) ? sacc[e] * inv_keep : 0.f);
-      *reinterpret_cast<bf16x4*>(drow + j0) = o;
+      for (int e = 0; e < 4; ++e) o[e] = (hv[e] > 0.f) ? sacc[e] * inv_keep : 0.f;
+      store_act4(drow + j0, o);
     }
     DTF_HSTAMP(4);   // da row stored
   }
@@ -180,9 +177,10 @@ __global__ __launch_bounds__(256) void transpose_head_w(const float* __restrict_
 
 // grid = (H/256, KS).  slab layout per k-split: [H*10 dW_out][12: db_out padded][H db_d1]
 // (body in head_wgrad_core.hpp: the training step runs it inside the fc1 dgrad GEMM launch instead)
-__global__ __launch_bounds__(256) void head_wgrad(HeadWgradArgs a) {
+template <typename AT>
+__global__ __launch_bounds__(256) void head_wgrad(HeadWgradArgsT<AT> a) {
   __shared__ __attribute__((aligned(16))) float red[head_wgrad_lds_floats<4>()];
-  head_wgrad_block<4>(a, blockIdx.x, blockIdx.y, red);
+  head_wgrad_block<4, AT>(a, blockIdx.x, blockIdx.y, red);
 }
 
 }  // namespace dtf
@@ -196,27 +194,37 @@ extern "C" int dtf_head_set_timing_buf(void* p) {
 }
 #endif
 
-extern "C" {
-
+template <typename AT>
 static int head_launch(void* h1, Fc1Epilogue epi, const void* wT, const void* bias, const void* labels,
                        const void* idx, void* logits_out, void* loss_rows, void* correct_rows, void* dlogits, void* da,
                        int B, int H, float grad_scale, float inv_keep, int backward, hipStream_t s) {
   if (H % 4) return -3;
   int blocks = B < 4096 ? B : 4096;
-  hipLaunchKernelGGL(head_fwd_bwd, dim3(blocks), dim3(256), 0, s, (bf16*)h1, epi, (const float*)wT,
+  hipLaunchKernelGGL(head_fwd_bwd<AT>, dim3(blocks), dim3(256), 0, s, (AT*)h1, epi, (const float*)wT,
                      (const float*)bias, (const int*)labels, (const int*)idx, (float*)logits_out,
-                     (float*)loss_rows, (float*)correct_rows, (float*)dlogits, (bf16*)da, B, H, grad_scale,
+                     (float*)loss_rows, (float*)correct_rows, (float*)dlogits, (AT*)da, B, H, grad_scale,
                      inv_keep, backward);
   return (int)hipGetLastError();
 }
+
+extern "C" {
 
 // h1 [B][H] bf16 is an input; wT = output weight transposed, fp32 [10][H]
 int dtf_head_fwd_bwd(const void* h1, const void* wT, const void* bias, const void* labels, const void* idx,
                      void* logits_out, void* loss_rows, void* correct_rows, void* dlogits, void* da, int B,
                      int H, float grad_scale, float inv_keep, int backward, hipStream_t s) {
-  return head_launch(const_cast<void*>(h1), Fc1Epilogue{nullptr, nullptr, 0, DropoutArgs{1.0f, 0, nullptr}}, wT, bias,
-                     labels, idx, logits_out, loss_rows, correct_rows, dlogits, da, B, H, grad_scale, inv_keep,
-                     backward, s);
+  return head_launch<bf16>(const_cast<void*>(h1), Fc1Epilogue{nullptr, nullptr, 0, DropoutArgs{1.0f, 0, nullptr}}, wT, bias,
+                           labels, idx, logits_out, loss_rows, correct_rows, dlogits, da, B, H, grad_scale, inv_keep,
+                           backward, s);
+}
+
+// the same with fp32 activations (h1, da): --dtype fp32
+int dtf_head_f32_fwd_bwd(const void* h1, const void* wT, const void* bias, const void* labels, const void* idx,
+                         void* logits_out, void* loss_rows, void* correct_rows, void* dlogits, void* da, int B,
+                         int H, float grad_scale, float inv_keep, int backward, hipStream_t s) {
+  return head_launch<float>(const_cast<void*>(h1), Fc1Epilogue{nullptr, nullptr, 0, DropoutArgs{1.0f, 0, nullptr}}, wT, bias,
+                            labels, idx, logits_out, loss_rows, correct_rows, dlogits, da, B, H, grad_scale, inv_keep,
+                            backward, s);
 }
 
 // fused fc1 epilogue + head: h1 = dropout(relu(sum_s part[s] + bias1)) is produced (and stored) here
@@ -226,8 +234,18 @@ int dtf_head_fused_fwd_bwd(const void* part, int S, const void* bias1, float kee
                            void* da, int B, int H, float grad_scale, float inv_keep, int backward, hipStream_t s) {
   if (!part || S < 1) return -3;
   Fc1Epilogue epi{(const float*)part, (const float*)bias1, S, DropoutArgs{keep_prob, seed, (const int64_t*)state}};
-  return head_launch(h1, epi, wT, bias, labels, idx, logits_out, loss_rows, correct_rows, dlogits, da, B, H,
-                     grad_scale, inv_keep, backward, s);
+  return head_launch<bf16>(h1, epi, wT, bias, labels, idx, logits_out, loss_rows, correct_rows, dlogits, da, B, H,
+                           grad_scale, inv_keep, backward, s);
+}
+
+int dtf_head_f32_fused_fwd_bwd(const void* part, int S, const void* bias1, float keep_prob, uint64_t seed,
+                               const void* state, void* h1, const void* wT, const void* bias, const void* labels,
+                               const void* idx, void* logits_out, void* loss_rows, void* correct_rows, void* dlogits,
+                               void* da, int B, int H, float grad_scale, float inv_keep, int backward, hipStream_t s) {
+  if (!part || S < 1) return -3;
+  Fc1Epilogue epi{(const float*)part, (const float*)bias1, S, DropoutArgs{keep_prob, seed, (const int64_t*)state}};
+  return head_launch<float>(h1, epi, wT, bias, labels, idx, logits_out, loss_rows, correct_rows, dlogits, da, B, H,
+                            grad_scale, inv_keep, backward, s);
 }
 
 // wT[10][H] = w[H][10]^T (fp32)
@@ -244,7 +262,18 @@ int dtf_head_wgrad(const void* h1, const void* dlogits, const void* da, void* pa
   if (H % 4) return -3;
   HeadWgradArgs a{(const bf16*)h1, (const float*)dlogits, (const bf16*)da, (float*)part, B, H, rps,
                   (H + kHeadCols - 1) / kHeadCols};
-  hipLaunchKernelGGL(head_wgrad, dim3(a.nbx, KS), dim3(256), 0, s, a);
+  hipLaunchKernelGGL(head_wgrad<bf16>, dim3(a.nbx, KS), dim3(256), 0, s, a);
+  return (int)hipGetLastError();
+}
+
+int dtf_head_f32_wgrad(const void* h1, const void* dlogits, const void* da, void* part, int B, int H, int KS,
+                       hipStream_t s) {
+  if (KS <= 0) return -2;
+  int rps = (B + KS - 1) / KS;
+  if (H % 4) return -3;
+  HeadWgradArgsT<float> a{(const float*)h1, (const float*)dlogits, (const float*)da, (float*)part, B, H, rps,
+                          (H + kHeadCols - 1) / kHeadCols};
+  hipLaunchKernelGGL(head_wgrad<float>, dim3(a.nbx, KS), dim3(256), 0, s, a);
   return (int)hipGetLastError();
 }
 

@@ -12,14 +12,28 @@
 
 namespace dtf {
 
-struct HeadWgradArgs {
-  const bf16* h1;
+// AT = element type of the activations h1 / da: bf16 (mixed-precision path) or float (--dtype fp32)
+template <typename AT>
+struct HeadWgradArgsT {
+  const AT* h1;
   const float* dlogits;
-  const bf16* da;
+  const AT* da;
   float* part;
   int B, H, rows_per_split;
   int nbx;  // blocks along the hidden dimension = ceil(H / 256)
 };
+typedef HeadWgradArgsT<bf16> HeadWgradArgs;
+
+// four consecutive activations as fp32
+__device__ __forceinline__ f32x4 load_act4(const bf16* p) {
+  const bf16x4 v = *reinterpret_cast<const bf16x4*>(p);
+  return (f32x4){(float)v[0], (float)v[1], (float)v[2], (float)v[3]};
+}
+__device__ __forceinline__ f32x4 load_act4(const float* p) { return *reinterpret_cast<const f32x4*>(p); }
+__device__ __forceinline__ void store_act4(bf16* p, const f32x4& v) {
+  *reinterpret_cast<bf16x4*>(p) = (bf16x4){(bf16)v[0], (bf16)v[1], (bf16)v[2], (bf16)v[3]};
+}
+__device__ __forceinline__ void store_act4(float* p, const f32x4& v) { *reinterpret_cast<f32x4*>(p) = v; }
 
 constexpr int kHeadCls = 10;
 constexpr int kHeadCols = 256;   // hidden columns per workgroup
@@ -27,13 +41,13 @@ template <int NSUB>
 constexpr int head_wgrad_lds_floats() { return (NSUB / 2) * ((kHeadCls + 1) * kHeadCols + 16); }
 
 // red: head_wgrad_lds_floats<NSUB>() floats of LDS.  H must be a multiple of 4.
-template <int NSUB>
-__device__ __forceinline__ void head_wgrad_block(const HeadWgradArgs& a, int bx, int by, float* red) {
+template <int NSUB, typename AT = bf16>
+__device__ __forceinline__ void head_wgrad_block(const HeadWgradArgsT<AT>& a, int bx, int by, float* red) {
   static_assert(NSUB == 4 || NSUB == 8, "tree reduction over 4 or 8 waves");
   constexpr int kCls = kHeadCls;
   constexpr int kWaveFloats = (kCls + 1) * kHeadCols + 16;   // per-wave slot in red: [11][256] + 16 for db_out
-  const bf16* __restrict__ h1 = a.h1;
-  const bf16* __restrict__ da = a.da;
+  const AT* __restrict__ h1 = a.h1;
+  const AT* __restrict__ da = a.da;
   const float* __restrict__ dlogits = a.dlogits;
   const int B = a.B, H = a.H;
   const int lane = threadIdx.x & 63, sub = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // wave-uniform row phase
@@ -48,9 +62,8 @@ __device__ __forceinline__ void head_wgrad_block(const HeadWgradArgs& a, int bx,
   for (int c = 0; c <= kCls; ++c) acc[c] = (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
   for (int c = 0; c < kCls; ++c) dbo[c] = 0.f;
-  auto row = [&](const bf16x4& hv, const bf16x4& dv, int b) {
+  auto row = [&](const f32x4& hf, const f32x4& dv, int b) {
     const float* dl = dlogits + (size_t)b * kCls;   // wave-uniform address -> scalar loads
-    const f32x4 hf = {(float)hv[0], (float)hv[1], (float)hv[2], (float)hv[3]};
 #pragma unroll
     for (int c = 0; c < kCls; ++c) {
       const float d = dl[c];
@@ -59,24 +72,24 @@ __device__ __forceinline__ void head_wgrad_block(const HeadWgradArgs& a, int bx,
       for (int e = 0; e < 4; ++e) acc[c][e] = fmaf(hf[e], d, acc[c][e]);
     }
 #pragma unroll
-    for (int e = 0; e < 4; ++e) acc[kCls][e] += (float)dv[e];
+    for (int e = 0; e < 4; ++e) acc[kCls][e] += dv[e];
   };
   // four rows per trip: their activation loads are issued together (a one-row loop was a chain of
   // dependent-latency trips)
   int b = b0 + sub;
   for (; b + 3 * NSUB < b1; b += 4 * NSUB) {
-    bf16x4 hv[4], dv[4];
+    f32x4 hv[4], dv[4];
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
-      hv[u] = *reinterpret_cast<const bf16x4*>(h1 + (size_t)(b + NSUB * u) * H + jl);
-      dv[u] = *reinterpret_cast<const bf16x4*>(da + (size_t)(b + NSUB * u) * H + jl);
+      hv[u] = load_act4(h1 + (size_t)(b + NSUB * u) * H + jl);
+      dv[u] = load_act4(da + (size_t)(b + NSUB * u) * H + jl);
     }
 #pragma unroll
     for (int u = 0; u < 4; ++u) row(hv[u], dv[u], b + NSUB * u);
   }
   for (; b < b1; b += NSUB) {
-    const bf16x4 hv = *reinterpret_cast<const bf16x4*>(h1 + (size_t)b * H + jl);
-    const bf16x4 dv = *reinterpret_cast<const bf16x4*>(da + (size_t)b * H + jl);
+    const f32x4 hv = load_act4(h1 + (size_t)b * H + jl);
+    const f32x4 dv = load_act4(da + (size_t)b * H + jl);
     row(hv, dv, b);
   }
   // tree over the waves: the upper half of the live waves writes, the lower half adds (fixed order)

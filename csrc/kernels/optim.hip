@@ -180,7 +180,8 @@ struct FusedSgdArgs {
   float* out_wT;               // fp32 [10][H] transpose of the output weight for head_fwd_bwd (nullptr: none)
   long out_w_off;
   int H;
-  bf16* wc2T;                  // [fwd pack | dgrad pack] of the wc2 shadow (nullptr: none)
+  bf16* wc2T;                  // [fwd pack | dgrad pack] of the wc2 shadow (nullptr: none); with shadow == nullptr
+                               // (the fp32 configuration) it points at the FP32 packs of conv2_f32.hip instead
   long wc2_off;
   int c1, c2;
   StepAdvance adv;
@@ -237,7 +238,7 @@ __device__ __forceinline__ void tail_update4(const FusedSgdArgs& a, long e0, f32
     for (int e = 0; e < 4; ++e) wv[e] = fmaf(-lr, gs[e], wv[e]);
   }
   *reinterpret_cast<f32x4*>(a.w + e0) = wv;
-  store_bf16x4(a.shadow + e0, wv[0], wv[1], wv[2], wv[3]);
+  if (a.shadow) store_bf16x4(a.shadow + e0, wv[0], wv[1], wv[2], wv[3]);
   const long ro = e0 - a.out_w_off;
   if (a.out_wT && ro >= 0 && ro < 10L * a.H) {
 #pragma unroll
@@ -245,7 +246,18 @@ __device__ __forceinline__ void tail_update4(const FusedSgdArgs& a, long e0, f32
   }
   const long r = e0 - a.wc2_off;
   const long nw = 25L * a.c1 * a.c2;
-  if (a.wc2T && r >= 0 && r < nw) {
+  if (a.wc2T && r >= 0 && r < nw && !a.shadow) {
+    // fp32 configuration (no bf16 shadow): wc2T holds the fp32 fragment packs of conv2_f32.hip
+    // (pack_conv2_weights_f32): [fwd pack | dgrad pack], one lane slot = four consecutive k
+    float* pk = reinterpret_cast<float*>(a.wc2T);
+    const int tap = (int)(r / (a.c1 * a.c2)), rem = (int)(r % (a.c1 * a.c2));
+    const int ci = rem / a.c2, co = rem % a.c2;
+    const long f0 = (((long)tap * (a.c1 / 16) + ci / 16) * (a.c2 / 16) + co / 16) * 256 + (((ci % 16) / 4) * 16 + co % 16) * 4 + ci % 4;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) pk[f0 + 4 * e] = wv[e];   // co+e -> next lane slot (co % 16 + e <= 15)
+    const long d0 = (((long)tap * (a.c2 / 16) + co / 16) * (a.c1 / 16) + ci / 16) * 256 + (((co % 16) / 4) * 16 + ci % 16) * 4;
+    *reinterpret_cast<f32x4*>(pk + nw + d0) = wv;          // co .. co+3 = the four k of one lane slot
+  } else if (a.wc2T && r >= 0 && r < nw) {
     // HWIO element (tap, ci, co..co+3) -> the two fragment-ordered packs of conv2.hip
     // (pack_conv2_weights): [fwd pack | dgrad pack]
     const int tap = (int)(r / (a.c1 * a.c2)), rem = (int)(r % (a.c1 * a.c2));
@@ -371,7 +383,7 @@ __global__ __launch_bounds__(256) void fused_reduce_sgd(FusedSgdArgs a, TailP2P 
         for (int e = 0; e < 4; ++e) wv[e] = fmaf(-lr, gv[e], wv[e]);
       }
       reinterpret_cast<f32x4*>(a.w)[i] = wv;
-      store_bf16x4(a.shadow + 4 * i, wv[0], wv[1], wv[2], wv[3]);
+      if (a.shadow) store_bf16x4(a.shadow + 4 * i, wv[0], wv[1], wv[2], wv[3]);
     }
   }
   advance_state(a.adv);   // cursor / global_step / dropout offset: nothing in this kernel reads them

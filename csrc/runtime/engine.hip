@@ -16,7 +16,8 @@ struct DtfEngineDesc {
   int head_ks, c2_g, c1_g, optimizer /*0 sgd, 1 adam*/, shuffle, multi_stream;
   unsigned ds_n, ds_hb, sample_seed, fuse_dense_update;  // last: fc1 SGD update inside its wgrad GEMM (1 GPU)
   uint64_t seed;
-  float keep_prob, pad1;
+  float keep_prob;
+  int dtype;   // 0: bf16 compute copies + fp32 master weights; 1: exact fp32 end to end (csrc/kernels/*_f32.hip)
   long n_total;
   long off_out_w, off_out_b, off_bd1, off_wd1, off_wc2, off_bc2, off_wc1, off_bc1;  // float offsets in the arena
   long head_stride, c2_stride, c1_stride;
@@ -45,6 +46,9 @@ struct DtfEngineDesc {
 
 static inline float* f32at(void* base, long off) { return (float*)base + off; }
 static inline char* bf16at(void* base, long off) { return (char*)base + 2 * off; }
+static inline bool is_f32(const DtfEngineDesc* e) { return e->dtype == 1; }
+// the fp32 configuration keeps no bf16 copies: optimizer kernels are told so with shadow == NULL
+static inline void* shadow_of(const DtfEngineDesc* e) { return is_f32(e) ? nullptr : e->shadow; }
 
 int dtf_engine_init(DtfEngineDesc* e) {
   HIP_TRY(hipStreamCreateWithFlags(&e->side1, hipStreamNonBlocking));
@@ -78,6 +82,16 @@ int dtf_engine_sample(const DtfEngineDesc* e, hipStream_t s) {
 static int forward_conv_impl(const DtfEngineDesc* e, const void* images, const void* idx, int sampled, int n,
                              hipStream_t s) {
   const void* state = sampled ? e->state : nullptr;
+  if (is_f32(e)) {
+    if (sampled)
+      DTF_TRY(dtf_conv1_f32_fwd_sampled(images, e->idx, e->state, e->ds_n, e->ds_hb, e->sample_seed, e->shuffle,
+                                        f32at(e->params, e->off_wc1), f32at(e->params, e->off_bc1), e->p1, e->arg1, n,
+                                        e->c1, 0, s));
+    else
+      DTF_TRY(dtf_conv1_f32_fwd(images, idx, f32at(e->params, e->off_wc1), f32at(e->params, e->off_bc1), e->p1, e->arg1,
+                                n, e->c1, 0, s));
+    return dtf_conv2_f32_fwd(e->p1, e->wc2T, f32at(e->params, e->off_bc2), e->p2, e->arg2, n, e->c1, e->c2, s);
+  }
   if (e->c1 == 32 && e->c2 == 64)
     return dtf_conv12_fwd(images, sampled ? nullptr : idx, e->idx, state, e->ds_n, e->ds_hb, e->sample_seed, e->shuffle,
                           f32at(e->params, e->off_wc1), f32at(e->params, e->off_bc1), e->p1, e->arg1, e->wc2T,
@@ -99,6 +113,14 @@ int dtf_engine_forward_conv(const DtfEngineDesc* e, const void* images, const vo
 int dtf_engine_forward_dense(const DtfEngineDesc* e, const void* labels, const void* idx, int backward, int n,
                              int train_mode, hipStream_t s) {
   const float keep = train_mode ? e->keep_prob : 1.0f;
+  if (is_f32(e)) {
+    const int S = dtf_gemm_f32_nn_partial(e->p2, f32at(e->params, e->off_wd1), e->fc1_part, n, e->hidden, e->flat, e->flat,
+                                          e->hidden, 0, s);
+    if (S <= 0) return S == 0 ? -1 : S;
+    return dtf_head_f32_fused_fwd_bwd(e->fc1_part, S, f32at(e->params, e->off_bd1), keep, e->seed, e->state, e->h1,
+                                      e->out_wT, f32at(e->params, e->off_out_b), labels, idx, e->logits, e->loss_rows,
+                                      e->correct_rows, e->dlogits, e->da, n, e->hidden, 1.0f / n, 1.0f / keep, backward, s);
+  }
   // wd1 is consumed in its native [in, out] layout (no transposed copy), split-K; the bias + ReLU +
   // dropout epilogue runs inside the head kernel, which turns the partial sums into h1 on the fly
   const int S = dtf_gemm_nn_partial(e->p2, bf16at(e->shadow, e->off_wd1), e->fc1_part, n, e->hidden, e->flat, e->flat,
@@ -113,6 +135,10 @@ int dtf_engine_forward_dense(const DtfEngineDesc* e, const void* labels, const v
 // (dx stays in LDS; csrc/kernels/conv2.hip Conv1WgradFused) which writes exactly (B + 1) / 2 slabs --
 // engine.py sizes c1_g accordingly.
 static int dgrad_conv1_wgrad(const DtfEngineDesc* e, const void* images, const void* idx, hipStream_t s) {
+  if (is_f32(e)) {
+    DTF_TRY(dtf_conv2_f32_dgrad(e->dflat, e->arg2, f32at(e->wc2T, 25L * e->c1 * e->c2), e->dp1, e->B, e->c1, e->c2, s));
+    return dtf_conv1_f32_wgrad(images, idx, e->dp1, e->arg1, e->c1_part, e->B, e->c1, e->c1_g, s);
+  }
   if (e->c1 == 32 && e->c2 == 64 && idx && e->c1_g == (e->B + 1) / 2)
     return dtf_conv2_dgrad_conv1_wgrad(e->dflat, e->arg2, bf16at(e->wc2T, 25L * e->c1 * e->c2), images, idx, e->arg1,
                                        e->c1_part, e->B, s);
@@ -125,7 +151,9 @@ static int dgrad_conv1_wgrad(const DtfEngineDesc* e, const void* images, const v
 // reduce == -1 does not compute them either: the training step runs the head wgrad inside the fc1
 // dgrad launch (backward_conv_impl with head_w != 0).
 static int backward_dense_impl(const DtfEngineDesc* e, int reduce, hipStream_t s) {
-  if (reduce >= 0) DTF_TRY(dtf_head_wgrad(e->h1, e->dlogits, e->da, e->head_part, e->B, e->hidden, e->head_ks, s));
+  if (reduce >= 0)
+    DTF_TRY((is_f32(e) ? dtf_head_f32_wgrad : dtf_head_wgrad)(e->h1, e->dlogits, e->da, e->head_part, e->B, e->hidden,
+                                                              e->head_ks, s));
   if (reduce > 0) {
     const void* part[1] = {e->head_part};
     void* out[1] = {f32at(e->grads, e->off_out_w)};
@@ -133,6 +161,9 @@ static int backward_dense_impl(const DtfEngineDesc* e, int reduce, hipStream_t s
     long st[1] = {e->head_stride};
     DTF_TRY(dtf_reduce_segments(1, part, out, G, n, st, s));
   }
+  if (is_f32(e))
+    return dtf_gemm_f32_tn(e->p2, e->da, f32at(e->grads, e->off_wd1), e->flat, e->hidden, e->B, e->flat, e->hidden,
+                           e->hidden, nullptr, s);
   return dtf_gemm_tn(e->p2, e->da, f32at(e->grads, e->off_wd1), e->flat, e->hidden, e->B, e->flat, e->hidden,
                      e->hidden, 0, s);
 }
@@ -141,6 +172,11 @@ int dtf_engine_backward_dense(const DtfEngineDesc* e, hipStream_t s) { return ba
 // fc1 dgrad -> {conv2 dgrad -> conv1 wgrad} || conv2 wgrad (side stream) -> slab reduce.
 // record_dgrad != 0: e->ev_dgrad is recorded right after fc1 dgrad (the last reader of bf16 wd1).
 static int fc1_dgrad(const DtfEngineDesc* e, int head_w, hipStream_t s) {
+  if (is_f32(e)) {
+    if (head_w) DTF_TRY(dtf_head_f32_wgrad(e->h1, e->dlogits, e->da, e->head_part, e->B, e->hidden, e->head_ks, s));
+    return dtf_gemm_f32_nt(e->da, f32at(e->params, e->off_wd1), e->dflat, e->B, e->flat, e->hidden, e->hidden, e->hidden,
+                           e->flat, s);
+  }
   if (head_w)   // + the output-layer weight gradient as extra workgroups of the same launch
     return dtf_gemm_nt_head_wgrad(e->da, bf16at(e->shadow, e->off_wd1), e->dflat, e->B, e->flat, e->hidden, e->hidden,
                                   e->hidden, e->flat, e->h1, e->dlogits, e->da, e->head_part, e->B, e->hidden,
@@ -162,7 +198,8 @@ static int backward_conv_impl(const DtfEngineDesc* e, const void* images, const 
     HIP_TRY(hipStreamWaitEvent(e->side2, e->ev_fork, 0));
     s2 = e->side2;
   }
-  DTF_TRY(dtf_conv2_wgrad(e->p1, e->dflat, e->arg2, e->c2_part, e->B, e->c1, e->c2, e->c2_g, s2));
+  DTF_TRY((is_f32(e) ? dtf_conv2_f32_wgrad : dtf_conv2_wgrad)(e->p1, e->dflat, e->arg2, e->c2_part, e->B, e->c1, e->c2,
+                                                              e->c2_g, s2));
   if (e->multi_stream) HIP_TRY(hipEventRecord(e->ev_join2, s2));
   DTF_TRY(dgrad_conv1_wgrad(e, images, idx, s));
   if (e->multi_stream) HIP_TRY(hipStreamWaitEvent(s, e->ev_join2, 0));
@@ -213,11 +250,12 @@ static int update_range_src(const DtfEngineDesc* e, long lo, long hi, int advanc
   void* st = advance ? e->state : nullptr;
   const long cinc = (advance && advance_cursor) ? e->B : 0;
   if (e->optimizer == 0)
-    DTF_TRY(dtf_sgd_update(f32at(e->params, lo), g, bf16at(e->shadow, lo), e->hyper, n, st, cinc,
+    DTF_TRY(dtf_sgd_update(f32at(e->params, lo), g, is_f32(e) ? nullptr : bf16at(e->shadow, lo), e->hyper, n, st, cinc,
                            step_inc, 1, s));
   else
     DTF_TRY(dtf_adam_update(f32at(e->params, lo), g, f32at(e->adam_m, lo), f32at(e->adam_v, lo),
-                            bf16at(e->shadow, lo), e->hyper, n, e->state, adam_slot, st, cinc, step_inc, 1, s));
+                            is_f32(e) ? nullptr : bf16at(e->shadow, lo), e->hyper, n, e->state, adam_slot, st, cinc,
+                            step_inc, 1, s));
   // the head kernel reads the output weight transposed: keep that copy current
   if (lo <= e->off_out_w && e->off_out_w < hi)
     DTF_TRY(dtf_transpose_head_w(f32at(e->params, e->off_out_w), e->out_wT, e->hidden, s));
@@ -227,7 +265,8 @@ static int update_range_src(const DtfEngineDesc* e, long lo, long hi, int advanc
 // only wc2 needs a derived copy: its two fragment-ordered packs (2 x 100 KB, conv2.hip); wd1 is
 // used in place by both fc1 GEMMs
 int dtf_engine_transposes(const DtfEngineDesc* e, int wc2, hipStream_t s) {
-  if (wc2) DTF_TRY(dtf_conv2_pack_weights(bf16at(e->shadow, e->off_wc2), e->wc2T, e->c1, e->c2, s));
+  if (wc2 && is_f32(e)) DTF_TRY(dtf_conv2_f32_pack_weights(f32at(e->params, e->off_wc2), e->wc2T, e->c1, e->c2, s));
+  else if (wc2) DTF_TRY(dtf_conv2_pack_weights(bf16at(e->shadow, e->off_wc2), e->wc2T, e->c1, e->c2, s));
   return dtf_transpose_head_w(f32at(e->params, e->off_out_w), e->out_wT, e->hidden, s);
 }
 
@@ -244,9 +283,14 @@ static int train_tail_fused_dense(const DtfEngineDesc* e, long step_inc, hipStre
     s1 = e->side1;
     s2 = e->side2;
   }
-  DTF_TRY(dtf_gemm_tn_sgd(e->p2, e->da, f32at(e->params, e->off_wd1), bf16at(e->shadow, e->off_wd1), e->hyper, e->flat,
-                          e->hidden, e->B, e->flat, e->hidden, e->hidden, s1));
-  DTF_TRY(dtf_conv2_wgrad(e->p1, e->dflat, e->arg2, e->c2_part, e->B, e->c1, e->c2, e->c2_g, s2));
+  if (is_f32(e))
+    DTF_TRY(dtf_gemm_f32_tn(e->p2, e->da, f32at(e->params, e->off_wd1), e->flat, e->hidden, e->B, e->flat, e->hidden,
+                            e->hidden, e->hyper, s1));
+  else
+    DTF_TRY(dtf_gemm_tn_sgd(e->p2, e->da, f32at(e->params, e->off_wd1), bf16at(e->shadow, e->off_wd1), e->hyper, e->flat,
+                            e->hidden, e->B, e->flat, e->hidden, e->hidden, s1));
+  DTF_TRY((is_f32(e) ? dtf_conv2_f32_wgrad : dtf_conv2_wgrad)(e->p1, e->dflat, e->arg2, e->c2_part, e->B, e->c1, e->c2,
+                                                              e->c2_g, s2));
   DTF_TRY(dgrad_conv1_wgrad(e, e->ds_images, e->idx, s));
   if (e->multi_stream) {
     HIP_TRY(hipEventRecord(e->ev_join1, s1));
@@ -259,7 +303,7 @@ static int train_tail_fused_dense(const DtfEngineDesc* e, long step_inc, hipStre
   long st[3] = {e->head_stride, e->c2_stride, e->c1_stride};
   long off[3] = {e->off_out_w, e->off_wc2, e->off_wc1};
   // dense range empty: wd1 is already updated
-  return dtf_fused_reduce_sgd(3, part, G, n, st, off, e->params, e->grads, e->shadow, e->hyper, e->off_wc2, e->off_wc2,
+  return dtf_fused_reduce_sgd(3, part, G, n, st, off, e->params, e->grads, shadow_of(e), e->hyper, e->off_wc2, e->off_wc2,
                               e->wc2T, e->off_wc2, e->c1, e->c2, e->out_wT, e->off_out_w, e->hidden, e->state, e->B, step_inc, 1, s);
 }
 
@@ -276,7 +320,7 @@ int dtf_engine_train_step(const DtfEngineDesc* e, long step_inc, hipStream_t s) 
     int G[3] = {e->head_ks, e->c2_g, e->c1_g}, n[3] = {(int)e->head_stride, (int)e->c2_stride, (int)e->c1_stride};
     long st[3] = {e->head_stride, e->c2_stride, e->c1_stride};
     long off[3] = {e->off_out_w, e->off_wc2, e->off_wc1};
-    return dtf_fused_reduce_adam(3, part, G, n, st, off, e->params, e->grads, e->adam_m, e->adam_v, e->shadow, e->hyper,
+    return dtf_fused_reduce_adam(3, part, G, n, st, off, e->params, e->grads, e->adam_m, e->adam_v, shadow_of(e), e->hyper,
                                  e->off_wd1, e->off_out_w, e->wc2T, e->off_wc2, e->c1, e->c2, e->out_wT, e->off_out_w,
                                  e->hidden, e->state, 3, e->B, step_inc, 1, s);
   }
@@ -286,7 +330,7 @@ int dtf_engine_train_step(const DtfEngineDesc* e, long step_inc, hipStream_t s) 
   int G[3] = {e->head_ks, e->c2_g, e->c1_g}, n[3] = {(int)e->head_stride, (int)e->c2_stride, (int)e->c1_stride};
   long st[3] = {e->head_stride, e->c2_stride, e->c1_stride};
   long off[3] = {e->off_out_w, e->off_wc2, e->off_wc1};
-  return dtf_fused_reduce_sgd(3, part, G, n, st, off, e->params, e->grads, e->shadow, e->hyper, e->off_wd1, e->off_out_w,
+  return dtf_fused_reduce_sgd(3, part, G, n, st, off, e->params, e->grads, shadow_of(e), e->hyper, e->off_wd1, e->off_out_w,
                               e->wc2T, e->off_wc2, e->c1, e->c2, e->out_wT, e->off_out_w, e->hidden, e->state, e->B, step_inc, 1, s);
 }
 
@@ -345,17 +389,17 @@ int dtf_engine_dp_phase3(const DtfEngineDesc* e, long dense_hi, int tail_adam_sl
     long st[3] = {e->head_stride, e->c2_stride, e->c1_stride};
     long off[3] = {e->off_out_w, e->off_wc2, e->off_wc1};
     if (e->optimizer == 0)
-      DTF_TRY(dtf_fused_reduce_sgd(3, part, G, n, st, off, e->params, e->grads, e->shadow, e->hyper, e->off_wc2,
+      DTF_TRY(dtf_fused_reduce_sgd(3, part, G, n, st, off, e->params, e->grads, shadow_of(e), e->hyper, e->off_wc2,
                                    e->off_wc2, e->wc2T, e->off_wc2, e->c1, e->c2, e->out_wT, e->off_out_w, e->hidden,
                                    e->state, e->B, step_inc, 1, s));
     else
-      DTF_TRY(dtf_fused_reduce_adam(3, part, G, n, st, off, e->params, e->grads, e->adam_m, e->adam_v, e->shadow,
+      DTF_TRY(dtf_fused_reduce_adam(3, part, G, n, st, off, e->params, e->grads, e->adam_m, e->adam_v, shadow_of(e),
                                     e->hyper, e->off_wc2, e->off_wc2, e->wc2T, e->off_wc2, e->c1, e->c2, e->out_wT,
                                     e->off_out_w, e->hidden, e->state, tail_adam_slot, e->B, step_inc, 1, s));
   } else {
     // update_range refreshes out_wT on whichever stream updates out_w (here, or the dense range on comm)
     DTF_TRY(dtf_engine_update_range(e, dense_hi, e->n_total, 1, 1, step_inc, tail_adam_slot, s));
-    DTF_TRY(dtf_conv2_pack_weights(bf16at(e->shadow, e->off_wc2), e->wc2T, e->c1, e->c2, s));
+    DTF_TRY(dtf_engine_transposes(e, 1, s));
   }
   if (wait_dense) HIP_TRY(hipStreamWaitEvent(s, e->ev_dense_updated, 0));
   return 0;
@@ -372,12 +416,12 @@ int dtf_engine_dp_phase3_p2p(const DtfEngineDesc* e, int tail_adam_slot, long st
     long st[3] = {e->head_stride, e->c2_stride, e->c1_stride};
     long off[3] = {e->off_out_w, e->off_wc2, e->off_wc1};
     DTF_TRY(dtf_fused_reduce_p2p(e->optimizer != 0, 3, part, G, n, st, off, e->params, e->grads, e->adam_m, e->adam_v,
-                                 e->shadow, e->hyper, e->wc2T, e->off_wc2, e->c1, e->c2, e->out_wT, e->off_out_w, e->hidden,
+                                 shadow_of(e), e->hyper, e->wc2T, e->off_wc2, e->c1, e->c2, e->out_wT, e->off_out_w, e->hidden,
                                  e->state, tail_adam_slot, e->B, step_inc, 1, bases, world, rank, n_max, seq, status,
                                  timeout_s, e->off_out_w, s));
   } else {
     // (b) the reduced tail (phase 2 with reduce_tail == 1) through 64 fat workgroups that also apply the update
-    DTF_TRY(dtf_p2p_tail_update(e->optimizer != 0, e->params, e->grads, e->adam_m, e->adam_v, e->shadow, e->hyper, e->wc2T,
+    DTF_TRY(dtf_p2p_tail_update(e->optimizer != 0, e->params, e->grads, e->adam_m, e->adam_v, shadow_of(e), e->hyper, e->wc2T,
                                 e->off_wc2, e->c1, e->c2, e->out_wT, e->off_out_w, e->hidden, e->state, tail_adam_slot,
                                 e->B, step_inc, 1, bases, world, rank, e->n_total - e->off_out_w, n_max, seq, status,
                                 timeout_s, e->off_out_w, s));

@@ -38,7 +38,8 @@ def _half_bits(n: int) -> int:
 
 @dataclass
 class DeviceDataset:
-    """An HBM-resident dataset: bf16 images [N,784] in [0,1] and int32 labels [N]."""
+    """An HBM-resident dataset: images [N,784] in [0,1] and int32 labels [N].  Images are bf16 for the
+    mixed-precision engine and fp32 for the fp32 engine (the reference's float32 placeholders, M:113)."""
 
     images: torch.Tensor
     labels: torch.Tensor
@@ -47,31 +48,43 @@ class DeviceDataset:
     def n(self) -> int:
         return int(self.images.shape[0])
 
+    @property
+    def dtype(self) -> str:
+        return "fp32" if self.images.dtype == torch.float32 else "bf16"
+
     @staticmethod
-    def synthetic(n: int, seed: int = 1234, device="cuda") -> "DeviceDataset":
-        """K12: generate MNIST-shaped synthetic data directly in HBM."""
+    def synthetic(n: int, seed: int = 1234, device="cuda", dtype: str = "bf16") -> "DeviceDataset":
+        """K12: generate MNIST-shaped synthetic data directly in HBM.  The generator's pixel values are exactly
+        representable in bf16, so the fp32 dataset holds the same numbers."""
         lib = native.load()
         images = torch.empty((n, 784), dtype=torch.bfloat16, device=device)
         labels = torch.empty((n,), dtype=torch.int32, device=device)
         s = torch.cuda.current_stream().cuda_stream
         check(lib.dtf_gen_synthetic(ptr(images), ptr(labels), n, seed & 0xFFFFFFFF, s), "gen_synthetic")
+        if dtype == "fp32":
+            images = images.float()     # one-time set-up, not a step op
         return DeviceDataset(images, labels)
 
     @staticmethod
-    def from_uint8(images_u8: torch.Tensor, labels: torch.Tensor, device="cuda") -> "DeviceDataset":
-        """Upload raw idx pixels once and convert to bf16 [0,1] on device (TF: float32(x)/255)."""
+    def from_uint8(images_u8: torch.Tensor, labels: torch.Tensor, device="cuda", dtype: str = "bf16") -> "DeviceDataset":
+        """Upload raw idx pixels once and convert to [0,1] on device (TF: float32(x)/255)."""
         lib = native.load()
         src = images_u8.reshape(images_u8.shape[0], -1).contiguous().to(device)
-        dst = torch.empty(src.shape, dtype=torch.bfloat16, device=device)
         s = torch.cuda.current_stream().cuda_stream
-        check(lib.dtf_u8_to_bf16_unit(ptr(src), ptr(dst), src.numel(), s), "u8_to_bf16")
+        if dtype == "fp32":
+            dst = torch.empty(src.shape, dtype=torch.float32, device=device)
+            check(lib.dtf_u8_to_f32_unit(ptr(src), ptr(dst), src.numel(), s), "u8_to_f32")
+        else:
+            dst = torch.empty(src.shape, dtype=torch.bfloat16, device=device)
+            check(lib.dtf_u8_to_bf16_unit(ptr(src), ptr(dst), src.numel(), s), "u8_to_bf16")
         return DeviceDataset(dst, labels.to(device=device, dtype=torch.int32).contiguous())
 
     @staticmethod
-    def from_float(images: torch.Tensor, labels: torch.Tensor, device="cuda") -> "DeviceDataset":
+    def from_float(images: torch.Tensor, labels: torch.Tensor, device="cuda", dtype: str = "bf16") -> "DeviceDataset":
         if labels.dim() == 2:  # one-hot, as the reference feeds them
             labels = labels.argmax(-1)
-        return DeviceDataset(images.reshape(images.shape[0], -1).to(device=device, dtype=torch.bfloat16).contiguous(),
+        tdt = torch.float32 if dtype == "fp32" else torch.bfloat16
+        return DeviceDataset(images.reshape(images.shape[0], -1).to(device=device, dtype=tdt).contiguous(),
                              labels.to(device=device, dtype=torch.int32).contiguous())
 
 
@@ -82,10 +95,18 @@ class HipEngine:
                  optimizer: str = "sgd", learning_rate: float = 1e-3, keep_prob: float = 1.0,
                  seed: int = 0, device="cuda", grad_scale: float = 1.0, shuffle: bool = True,
                  adam_betas=(0.9, 0.999), adam_eps: float = 1e-8, step_inc: int = 1, multi_stream: Optional[bool] = None,
-                 fuse_dense_update: bool = False):
+                 fuse_dense_update: bool = False, dtype: str = "bf16"):
         if not torch.cuda.is_available():
             raise RuntimeError("HipEngine needs a GPU (use backend='cpu' / models.oracle on CPU)")
         self.lib = native.load()
+        if dtype not in ("bf16", "fp32"):
+            raise ValueError(f"dtype must be 'bf16' or 'fp32', got {dtype!r}")
+        # "bf16": bf16 MFMA compute copies, fp32 accumulation and fp32 master weights.
+        # "fp32": the reference's precision (M:113-115 float32 everywhere): fp32 activations, weights read directly,
+        #         exact-fp32 MFMA kernels (csrc/kernels/*_f32.hip); no bf16 copy of anything exists.
+        self.dtype = dtype
+        if dataset is not None and dataset.dtype != dtype:
+            raise ValueError(f"dataset holds {dataset.dtype} images but the engine computes in {dtype}")
         self.spec, self.B = spec, int(batch)
         self.layout = ArenaLayout(spec)
         self.device = torch.device(device)
@@ -97,7 +118,8 @@ class HipEngine:
         self.dataset = dataset
         # fork/join side streams in backward (conv2 wgrad || dgrad chain || fc1 wgrad).  Measured A/B on the
         # 8..9-kernel step: -5 % at batch 1024 (fork/join costs more than the overlap returns), +3..4 % from 2048 up.
-        self.multi_stream = (batch > 1024) if multi_stream is None else bool(multi_stream)
+        # (the fp32 kernels fill the chip on their own: single stream)
+        self.multi_stream = (batch > 1024 and dtype == "bf16") if multi_stream is None else bool(multi_stream)
         self.fuse_dense_update = bool(fuse_dense_update)
         dev, B, H, C1, C2, FLAT = self.device, self.B, spec.hidden, spec.c1, spec.c2, spec.flat
         n = self.layout.total
@@ -105,10 +127,12 @@ class HipEngine:
         f32 = dict(dtype=torch.float32, device=dev)
         bf = dict(dtype=torch.bfloat16, device=dev)
         u8 = dict(dtype=torch.uint8, device=dev)
+        act = f32 if dtype == "fp32" else bf               # activation storage type
         self.params = torch.zeros(n, **f32)
         self.grads = torch.zeros(n, **f32)
-        self.shadow = torch.zeros(n, **bf)
-        self.wc2T = torch.zeros((2, 25 * C1 * C2), **bf)   # [fwd pack | dgrad pack] of wc2 (csrc/kernels/conv2.hip)
+        self.shadow = torch.zeros(n if dtype == "bf16" else 4, **bf)   # fp32 engine: no compute copies
+        # [fwd pack | dgrad pack] of wc2 in MFMA fragment order (csrc/kernels/conv2.hip / conv2_f32.hip)
+        self.wc2T = torch.zeros((2, 25 * C1 * C2), **act)
         self.out_wT = torch.zeros((10, H), **f32)          # output weight transposed, for the head kernel
         if optimizer == "adam":
             self.adam_m = torch.zeros(n, **f32)
@@ -120,11 +144,11 @@ class HipEngine:
                                   **f32)
 
         self.idx = torch.zeros(B, dtype=torch.int32, device=dev)
-        self.p1 = torch.empty((B, 14, 14, C1), **bf)
+        self.p1 = torch.empty((B, 14, 14, C1), **act)
         self.arg1 = torch.empty((B, 14, 14, C1), **u8)
-        self.p2 = torch.empty((B, 7, 7, C2), **bf)
+        self.p2 = torch.empty((B, 7, 7, C2), **act)
         self.arg2 = torch.empty((B, 7, 7, C2), **u8)
-        self.h1 = torch.empty((B, H), **bf)
+        self.h1 = torch.empty((B, H), **act)
         tiles = ((B + 127) // 128) * ((H + 127) // 128)
         self.fc1_splits = max(1, min(8, -(-256 // tiles)))       # mirrors dtf_gemm_nn_fwd's choice
         self.fc1_part = torch.empty((self.fc1_splits, B, H), **f32)
@@ -132,9 +156,9 @@ class HipEngine:
         self.loss_rows = torch.empty(B, **f32)
         self.correct_rows = torch.empty(B, **f32)
         self.dlogits = torch.empty((B, spec.classes), **f32)
-        self.da = torch.empty((B, H), **bf)
-        self.dflat = torch.empty((B, FLAT), **bf)
-        self.dp1 = torch.empty((B, 14, 14, C1), **bf)
+        self.da = torch.empty((B, H), **act)
+        self.dflat = torch.empty((B, FLAT), **act)
+        self.dp1 = torch.empty((B, 14, 14, C1), **act)
 
         # split-K geometry
         # output-layer wgrad: 256-column workgroups x head_ks batch splits (slabs summed by the fused tail)
@@ -147,13 +171,17 @@ class HipEngine:
         # chip for the 32/64 model (4 tiles); the widened model has 64 tiles and 3.3 MB slabs -> 8 slabs
         c2_tiles = (C1 // 16) * (C2 // 32)
         self.c2_g = max(1, min((B + 1) // 2, int(os.environ.get("DTF_C2_G", "64" if c2_tiles <= 4 else "8"))))
+        if dtype == "fp32":
+            # conv5x5_wgrad_f32: one workgroup per (image range, 32 ci x 64 co tile), one workgroup per CU
+            f32_tiles = (C1 // 32) * (C2 // 64)
+            self.c2_g = max(1, min(B, int(os.environ.get("DTF_C2_G", str(max(1, 256 // f32_tiles))))))
         self.c2_stride = 25 * C1 * C2 + C2
         self.c2_part = torch.empty((self.c2_g, self.c2_stride), **f32)
         # conv1 wgrad slabs: the fused conv2-dgrad -> conv1-wgrad kernel of the 32/64 model writes one per
         # workgroup (2 images each); the stand-alone kernel takes any grid
         # Measured (bench.py A/B): +2.7 % at batch 256, neutral at 1024, -10 % at 4096+ (lower occupancy of the
         # dgrad phase, one slab per two images) -> fused up to 1024 images per GPU.  Env var: A/B switch for tools.
-        fused_c1w = (C1, C2) == (32, 64) and B <= 1024 and os.environ.get("DTF_FUSED_C1W", "1") == "1"
+        fused_c1w = (C1, C2) == (32, 64) and B <= 1024 and dtype == "bf16" and os.environ.get("DTF_FUSED_C1W", "1") == "1"
         self.c1_g = (B + 1) // 2 if fused_c1w else max(1, min(B, 512))
         self.c1_stride = 26 * C1
         self.c1_part = torch.empty((self.c1_g, self.c1_stride), **f32)
@@ -183,6 +211,7 @@ class HipEngine:
         # materialised in the gradient arena)
         d.fuse_dense_update = int(self.fuse_dense_update and self.optimizer == "sgd")
         d.sample_seed, d.seed, d.keep_prob = self.seed & 0xFFFFFFFF, self.seed & (2 ** 64 - 1), self.keep_prob
+        d.dtype = 1 if self.dtype == "fp32" else 0
         d.n_total = lay.total
         for name in lay.names():
             setattr(d, "off_" + name, lay.offsets[name])
@@ -198,6 +227,8 @@ class HipEngine:
         check(self.lib.dtf_engine_init(ctypes.byref(d)), "engine_init")
 
     def _set_dataset(self, ds: Optional[DeviceDataset]):
+        if ds is not None and ds.dtype != self.dtype:
+            raise ValueError(f"dataset holds {ds.dtype} images but the engine computes in {self.dtype}")
         self.dataset = ds
         if ds is not None:
             self._desc.ds_images, self._desc.ds_labels = ds.images.data_ptr(), ds.labels.data_ptr()
@@ -260,7 +291,7 @@ class HipEngine:
         """bf16 compute copies: the arena itself (+ K-contiguous transposes for the NT kernels)."""
         s = self._s()
         sp = self.spec
-        if cast:
+        if cast and self.dtype == "bf16":
             check(self.lib.dtf_cast_bf16(ptr(self.params), ptr(self.shadow), self.layout.total, s), "cast_bf16")
         self.refresh_transposes()
 
@@ -332,9 +363,13 @@ class HipEngine:
         """One full optimisation step on the resident dataset: a single native call."""
         check(self.lib.dtf_engine_train_step(self._d(), self.step_inc, self._s()), "train_step")
 
+    @property
+    def act_dtype(self) -> torch.dtype:
+        return torch.float32 if self.dtype == "fp32" else torch.bfloat16
+
     def train_step_on(self, images: torch.Tensor, labels: torch.Tensor):
-        """One step on an explicit batch (bf16 [B,784], int32 [B]) -- the feed_dict path."""
-        assert images.shape[0] == self.B
+        """One step on an explicit batch ([B,784] in the engine's dtype, int32 [B]) -- the feed_dict path."""
+        assert images.shape[0] == self.B and images.dtype == self.act_dtype
         self.launch_forward(images, labels, None, backward=True)
         self.launch_backward(images, None)
         self.launch_update(advance_cursor=False)

@@ -85,6 +85,25 @@ _SIGS = {
     "dtf_init_truncated_normal": [c_void_p, c_long, c_float, c_uint64, c_uint64, c_void_p],
     "dtf_fill_f32": [c_void_p, c_long, c_float, c_void_p],
     "dtf_u8_to_bf16_unit": [c_void_p, c_void_p, c_long, c_void_p],
+    # ---- exact-fp32 kernel set (csrc/kernels/*_f32.hip) ----
+    "dtf_conv1_f32_fwd": [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p],
+    "dtf_conv1_f32_fwd_sampled": [c_void_p, c_void_p, c_void_p, c_uint, c_uint, c_uint, c_int, c_void_p, c_void_p, c_void_p,
+                                  c_void_p, c_int, c_int, c_int, c_void_p],
+    "dtf_conv1_f32_wgrad": [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p],
+    "dtf_u8_to_f32_unit": [c_void_p, c_void_p, c_long, c_void_p],
+    "dtf_conv2_f32_pack_weights": [c_void_p, c_void_p, c_int, c_int, c_void_p],
+    "dtf_conv2_f32_fwd": [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p],
+    "dtf_conv2_f32_dgrad": [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p],
+    "dtf_conv2_f32_wgrad": [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p],
+    "dtf_gemm_f32_nn_partial": [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p],
+    "dtf_gemm_f32_nt": [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p],
+    "dtf_gemm_f32_tn": [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p],
+    "dtf_head_f32_fwd_bwd": [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
+                             c_void_p, c_void_p, c_int, c_int, c_float, c_float, c_int, c_void_p],
+    "dtf_head_f32_fused_fwd_bwd": [c_void_p, c_int, c_void_p, c_float, c_uint64, c_void_p, c_void_p, c_void_p, c_void_p,
+                                   c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int,
+                                   c_float, c_float, c_int, c_void_p],
+    "dtf_head_f32_wgrad": [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p],
 }
 
 
@@ -95,7 +114,7 @@ class EngineDesc(ctypes.Structure):
         [(n, c_int) for n in ("B", "c1", "c2", "hidden", "flat", "classes", "head_ks", "c2_g", "c1_g", "optimizer",
                               "shuffle", "multi_stream")]
         + [(n, c_uint) for n in ("ds_n", "ds_hb", "sample_seed", "fuse_dense_update")]
-        + [("seed", c_uint64), ("keep_prob", c_float), ("pad1", c_float), ("n_total", c_long)]
+        + [("seed", c_uint64), ("keep_prob", c_float), ("dtype", c_int), ("n_total", c_long)]
         + [(n, c_long) for n in ("off_out_w", "off_out_b", "off_bd1", "off_wd1", "off_wc2", "off_bc2", "off_wc1",
                                  "off_bc1", "head_stride", "c2_stride", "c1_stride")]
         + [(n, c_void_p) for n in ("params", "grads", "shadow", "fc1_part", "wc2T", "adam_m", "adam_v", "state", "hyper",

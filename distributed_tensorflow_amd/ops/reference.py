@@ -85,3 +85,13 @@ def conv2_pack_reference(w):
     f = w.reshape(t, cin // 32, 4, 8, cout // 16, 16).permute(0, 1, 4, 2, 5, 3).contiguous().reshape(-1)
     d = w.reshape(t, cin // 16, 16, cout // 32, 4, 8).permute(0, 3, 1, 4, 2, 5).contiguous().reshape(-1)
     return f, d
+
+
+def conv2_pack_reference_f32(w):
+    """Fragment-ordered fp32 packs of a [25, cin, cout] conv2 weight as csrc/kernels/conv2_f32.hip
+    (pack_conv2_weights_f32) lays them out: (fwd_pack, dgrad_pack), each flat with 25*cin*cout elements.
+    fwd: [tap][ci/16][co/16][(ci%16)/4][co%16][ci%4]; dgrad: [tap][co/16][ci/16][(co%16)/4][ci%16][co%4]."""
+    t, cin, cout = w.shape
+    f = w.reshape(t, cin // 16, 4, 4, cout // 16, 16).permute(0, 1, 4, 2, 5, 3).contiguous().reshape(-1)
+    d = w.reshape(t, cin // 16, 16, cout // 16, 4, 4).permute(0, 3, 1, 4, 2, 5).contiguous().reshape(-1)
+    return f, d

@@ -1,0 +1,167 @@
+"""End-to-end checks of the fp32 engine (HipEngine(dtype="fp32"): exact-fp32 MFMA kernels, fp32 activations,
+weights read directly) -- the reference's precision (reference .idea/MNISTDist.py:113-115,148-149).
+
+One step against an fp64 evaluation of the same fp32 parameters and batch (<= 1e-4 on every gradient tensor,
+<= 1e-5 on the loss), a multi-step loss curve against the fp32 PyTorch oracle, and the bitwise invariants the
+bf16 engine is held to (graph replay == eager, fused fc1 update == optimizer kernel, DP schedule at world 1 ==
+plain step)."""
+import numpy as np
+import pytest
+import torch
+
+from distributed_tensorflow_amd.data import batch_indices
+from distributed_tensorflow_amd.models.oracle import OracleModel
+from distributed_tensorflow_amd.models.spec import ModelSpec
+from distributed_tensorflow_amd.ops import reference as R
+
+pytestmark = pytest.mark.gpu
+
+
+def rel_err(a, b):
+    a, b = a.double().cpu(), b.double().cpu()
+    return float((a - b).norm() / (b.norm() + 1e-30))
+
+
+@pytest.fixture(scope="module")
+def dataset(gpu_lib):
+    from distributed_tensorflow_amd.engine import DeviceDataset
+    return DeviceDataset.synthetic(4096, seed=1234, dtype="fp32")
+
+
+def ref_step64(params, x, y):
+    """fp64 forward + backward of the reference model on the CPU: (loss, {name: grad})."""
+    p = {n: t.double().clone().requires_grad_(True) for n, t in params.items()}
+    z = R.conv_net(x.double().cpu(), p)
+    loss = (-torch.log_softmax(z, -1).gather(1, y.cpu().long().unsqueeze(1)).squeeze(1)).mean()   # stays fp64
+    loss.backward()
+    return float(loss), {n: p[n].grad for n in p}, z.detach()
+
+
+@pytest.mark.parametrize("B,spec_name", [(100, "deep_mnist"), (37, "deep_mnist"), (6, "wide")])
+def test_f32_step_matches_fp64_reference(gpu_lib, dataset, B, spec_name):
+    from distributed_tensorflow_amd.engine import HipEngine
+    spec = ModelSpec.from_name(spec_name)
+    lr = 0.01
+    eng = HipEngine(spec, B, dataset, optimizer="sgd", learning_rate=lr, seed=5, dtype="fp32")
+    eng.init_params()
+    p0 = eng.export_params()
+    idx = batch_indices(0, B, dataset.n, 5)
+    x = dataset.images[torch.as_tensor(idx, device="cuda")]
+    y = dataset.labels[torch.as_tensor(idx, device="cuda")]
+    loss_ref, g_ref, z_ref = ref_step64(p0, x, y)
+
+    eng.launch_train_step()
+    torch.cuda.synchronize()
+    assert np.array_equal(eng.idx.cpu().numpy().astype(np.int64), idx)
+    loss, acc = eng.last_metrics()
+    assert abs(loss - loss_ref) / abs(loss_ref) < 1e-5, (loss, loss_ref)
+    assert rel_err(eng.logits, z_ref) < 1e-5
+    g = eng.export_grads()
+    for name in eng.layout.names():
+        e = rel_err(g[name], g_ref[name])
+        assert e < 1e-4, (name, e)
+    assert eng.global_step == 1 and int(eng.state[0]) == B
+    # the update is w - lr * g of exactly the gradient the engine reports (one fmaf per element)
+    p = eng.export_params()
+    for name in eng.layout.names():
+        want = (p0[name].double() - lr * g[name].double())
+        assert float((p[name].double() - want).abs().max()) <= 1e-6 * float(p0[name].abs().max()), name
+    # derived fp32 copies follow the weights
+    f_ref, d_ref = R.conv2_pack_reference_f32(eng.pview("wc2").reshape(25, spec.c1, spec.c2))
+    assert torch.equal(eng.wc2T[0], f_ref) and torch.equal(eng.wc2T[1], d_ref)
+    assert torch.equal(eng.out_wT, eng.pview("out_w").reshape(spec.hidden, 10).t().contiguous())
+
+
+@pytest.mark.parametrize("optimizer,lr", [("sgd", 0.02), ("adam", 1e-3)])
+def test_f32_loss_curve_matches_fp32_oracle(gpu_lib, dataset, optimizer, lr):
+    """40 optimisation steps on the same batches: the loss curve of the fp32 engine follows the fp32 PyTorch oracle
+    (ATen ops on the same device) to <= 1e-4 relative per step -- both are fp32 evaluations of the same recurrence,
+    differing only in summation order."""
+    from distributed_tensorflow_amd.engine import HipEngine
+    spec, B, steps = ModelSpec(), 64, 40
+    eng = HipEngine(spec, B, dataset, optimizer=optimizer, learning_rate=lr, seed=21, dtype="fp32")
+    eng.init_params(seed=3)
+    oracle = OracleModel(spec, device="cuda", optimizer=optimizer, learning_rate=lr)
+    oracle.load_params(eng.export_params())
+    worst = 0.0
+    first = last = None
+    for s in range(steps):
+        idx = torch.as_tensor(batch_indices(s * B, B, dataset.n, 21), device="cuda")
+        l_ref, _ = oracle.train_step(dataset.images[idx], dataset.labels[idx])
+        eng.train_step()
+        l, _ = eng.last_metrics()
+        worst = max(worst, abs(l - l_ref) / max(abs(l_ref), 1e-3))
+        first = l if first is None else first
+        last = l
+    assert worst < 1e-4, worst
+    assert last < 0.7 * first, (first, last)
+    p_ref, p = oracle.export_params(), eng.export_params()
+    for name in eng.layout.names():
+        assert rel_err(p[name], p_ref[name]) < 1e-4, name
+
+
+def test_f32_graph_replay_and_fused_dense_update_are_bitwise(gpu_lib, dataset):
+    from distributed_tensorflow_amd.engine import HipEngine
+    engines = []
+    for fuse, graph in ((False, False), (True, False), (True, True)):
+        eng = HipEngine(ModelSpec(), 96, dataset, optimizer="sgd", learning_rate=0.01, seed=3, fuse_dense_update=fuse,
+                        dtype="fp32")
+        eng.init_params(seed=13)
+        if graph:
+            eng.capture()
+            assert eng.global_step == 0
+        for _ in range(8):
+            eng.train_step()
+        torch.cuda.synchronize()
+        engines.append(eng)
+    a = engines[0]
+    for b in engines[1:]:
+        assert a.global_step == b.global_step == 8
+        assert torch.equal(a.params, b.params) and torch.equal(a.wc2T, b.wc2T) and torch.equal(a.out_wT, b.out_wT)
+        assert a.last_metrics() == b.last_metrics()
+
+
+def test_f32_adam_dropout_trains_and_evaluates(gpu_lib, dataset):
+    from distributed_tensorflow_amd.engine import HipEngine
+    eng = HipEngine(ModelSpec(), 128, dataset, optimizer="adam", learning_rate=1e-3, keep_prob=0.5, seed=9, dtype="fp32")
+    eng.init_params()
+    first = None
+    for i in range(60):
+        eng.train_step()
+        if i == 0:
+            first = eng.last_metrics()[0]
+    last = eng.last_metrics()[0]
+    assert last < 0.3 * first, (first, last)
+    # evaluation (dropout off) agrees with the fp32 oracle holding the same weights
+    oracle = OracleModel(ModelSpec(), device="cuda")
+    oracle.load_params(eng.export_params())
+    l_ref, a_ref = oracle.loss_and_accuracy(dataset.images[:1000], dataset.labels[:1000])
+    loss, acc = eng.evaluate(dataset.images[:1000], dataset.labels[:1000])
+    assert abs(loss - float(l_ref)) < 1e-4 * max(1.0, abs(float(l_ref)))
+    assert abs(acc - float(a_ref)) <= 1.0 / 1000
+
+
+def test_f32_sync_dp_world1_matches_plain_engine(gpu_lib, dataset):
+    import os
+    import torch.distributed as dist
+    from distributed_tensorflow_amd.engine import HipEngine
+    from distributed_tensorflow_amd.parallel import comm
+    from distributed_tensorflow_amd.parallel.sync_dp import SyncDataParallel
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", "29613"
+    comm.init_process_group("nccl", 0, 1, device=torch.device("cuda", 0))
+    try:
+        a = HipEngine(ModelSpec(), 128, dataset, learning_rate=0.01, seed=4, dtype="fp32")
+        b = HipEngine(ModelSpec(), 128, dataset, learning_rate=0.01, seed=4, dtype="fp32")
+        a.init_params(seed=2)
+        b.init_params(seed=2)
+        dp = SyncDataParallel(b, tail_group=dist.new_group([0]))
+        dp.broadcast_parameters()
+        for _ in range(5):
+            a.launch_train_step()
+            dp.train_step()
+        dp.flush()
+        torch.cuda.synchronize()
+        assert torch.equal(a.params, b.params) and torch.equal(a.wc2T, b.wc2T)
+        assert a.global_step == b.global_step == 5
+    finally:
+        dist.destroy_process_group()

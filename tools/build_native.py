@@ -49,7 +49,7 @@ def build_kernels(force: bool = False, verbose: bool = True) -> Path:
     hipcc = _hipcc()
     BUILD.mkdir(exist_ok=True)
     OUT.mkdir(parents=True, exist_ok=True)
-    headers = list((CSRC / "kernels").glob("*.hpp")) + list((CSRC / "runtime").glob("*.hpp"))
+    headers = [h for d in ("kernels", "runtime") for pat in ("*.hpp", "*.h") for h in (CSRC / d).glob(pat)]
     srcs = sorted((CSRC / "kernels").glob("*.hip")) + sorted((CSRC / "runtime").glob("*.hip"))
     objs = []
     jobs = []
