@@ -1,7 +1,7 @@
 """Compute backends behind one small interface, so the trainer / supervisor / parallel
 strategies are identical for the MI355X engine and the CPU oracle.
 
-  HipBackend  hand-written gfx950 kernels on an HBM-resident dataset (engine.HipEngine)
+  HipBackend  hand-written gfx950 kernels on an HBM-resident dataset (engine.HipEngine), bf16 or exact fp32
   CpuBackend  fp32 PyTorch oracle + TF-style ``next_batch`` input pipeline; this is what the
               "1 ps + 2 workers on localhost CPU" plumbing configuration runs on (gloo)
 
@@ -126,17 +126,19 @@ class HipBackend(Backend):
     name = "hip"
 
     def __init__(self, spec: ModelSpec, batch: int, data: Datasets, optimizer="sgd", learning_rate=1e-3,
-                 keep_prob=1.0, seed=0, device="cuda", use_graph=True):
+                 keep_prob=1.0, seed=0, device="cuda", use_graph=True, dtype="bf16"):
         from .engine import DeviceDataset, HipEngine
         self.spec, self.batch, self.data = spec, batch, data
+        self.dtype = dtype
         tr = data.train
-        self.train_ds = DeviceDataset.from_float(torch.from_numpy(tr.images), torch.from_numpy(tr.int_labels), device)
+        self.train_ds = DeviceDataset.from_float(torch.from_numpy(tr.images), torch.from_numpy(tr.int_labels), device,
+                                                 dtype=dtype)
         self._eval_cache = {}
         self.engine = HipEngine(spec, batch, self.train_ds, optimizer=optimizer, learning_rate=learning_rate,
-                                keep_prob=keep_prob, seed=seed, device=device, fuse_dense_update=True)
+                                keep_prob=keep_prob, seed=seed, device=device, fuse_dense_update=True, dtype=dtype)
         self.layout = self.engine.layout
         # measured on MI355X: eager launches of the 8-kernel step beat graph replay up to 1024 images/step
-        self.use_graph = bool(use_graph) and batch > 1024
+        self.use_graph = bool(use_graph) and batch > 1024 and dtype == "bf16"
         self._host_step = 0
 
     params = property(lambda self: self.engine.params)
@@ -180,7 +182,8 @@ class HipBackend(Backend):
         if split not in self._eval_cache:
             ds = getattr(self.data, split)
             self._eval_cache[split] = DeviceDataset.from_float(torch.from_numpy(ds.images),
-                                                               torch.from_numpy(ds.int_labels), self.engine.device)
+                                                               torch.from_numpy(ds.int_labels), self.engine.device,
+                                                               dtype=self.dtype)
         d = self._eval_cache[split]
         return self.engine.evaluate(d.images, d.labels)
 
@@ -212,46 +215,6 @@ class HipBackend(Backend):
         e.state[e.STATE_ADAM_T2] = int(state.get("t", 0))
 
 
-class TorchBackend(CpuBackend):
-    """Reference backend: the fp32 PyTorch oracle on the GPU (ATen -> MIOpen / hipBLASLt).  Not the
-    product path -- it exists to give the fp32 configuration and an on-device baseline that the
-    hand-written kernel engine is measured against (bench/torch_reference.py)."""
-
-    name = "torch"
-
-    def __init__(self, spec, batch, data, optimizer="sgd", learning_rate=1e-3, keep_prob=1.0, seed=0,
-                 device="cuda", autocast_bf16=False):
-        from .data.sampler import batch_indices
-        self._batch_indices = batch_indices
-        self.spec, self.batch, self.data = spec, batch, data
-        self.model = OracleModel(spec, device=device, seed=seed, optimizer=optimizer, learning_rate=learning_rate,
-                                 keep_prob=keep_prob)
-        self.layout = self.model.layout
-        self.device = torch.device(device)
-        self.images = torch.from_numpy(data.train.images).to(self.device)
-        self.labels = torch.from_numpy(data.train.int_labels.astype(np.int64)).to(self.device)
-        self.seed, self.cursor = seed, 0
-        self.autocast_bf16 = autocast_bf16
-        self._metrics = (float("nan"), float("nan"))
-
-    def compute_gradients(self):
-        n = self.images.shape[0]
-        idx = torch.as_tensor(self._batch_indices(self.cursor, self.batch, n, self.seed), device=self.device)
-        self.cursor += self.batch
-        with torch.autocast("cuda", dtype=torch.bfloat16, enabled=self.autocast_bf16):
-            self._metrics = self.model.compute_gradients(self.images[idx], self.labels[idx])
-
-    def evaluate(self, split: str = "test"):
-        ds = getattr(self.data, split)
-        x = torch.from_numpy(ds.images).to(self.device)
-        y = torch.from_numpy(ds.int_labels.astype(np.int64)).to(self.device)
-        l, a = self.model.loss_and_accuracy(x, y)
-        return float(l), float(a)
-
-    def synchronize(self):
-        torch.cuda.synchronize(self.device)
-
-
 def make_backend(kind: str, spec: ModelSpec, batch: int, data: Datasets, **kw) -> Backend:
     if kind == "auto":
         kind = "hip" if torch.cuda.is_available() else "cpu"
@@ -260,8 +223,6 @@ def make_backend(kind: str, spec: ModelSpec, batch: int, data: Datasets, **kw) -
     if kind == "cpu":
         kw.pop("device", None)
         kw.pop("use_graph", None)
+        kw.pop("dtype", None)      # the CPU oracle is fp32
         return CpuBackend(spec, batch, data, **kw)
-    if kind in ("torch", "torch_bf16"):
-        kw.pop("use_graph", None)
-        return TorchBackend(spec, batch, data, autocast_bf16=(kind == "torch_bf16"), **kw)
     raise ValueError(f"unknown backend {kind!r}")

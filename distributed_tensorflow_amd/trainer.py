@@ -50,16 +50,18 @@ def resolve_task(F) -> TaskInfo:
 
 
 def _pick_backend(F) -> str:
-    if F.backend != "auto":
-        return F.backend
-    if not torch.cuda.is_available():
-        return "cpu"
+    """--backend: hip (hand-written gfx950 kernels) | cpu (PyTorch oracle + gloo plumbing) | auto.
+    --dtype selects the precision of the HIP engine's own kernel sets -- bf16 MFMA with fp32 master weights, or
+    the exact-fp32 MFMA set (the reference's float32, M:113-115); it never selects another backend."""
     dtype = getattr(F, "dtype", "bf16")
     if dtype not in ("bf16", "fp32"):
         raise SystemExit(f"--dtype must be bf16 or fp32, got {dtype!r}")
-    # the hand-written kernels compute in bf16 (fp32 accumulate, fp32 master weights); an all-fp32
-    # run on the GPU is the ATen/MIOpen reference backend
-    return "hip" if dtype == "bf16" else "torch"
+    if F.backend not in ("auto", "hip", "cpu"):
+        raise SystemExit(f"--backend must be auto, hip or cpu, got {F.backend!r} "
+                         "(the ATen/MIOpen reference lives in bench/torch_reference.py only)")
+    if F.backend != "auto":
+        return F.backend
+    return "hip" if torch.cuda.is_available() else "cpu"
 
 
 def run(F, log=print) -> dict:
@@ -72,7 +74,7 @@ def run(F, log=print) -> dict:
     if mode == "async" and task.num_ps == 0:
         raise SystemExit("--mode=async needs at least one ps task (--ps_hosts)")
 
-    if kind in ("hip", "torch", "torch_bf16"):
+    if kind == "hip":
         local_rank = int(os.environ.get("LOCAL_RANK", F.local_rank if F.local_rank >= 0 else task.rank))
         local_rank %= max(1, torch.cuda.device_count())
         torch.cuda.set_device(local_rank)
@@ -95,7 +97,8 @@ def run(F, log=print) -> dict:
     data = read_data_sets(F.data_dir, one_hot=(kind == "cpu"), synthetic=F.synthetic,
                           seed=F.seed + 1000 * task.rank)   # every worker shuffles independently (ref. item 9)
     backend = make_backend(kind, spec, F.batch_size, data, optimizer=F.optimizer, learning_rate=F.learning_rate,
-                           keep_prob=F.keep_prob, seed=F.seed + task.rank, device=device, use_graph=F.hip_graph)
+                           keep_prob=F.keep_prob, seed=F.seed + task.rank, device=device, use_graph=F.hip_graph,
+                           dtype=getattr(F, "dtype", "bf16"))
 
     chief_rank = task.cluster.rank_of("worker", 0)
     worker_group = tail_group = None

@@ -40,7 +40,7 @@ flags.DEFINE_float("keep_prob", 1.0, "dropout keep probability (the reference fe
 flags.DEFINE_string("model", "deep_mnist", "deep_mnist | wide (conv 128/256, fc4096)")
 flags.DEFINE_string("width", "", "alias of --model: base | wide")
 flags.DEFINE_integer("eval_every", 0, "chief also evaluates the test split every N global steps (0 = only at the end)")
-flags.DEFINE_string("backend", "auto", "auto | hip (MI355X kernels) | cpu (PyTorch oracle, gloo) | torch / torch_bf16 (fp32 / autocast ATen reference on the GPU)")
+flags.DEFINE_string("backend", "auto", "auto | hip (hand-written MI355X kernels) | cpu (PyTorch oracle, gloo)")
 flags.DEFINE_string("logdir", "/tmp/train_logs", "checkpoint directory (reference hard-codes /tmp/train_logs); '' disables")
 flags.DEFINE_float("save_model_secs", 600.0, "seconds between chief checkpoints (reference: 600)")
 flags.DEFINE_integer("saver_write_version", 2, "checkpoint format the chief writes: 2 = tensor bundle, 1 = TF<0.12 Saver file (both are read)")
@@ -48,7 +48,7 @@ flags.DEFINE_boolean("synthetic", False, "use MNIST-shaped synthetic data (autom
 flags.DEFINE_boolean("eval", True, "evaluate on the 10k test split at the end (chief)")
 flags.DEFINE_integer("seed", 0, "base random seed")
 flags.DEFINE_boolean("hip_graph", True, "allow replaying the single-GPU step as a captured HIP graph (used above 1024 images/step, where it measured faster than eager launches)")
-flags.DEFINE_string("dtype", "bf16", "compute dtype with --backend auto on a GPU: bf16 (hand-written MFMA kernels, fp32 master weights) | fp32 (ATen/MIOpen reference backend)")
+flags.DEFINE_string("dtype", "bf16", "precision of the hip backend: bf16 (bf16 MFMA kernels, fp32 accumulation + fp32 master weights) | fp32 (exact-fp32 MFMA kernel set: the reference's float32 end to end)")
 flags.DEFINE_integer("local_rank", -1, "GPU index for this process (default: LOCAL_RANK or rank % device_count)")
 flags.DEFINE_float("comm_timeout", 1800.0, "collective timeout in seconds (failure detection in sync mode)")
 flags.DEFINE_string("metrics_file", "", "append JSONL metrics here")
