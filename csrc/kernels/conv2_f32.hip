@@ -43,8 +43,10 @@ enum { F32_MODE_FWD = 0, F32_MODE_DGRAD = 1 };
 //   out  FWD  : pooled [B,7,7,NCTOT] fp32 + out_arg u8      DGRAD: dx [B,14,14,NCTOT] fp32
 // grid = (B, NCTOT / NCW)
 // ----------------------------------------------------------------------------------------------------
+constexpr int kF32RedBytes = 2 * 13 * 64 * 16;   // dgrad: the K-half partner's 13 accumulator tiles per n tile
+
 template <int KTOT, int NCTOT, int MODE>
-__global__ __launch_bounds__(256) void conv5x5_igemm_f32(const float* __restrict__ in, const uint8_t* __restrict__ in_arg,
+__global__ __launch_bounds__(256, 2) void conv5x5_igemm_f32(const float* __restrict__ in, const uint8_t* __restrict__ in_arg,
                                                          const float* __restrict__ wk, const float* __restrict__ bias,
                                                          float* __restrict__ out, uint8_t* __restrict__ out_arg, int B) {
   constexpr int KC = 32;
@@ -53,11 +55,11 @@ __global__ __launch_bounds__(256) void conv5x5_igemm_f32(const float* __restrict
   constexpr int KSPLIT = 4 / NTN;                         // K halves (dgrad)
   constexpr int NS = 25 * (KC / 16) / KSPLIT;             // k-block steps per wave and K chunk
   static_assert(KTOT % KC == 0 && NCTOT % NCW == 0, "channel counts must be multiples of the tile");
-  extern __shared__ __attribute__((aligned(16))) float tile[];   // [324][36]
+  extern __shared__ __attribute__((aligned(16))) float tile[];   // [324][36] (+ the dgrad reduction area)
 
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int ntile = wave % NTN, ksp = wave / NTN;
-  const int b = blockIdx.x, ng = blockIdx.y;
+  const int ng = blockIdx.y;
   const int l16 = lane & 15, g = lane >> 4;
 
   // A row of this lane in M tile t: window 4t + (l16 >> 2), position q = l16 & 3 (windows past 48 are clamped
@@ -69,138 +71,150 @@ __global__ __launch_bounds__(256) void conv5x5_igemm_f32(const float* __restrict
     const int pos = (2 * (wI / 7) + (q >> 1)) * kF32TileW + 2 * (wI % 7) + (q & 1);
     aoff[t] = pos * kF32Pitch + 4 * g;
   }
-  f32x4 acc[13];
-#pragma unroll
-  for (int t = 0; t < 13; ++t) acc[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-  // zero once: the halo stays zero, the interior is completely rewritten by every K chunk
+  // zero once: the halo stays zero, the interior is completely rewritten by every (image, K chunk)
   for (int i = tid; i < kF32TileBytes / 16; i += 256) reinterpret_cast<f32x4*>(tile)[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-#pragma unroll 1
-  for (int kc0 = 0; kc0 < KTOT; kc0 += KC) {
-    // ---- stage this chunk's 32 channels (all global loads first: one memory latency per chunk) ----
-    if (MODE == F32_MODE_FWD) {
-      constexpr int NCH = 196 * 8, ROUNDS = (NCH + 255) / 256;
-      f32x4 v[ROUNDS];
+  // ---- staging: (image, 32-channel K chunk) units; the global loads of unit u+1 are issued before the k-loop of
+  // unit u and written to LDS after it (persistent workgroups: the grid is ~2 per CU and walks the batch) ----
+  constexpr int NCH = (MODE == F32_MODE_FWD) ? 196 * 8 : 49 * 8;   // 16-byte chunks per unit
+  constexpr int ROUNDS = (NCH + 255) / 256;
+  f32x4 sv[ROUNDS];
+  unsigned scd[ROUNDS];
+  auto issue_loads = [&](int b, int kc0) {
 #pragma unroll
-      for (int r = 0; r < ROUNDS; ++r) {
-        const int c = min(tid + r * 256, NCH - 1);
-        v[r] = *reinterpret_cast<const f32x4*>(in + ((size_t)b * 196 + (c >> 3)) * KTOT + kc0 + (c & 7) * 4);
-      }
-      __syncthreads();   // zero fill done / previous chunk consumed
+    for (int r = 0; r < ROUNDS; ++r) {
+      const int c = min(tid + r * 256, NCH - 1);
+      const size_t off = ((size_t)b * (MODE == F32_MODE_FWD ? 196 : 49) + (c >> 3)) * KTOT + kc0 + (c & 7) * 4;
+      sv[r] = *reinterpret_cast<const f32x4*>(in + off);
+      if (MODE == F32_MODE_DGRAD) scd[r] = *reinterpret_cast<const unsigned*>(in_arg + off);
+    }
+  };
+  auto write_tile = [&]() {
 #pragma unroll
-      for (int r = 0; r < ROUNDS; ++r) {
-        const int c = tid + r * 256;
-        const int pos = c >> 3, ch = c & 7;
-        const int tp = (pos / 14 + 2) * kF32TileW + pos % 14 + 2;
-        if (c < NCH) *reinterpret_cast<f32x4*>(tile + tp * kF32Pitch + ch * 4) = v[r];
-      }
-    } else {
-      constexpr int NCH = 49 * 8, ROUNDS = (NCH + 255) / 256;
-      f32x4 v[ROUNDS];
-      unsigned cd[ROUNDS];
-#pragma unroll
-      for (int r = 0; r < ROUNDS; ++r) {
-        const int c = min(tid + r * 256, NCH - 1);
-        const size_t off = ((size_t)b * 49 + (c >> 3)) * KTOT + kc0 + (c & 7) * 4;
-        v[r] = *reinterpret_cast<const f32x4*>(in + off);
-        cd[r] = *reinterpret_cast<const unsigned*>(in_arg + off);
-      }
-      __syncthreads();
-#pragma unroll
-      for (int r = 0; r < ROUNDS; ++r) {
-        const int c = tid + r * 256;
-        const int pp = c >> 3, ch = c & 7;
-        if (c < NCH) {
+    for (int r = 0; r < ROUNDS; ++r) {
+      const int c = tid + r * 256;
+      const int pos = c >> 3, ch = c & 7;
+      if (c < NCH) {
+        if (MODE == F32_MODE_FWD) {
+          const int tp = (pos / 14 + 2) * kF32TileW + pos % 14 + 2;
+          *reinterpret_cast<f32x4*>(tile + tp * kF32Pitch + ch * 4) = sv[r];
+        } else {
+          // max-pool / ReLU gradient: the pooled gradient goes to the saved argmax position of its window
           f32x4 o[4];
-          expand_pool_grad_f32(v[r], cd[r], o);
+          expand_pool_grad_f32(sv[r], scd[r], o);
 #pragma unroll
           for (int q = 0; q < 4; ++q) {
-            const int tp = (2 * (pp / 7) + (q >> 1) + 2) * kF32TileW + 2 * (pp % 7) + (q & 1) + 2;
+            const int tp = (2 * (pos / 7) + (q >> 1) + 2) * kF32TileW + 2 * (pos % 7) + (q & 1) + 2;
             *reinterpret_cast<f32x4*>(tile + tp * kF32Pitch + ch * 4) = o[q];
           }
         }
       }
     }
-    __syncthreads();
+  };
 
-    // ---- k-loop: step s of this wave <-> (tap, 16-k block kb) ----
-    const float* bbase = wk + ((size_t)(kc0 / 16) * (NCTOT / 16) + ng * NTN + ntile) * 256 + lane * 4;
-    auto step_tap = [&](int s) { return KSPLIT == 1 ? (s >> 1) : s; };
-    auto step_kb = [&](int s) { return KSPLIT == 1 ? (s & 1) : ksp; };
-    auto load_b = [&](int s) -> f32x4 {
-      const int tap = step_tap(s), kb = step_kb(s);
-      const int wtap = (MODE == F32_MODE_DGRAD) ? 24 - tap : tap;
-      return *reinterpret_cast<const f32x4*>(bbase + ((size_t)wtap * (KTOT / 16) + kb) * (NCTOT / 16) * 256);
-    };
-    auto do_step = [&](int s, const f32x4& bf) {
-      const int tap = step_tap(s), kb = step_kb(s);
-      const float* ap = tile + ((tap / 5) * kF32TileW + tap % 5) * kF32Pitch + kb * 16;
-      f32x4 a[13];
-#pragma unroll
-      for (int t = 0; t < 13; ++t) a[t] = *reinterpret_cast<const f32x4*>(ap + aoff[t]);
-#pragma unroll
-      for (int e = 0; e < 4; ++e)
-#pragma unroll
-        for (int t = 0; t < 13; ++t) acc[t] = mfma16f(a[t][e], bf[e], acc[t]);
-    };
-    // B fragment of step s+1 requested before the MFMAs of step s; unconditional (the last step re-loads itself)
-    f32x4 b0 = load_b(0), b1;
+  int b = blockIdx.x;
+  if (b < B) issue_loads(b, 0);
 #pragma unroll 1
-    for (int s = 0; s < NS; s += 2) {
-      b1 = load_b(min(s + 1, NS - 1));
-      __builtin_amdgcn_sched_barrier(0);
-      do_step(s, b0);
-      if (s + 1 >= NS) break;
-      b0 = load_b(min(s + 2, NS - 1));
-      __builtin_amdgcn_sched_barrier(0);
-      do_step(s + 1, b1);
-    }
-  }
+  for (; b < B; b += gridDim.x) {
+    f32x4 acc[13];
+#pragma unroll
+    for (int t = 0; t < 13; ++t) acc[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-  // ---- K halves summed through LDS (dgrad) ----
-  if (KSPLIT == 2) {
-    __syncthreads();   // every wave is done with the tile
-    f32x4* red = reinterpret_cast<f32x4*>(tile);   // [ntile][13][64 lanes]
-    if (ksp == 1) {
-#pragma unroll
-      for (int t = 0; t < 13; ++t) red[(ntile * 13 + t) * 64 + lane] = acc[t];
-    }
-    __syncthreads();
-    if (ksp == 1) return;
-#pragma unroll
-    for (int t = 0; t < 13; ++t) acc[t] += red[(ntile * 13 + t) * 64 + lane];
-  }
+#pragma unroll 1
+    for (int kc0 = 0; kc0 < KTOT; kc0 += KC) {
+      __syncthreads();   // zero fill done / previous unit's k-loop (and reduction reads) finished
+      write_tile();
+      __syncthreads();
+      {   // next unit's loads fly during this unit's k-loop
+        const bool more_k = kc0 + KC < KTOT;
+        const int nb = more_k ? b : b + (int)gridDim.x;
+        if (nb < B) issue_loads(nb, more_k ? kc0 + KC : 0);
+      }
+      __builtin_amdgcn_sched_barrier(0);
 
-  // ---- epilogue.  C/D map: lane holds rows 4g + r -> window 4t + g, q = r; column l16 ----
-  const int n = ng * NCW + ntile * 16 + l16;
-  if (MODE == F32_MODE_FWD) {
-    const float bv = bias[n];
+      // ---- k-loop: step s of this wave <-> (tap, 16-k block kb) ----
+      const float* bbase = wk + ((size_t)(kc0 / 16) * (NCTOT / 16) + ng * NTN + ntile) * 256 + lane * 4;
+      auto step_tap = [&](int s) { return KSPLIT == 1 ? (s >> 1) : s; };
+      auto step_kb = [&](int s) { return KSPLIT == 1 ? (s & 1) : ksp; };
+      auto load_b = [&](int s) -> f32x4 {
+        const int tap = step_tap(s), kb = step_kb(s);
+        const int wtap = (MODE == F32_MODE_DGRAD) ? 24 - tap : tap;
+        return *reinterpret_cast<const f32x4*>(bbase + ((size_t)wtap * (KTOT / 16) + kb) * (NCTOT / 16) * 256);
+      };
+      auto do_step = [&](int s, const f32x4& bf) {
+        const int tap = step_tap(s), kb = step_kb(s);
+        const float* ap = tile + ((tap / 5) * kF32TileW + tap % 5) * kF32Pitch + kb * 16;
+        f32x4 a[13];
 #pragma unroll
-    for (int t = 0; t < 13; ++t) {
-      const int wI = 4 * t + g;
-      if (wI < 49) {
-        const f32x4 v = acc[t];
-        float best = v[0];
-        int bi = 0;
-        if (v[1] > best) { best = v[1]; bi = 1; }
-        if (v[2] > best) { best = v[2]; bi = 2; }
-        if (v[3] > best) { best = v[3]; bi = 3; }
-        const float o = fmaxf(best + bv, 0.f);
-        const size_t off = ((size_t)b * 49 + wI) * NCTOT + n;
-        out[off] = o;
-        out_arg[off] = (uint8_t)(o > 0.f ? bi : (int)kPoolDead);
+        for (int t = 0; t < 13; ++t) a[t] = *reinterpret_cast<const f32x4*>(ap + aoff[t]);
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+#pragma unroll
+          for (int t = 0; t < 13; ++t) acc[t] = mfma16f(a[t][e], bf[e], acc[t]);
+      };
+      // B fragment of step s+1 requested before the MFMAs of step s; unconditional (the last step re-loads itself)
+      f32x4 b0 = load_b(0), b1;
+#pragma unroll 1
+      for (int s = 0; s < NS; s += 2) {
+        b1 = load_b(min(s + 1, NS - 1));
+        __builtin_amdgcn_sched_barrier(0);
+        do_step(s, b0);
+        if (s + 1 >= NS) break;
+        b0 = load_b(min(s + 2, NS - 1));
+        __builtin_amdgcn_sched_barrier(0);
+        do_step(s + 1, b1);
       }
     }
-  } else {
+
+    // ---- K halves summed through LDS (dgrad); its own area behind the tile, so the tile's zero halo survives ----
+    if (KSPLIT == 2) {
+      f32x4* red = reinterpret_cast<f32x4*>(reinterpret_cast<char*>(tile) + kF32TileBytes);   // [ntile][13][64 lanes]
+      if (ksp == 1) {
 #pragma unroll
-    for (int t = 0; t < 13; ++t) {
-      const int wI = 4 * t + g;
-      if (wI < 49) {
+        for (int t = 0; t < 13; ++t) red[(ntile * 13 + t) * 64 + lane] = acc[t];
+      }
+      __syncthreads();
+      // every wave adds (branch-free: a conditional update of the accumulators costs a second register copy of
+      // them); only the ksp == 0 wave of a pair stores its result
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const int y = 2 * (wI / 7) + (r >> 1), x = 2 * (wI % 7) + (r & 1);
-          out[((size_t)b * 196 + y * 14 + x) * NCTOT + n] = acc[t][r];
+      for (int t = 0; t < 13; ++t) acc[t] += red[(ntile * 13 + t) * 64 + lane];
+    }
+
+    // ---- epilogue.  C/D map: lane holds rows 4g + r -> window 4t + g, q = r; column l16 ----
+    // (the lane's row group is made opaque per image: the store addresses are then recomputed here instead of being
+    // hoisted out of the image loop as ~50 loop-invariant registers that spill around the k-loop)
+    int ge = g;
+    asm volatile("" : "+v"(ge));
+    const int n = ng * NCW + ntile * 16 + l16;
+    if (MODE == F32_MODE_FWD) {
+      const float bv = bias[n];
+#pragma unroll
+      for (int t = 0; t < 13; ++t) {
+        const int wI = 4 * t + ge;
+        if (wI < 49) {
+          const f32x4 v = acc[t];
+          float best = v[0];
+          int bi = 0;
+          if (v[1] > best) { best = v[1]; bi = 1; }
+          if (v[2] > best) { best = v[2]; bi = 2; }
+          if (v[3] > best) { best = v[3]; bi = 3; }
+          const float o = fmaxf(best + bv, 0.f);
+          const size_t off = ((size_t)b * 49 + wI) * NCTOT + n;
+          out[off] = o;
+          out_arg[off] = (uint8_t)(o > 0.f ? bi : (int)kPoolDead);
+        }
+      }
+    } else if (ksp == 0) {
+#pragma unroll
+      for (int t = 0; t < 13; ++t) {
+        const int wI = 4 * t + ge;
+        if (wI < 49) {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const int y = 2 * (wI / 7) + (r >> 1), x = 2 * (wI % 7) + (r & 1);
+            out[((size_t)b * 196 + y * 14 + x) * NCTOT + n] = acc[t][r];
+          }
         }
       }
     }
@@ -401,17 +415,35 @@ __global__ __launch_bounds__(256, 1) void conv5x5_wgrad_f32(const float* __restr
 
 using namespace dtf;
 
+static int f32_cu_count() {
+  static int cus = 0;
+  if (!cus) {
+    int dev = 0;
+    hipDeviceProp_t prop;
+    if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) cus = prop.multiProcessorCount;
+    if (cus <= 0) cus = 256;
+  }
+  return cus;
+}
+
 template <int KTOT, int NCTOT, int MODE>
 static int launch_igemm_f32(const void* in, const void* in_arg, const void* wk, const void* bias, void* out, void* out_arg,
                             int B, hipStream_t s) {
   auto kern = conv5x5_igemm_f32<KTOT, NCTOT, MODE>;
+  // 80 KiB per workgroup = exactly two per CU (the dgrad reduction area fits in the slack): the grid is persistent,
+  // two workgroups per CU walking the batch, so there is no partial last round of workgroups
+  constexpr int lds = 80 * 1024;
+  static_assert(kF32TileBytes + kF32RedBytes <= lds, "tile + reduction area must fit");
   static bool attr_set = false;
   if (!attr_set) {
-    (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, kF32TileBytes);
+    (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     attr_set = true;
   }
   constexpr int NCW = (MODE == F32_MODE_FWD) ? 64 : 32;
-  hipLaunchKernelGGL(kern, dim3(B, NCTOT / NCW), dim3(256), kF32TileBytes, s, (const float*)in, (const uint8_t*)in_arg,
+  constexpr int groups = NCTOT / NCW;
+  int gx = (2 * f32_cu_count() + groups - 1) / groups;
+  if (gx > B) gx = B;
+  hipLaunchKernelGGL(kern, dim3(gx, groups), dim3(256), lds, s, (const float*)in, (const uint8_t*)in_arg,
                      (const float*)wk, (const float*)bias, (float*)out, (uint8_t*)out_arg, B);
   return (int)hipGetLastError();
 }
