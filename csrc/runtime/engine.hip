@@ -51,8 +51,13 @@ static inline bool is_f32(const DtfEngineDesc* e) { return e->dtype == 1; }
 static inline void* shadow_of(const DtfEngineDesc* e) { return is_f32(e) ? nullptr : e->shadow; }
 
 int dtf_engine_init(DtfEngineDesc* e) {
-  HIP_TRY(hipStreamCreateWithFlags(&e->side1, hipStreamNonBlocking));
-  HIP_TRY(hipStreamCreateWithFlags(&e->side2, hipStreamNonBlocking));
+  // side streams only for the backward fork/join (multi_stream): a process has 4 hardware queues by default
+  // (GPU_MAX_HW_QUEUES), and the data-parallel step already uses compute + comm + RCCL's own streams
+  e->side1 = e->side2 = nullptr;
+  if (e->multi_stream) {
+    HIP_TRY(hipStreamCreateWithFlags(&e->side1, hipStreamNonBlocking));
+    HIP_TRY(hipStreamCreateWithFlags(&e->side2, hipStreamNonBlocking));
+  }
   hipEvent_t* evs[9] = {&e->ev_head,        &e->ev_fork,          &e->ev_join1,      &e->ev_join2,       &e->ev_dgrad,
                         &e->ev_dense_ready, &e->ev_dense_updated, &e->ev_tail_ready, &e->ev_tail_reduced};
   for (auto ev : evs) HIP_TRY(hipEventCreateWithFlags(ev, hipEventDisableTiming));
@@ -68,6 +73,9 @@ int dtf_engine_destroy(DtfEngineDesc* e) {
   if (e->side2) (void)hipStreamDestroy(e->side2);
   return 0;
 }
+
+// number of HIP streams this engine created itself (the caller's compute / comm streams come on top)
+int dtf_engine_stream_count(const DtfEngineDesc* e) { return (e->side1 ? 1 : 0) + (e->side2 ? 1 : 0); }
 
 int dtf_stream_wait_event(hipStream_t s, hipEvent_t ev) { return (int)hipStreamWaitEvent(s, ev, 0); }
 int dtf_event_record(hipEvent_t ev, hipStream_t s) { return (int)hipEventRecord(ev, s); }

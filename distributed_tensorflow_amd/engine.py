@@ -234,6 +234,10 @@ class HipEngine:
             self._desc.ds_images, self._desc.ds_labels = ds.images.data_ptr(), ds.labels.data_ptr()
             self._desc.ds_n, self._desc.ds_hb = ds.n, _half_bits(ds.n)
 
+    def streams_in_use(self) -> int:
+        """HIP streams created by the native executor (side streams of the backward fork/join, 0 or 2)."""
+        return int(self.lib.dtf_engine_stream_count(ctypes.byref(self._desc)))
+
     def __del__(self):
         try:
             self.lib.dtf_engine_destroy(ctypes.byref(self._desc))

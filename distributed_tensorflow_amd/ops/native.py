@@ -130,6 +130,7 @@ _EP = ctypes.POINTER(EngineDesc)
 _ENGINE_SIGS = {
     "dtf_engine_init": [_EP],
     "dtf_engine_destroy": [_EP],
+    "dtf_engine_stream_count": [_EP],
     "dtf_stream_wait_event": [c_void_p, c_void_p],
     "dtf_event_record": [c_void_p, c_void_p],
     "dtf_engine_sample": [_EP, c_void_p],
