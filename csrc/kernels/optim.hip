@@ -273,6 +273,7 @@ __device__ __forceinline__ void tail_update4(const FusedSgdArgs& a, long e0, f32
 template <bool ADAM, bool P2P>
 __global__ __launch_bounds__(256) void fused_reduce_sgd(FusedSgdArgs a, TailP2P pp) {
   __shared__ f32x4 red[16][17];
+  __shared__ int p2p_bad;
   const float lr = a.hyper[0] * a.hyper[4];
   float lr_t = 0.f, b1 = 0.f, b2 = 0.f, eps = 0.f, gsc = 0.f;
   if (ADAM) {
@@ -344,6 +345,7 @@ __global__ __launch_bounds__(256) void fused_reduce_sgd(FusedSgdArgs a, TailP2P 
         for (int k = 0; k < W; ++k) *reinterpret_cast<f32x4*>(pp.stage[(pp.rank + k) % W] + slot) = gs;
       }
       if (threadIdx.x < 64) __threadfence_system();   // only wave 0 (grp 0..3) stored anything
+      if (threadIdx.x == 0) p2p_bad = 0;
       __syncthreads();
       if ((int)threadIdx.x < W) {
         __hip_atomic_store(pp.flags[threadIdx.x] + ((size_t)par * W + pp.rank) * kTailFlagSlots + blockIdx.x, pp.seq,
@@ -353,12 +355,16 @@ __global__ __launch_bounds__(256) void fused_reduce_sgd(FusedSgdArgs a, TailP2P 
         while (__hip_atomic_load(f, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) != pp.seq) {
           if (wall_clock64() - t0 > pp.timeout_ticks) {
             *pp.status = 1;
+            p2p_bad = 1;
             break;
           }
           __builtin_amdgcn_s_sleep(2);
         }
       }
       __syncthreads();
+      // a peer never arrived: the sum would be incomplete.  Leave parameters, moments and step state untouched
+      // (the host sees *status at its next health check and ends the run; a checkpoint taken meanwhile is clean)
+      if (p2p_bad) return;
       if (grp == 0 && i4 * 4 < sg.n) {
         const float* mine = pp.stage[pp.rank] + (size_t)par * W * pp.n_max + (size_t)(e0 - pp.tail_off);
         gs = *reinterpret_cast<const f32x4*>(mine);
@@ -417,7 +423,9 @@ __global__ __launch_bounds__(256) void p2p_tail_allreduce_update(FusedSgdArgs a,
 #pragma unroll 1
     for (int k = 0; k < W; ++k) reinterpret_cast<f32x4*>(pp.stage[(pp.rank + k) % W] + slot)[i] = v;
   }
+  __shared__ int p2p_bad;
   __threadfence_system();
+  if (tid == 0) p2p_bad = 0;
   __syncthreads();
   if (tid < W) {
     __hip_atomic_store(pp.flags[tid] + ((size_t)par * W + pp.rank) * kTailFlagSlots + b, pp.seq, __ATOMIC_RELEASE,
@@ -427,12 +435,14 @@ __global__ __launch_bounds__(256) void p2p_tail_allreduce_update(FusedSgdArgs a,
     while (__hip_atomic_load(f, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) != pp.seq) {
       if (wall_clock64() - t0 > pp.timeout_ticks) {
         *pp.status = 1;
+        p2p_bad = 1;
         break;
       }
       __builtin_amdgcn_s_sleep(2);
     }
   }
   __syncthreads();
+  if (p2p_bad) return;   // incomplete sum: no update, no state advance (see fused_reduce_sgd)
   const float* mine = pp.stage[pp.rank] + (size_t)par * W * pp.n_max;
   for (int i = lo4 + tid; i < hi4; i += 256) {
     const long e0 = pp.tail_off + 4L * i;

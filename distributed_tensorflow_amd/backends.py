@@ -57,6 +57,20 @@ class Backend:
     def export_optimizer_state(self) -> Optional[dict]: return None
     def load_optimizer_state(self, state: dict): pass
 
+    # coordinated stop: the last 4 floats of the gradient arena travel in every synchronous step's
+    # all-reduce; a worker that wants the job to stop raises its flag there and every worker reads the same sum
+    def raise_stop_flag(self):
+        self.grads[self.layout.ctrl:self.layout.ctrl + 1].fill_(1.0)
+
+    def stop_flag_sum(self) -> float:
+        """> 0 once any worker has raised its flag (reads device memory: synchronises the stream on the GPU)."""
+        return float(self.grads[self.layout.ctrl].item())
+
+    # optimizer slots as flat arenas, for the chief -> workers broadcast after a restore (None: no slots)
+    def adam_arenas(self) -> Optional[Tuple[torch.Tensor, torch.Tensor]]: return None
+    def get_adam_t(self) -> int: return 0
+    def set_adam_t(self, t: int): pass
+
 
 class CpuBackend(Backend):
     name = "cpu"
@@ -101,6 +115,18 @@ class CpuBackend(Backend):
 
     def get_global_step(self): return self.model.global_step
     def set_global_step(self, v): self.model.global_step = int(v)
+
+    def adam_arenas(self):
+        m = self.model
+        if m.optimizer != "adam":
+            return None
+        if m._adam_m is None:
+            m._adam_m = torch.zeros_like(m.arena)
+            m._adam_v = torch.zeros_like(m.arena)
+        return m._adam_m, m._adam_v
+
+    def get_adam_t(self): return int(self.model._adam_t)
+    def set_adam_t(self, t): self.model._adam_t = int(t)
 
     def export_optimizer_state(self):
         m = self.model
@@ -194,6 +220,17 @@ class HipBackend(Backend):
     def set_global_step(self, v):
         self.engine.set_global_step(v)
         self._host_step = int(v)
+
+    def adam_arenas(self):
+        e = self.engine
+        return (e.adam_m, e.adam_v) if e.optimizer == "adam" else None
+
+    def get_adam_t(self): return int(self.engine.state[self.engine.STATE_ADAM_T].item())
+
+    def set_adam_t(self, t):
+        e = self.engine
+        e.state[e.STATE_ADAM_T] = int(t)
+        e.state[e.STATE_ADAM_T2] = int(t)
 
     def export_optimizer_state(self):
         e = self.engine

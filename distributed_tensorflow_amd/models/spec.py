@@ -109,6 +109,10 @@ class ArenaLayout:
     The split-K slabs written by the wgrad kernels use the same relative layout
     as the arena segments they reduce into (head = out_w|out_b|bd1, conv2 =
     wc2|bc2, conv1 = wc1|bc1).
+
+    The arena ends in a 4-float CONTROL block (``ctrl``): no tensor lives there.  In the gradient arena it
+    carries the workers' stop requests inside the tail all-reduce of every synchronous step ("abort
+    flag all-reduce"), so a stop is seen by every worker at the same step and costs no extra collective.
     """
 
     spec: ModelSpec
@@ -116,6 +120,7 @@ class ArenaLayout:
     offsets: Dict[str, int] = field(default_factory=dict)
     sizes: Dict[str, int] = field(default_factory=dict)
     total: int = 0
+    ctrl: int = 0      # float offset of the control block (the last 4 floats of the arena)
 
     def __post_init__(self):
         shapes = self.spec.shapes()
@@ -127,7 +132,8 @@ class ArenaLayout:
             self.offsets[name] = off
             self.sizes[name] = n
             off += _align4(n)
-        self.total = off
+        self.ctrl = off
+        self.total = off + 4
 
     def shape(self, name: str) -> Tuple[int, ...]:
         return self.spec.shapes()[name]

@@ -79,6 +79,7 @@ def _get_int(t: torch.Tensor, i: int) -> int:
 
 class LocalStrategy:
     name = "local"
+    coordinated_stop = False      # a stop request takes effect at once, locally
 
     def __init__(self, backend: Backend):
         self.b = backend
@@ -104,14 +105,23 @@ class SyncAllReduce:
     """Synchronous data parallelism among the worker ranks."""
 
     name = "sync"
+    # Stop requests are COORDINATED: a synchronous worker that simply left the loop would strand its peers in the
+    # next collective.  request_stop() raises this worker's flag in the control block of the gradient arena, which
+    # rides in every step's (tail) all-reduce; poll_stop() reads the sum, which is the same number on every worker
+    # after the same step, so all of them leave the loop together (reference: sv.should_stop(), M:173; SURVEY X6).
+    coordinated_stop = True
 
     def __init__(self, backend: Backend, task: TaskInfo, worker_group, chief_rank: int, tail_group=None,
-                 p2p: bool = False, log=None):
+                 p2p: bool = False, log=None, stop_check_steps: int = 20):
         self.b, self.task, self.group, self.chief_rank = backend, task, worker_group, chief_rank
         self.world = task.num_workers
         self.step_count = backend.get_global_step()
         self._dp = None
         self._p2p = []
+        self._stop_requested = False
+        self.stop = False
+        # the GPU path reads the flag (a device sync) only every stop_check_steps global steps; the CPU path every step
+        self.stop_check_steps = max(1, int(stop_check_steps))
         # The overlapped schedule (parallel/sync_dp.py) needs collectives that run on streams: RCCL, or the
         # peer-to-peer kernels (--p2p_allreduce; these also work between tasks that share one GPU over gloo).
         if backend.name == "hip" and (dist.get_backend(worker_group) != "gloo" or p2p):
@@ -157,11 +167,26 @@ class SyncAllReduce:
         broadcast_state(self.b, self.chief_rank)
         self.step_count = self.b.get_global_step()
 
+    def request_stop(self):
+        self._stop_requested = True
+
+    def poll_stop(self) -> bool:
+        """True on every worker after the same step once any worker has requested a stop."""
+        if self.stop:
+            return True
+        if self._dp is None or self.step_count % self.stop_check_steps == 0:
+            self.stop = self.b.stop_flag_sum() > 0.0
+        return self.stop
+
     def step(self) -> int:
         if self._dp is not None:
+            if self._stop_requested:
+                self.b.raise_stop_flag()       # before the step's tail all-reduce reads the control block
             self._dp.train_step()
         else:
             self.b.compute_gradients()
+            if self._stop_requested:
+                self.b.raise_stop_flag()
             comm.all_reduce_sum(self.b.grads, group=self.group)
             self.b.apply_gradients(scale=1.0 / self.world)
         self.step_count += 1
@@ -174,19 +199,27 @@ class SyncAllReduce:
 
 
 def broadcast_state(backend: Backend, src_rank: int, group=None):
-    """Chief -> everyone: parameters + global_step (reference: chief runs init_op / restore while
-    the other tasks wait for the variables to be initialised)."""
+    """Chief -> everyone: parameters, global_step AND the optimizer slots (reference: chief runs init_op / restore
+    while the other tasks wait for the variables to be initialised).  Without the slots a restored Adam
+    run would continue with the chief's moments on the chief and zeros everywhere else: every replica would then
+    apply a different update to the same all-reduced gradient and the replicas would drift apart unnoticed."""
     comm.broadcast(backend.params, src_rank, group=group)
     dev = backend.params.device
-    st = torch.tensor([backend.get_global_step()], dtype=torch.int64, device=dev)
+    st = torch.tensor([backend.get_global_step(), backend.get_adam_t()], dtype=torch.int64, device=dev)
     comm.broadcast(st, src_rank, group=group)
-    backend.set_global_step(int(st.item()))
+    backend.set_global_step(int(st[0].item()))
+    slots = backend.adam_arenas()
+    if slots is not None:
+        for t in slots:
+            comm.broadcast(t, src_rank, group=group)
+        backend.set_adam_t(int(st[1].item()))
     backend.params_changed()
 
 
 # ----------------------------------------------------------------------------- async, p2p
 class AsyncP2PWorker:
     name = "async-p2p"
+    coordinated_stop = False      # asynchronous workers come and go on their own (reference M:174-176)
 
     def __init__(self, backend: Backend, task: TaskInfo, chief_rank: int):
         self.b, self.task, self.chief_rank = backend, task, chief_rank
@@ -297,10 +330,16 @@ class AsyncRounds:
     """Parameter-server emulation with reduce + broadcast collectives (ps rank 0 owns the weights)."""
 
     name = "async-rounds"
+    coordinated_stop = False
 
-    def __init__(self, backend: Backend, task: TaskInfo, chief_rank: int, staleness: int = 1):
+    def __init__(self, backend: Backend, task: TaskInfo, chief_rank: int, staleness: int = 1, optimizer: str = "sgd"):
         if staleness not in (0, 1):
             raise ValueError("staleness must be 0 or 1 rounds")
+        if optimizer != "sgd":
+            # one application of the SUM of W gradients equals W sequential un-averaged applications for SGD only;
+            # with Adam it would silently be a different algorithm (and global_step would run W times ahead of t)
+            raise ValueError("--async_impl=broadcast applies the summed gradient of a round in one update, which is "
+                             "the parameter-server semantics for SGD only: use --async_impl=p2p with --optimizer adam")
         self.b, self.task, self.chief_rank, self.staleness = backend, task, chief_rank, staleness
         self.ps_rank = 0
         self.W = task.num_workers

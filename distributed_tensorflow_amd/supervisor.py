@@ -8,9 +8,12 @@ save_model_secs=600)`` + ``sv.managed_session`` / ``should_stop`` / ``stop`` giv
     broadcast from the chief),
   * the chief saves ``logdir/model.ckpt-<global_step>`` every ``save_model_secs`` seconds
     (TF-bundle files + ``checkpoint`` state file, newest 5 kept) and once more at stop,
-  * ``should_stop()`` turns true after ``request_stop()`` or when the managed block raises.
-Saves happen from the training thread between steps (never concurrently with an update), so a
-checkpoint is always a consistent snapshot.
+  * ``should_stop()`` turns true after ``request_stop()`` or when the managed block raises.  In synchronous mode
+    the request is job-wide: it travels in the control block of the gradient all-reduce
+    (parallel/strategies.py::SyncAllReduce) and every worker leaves the loop after the same step -- a worker
+    that just walked away would strand its peers in the next collective.
+Saves snapshot the state between steps (never concurrently with an update), so a checkpoint is always consistent;
+the file write itself runs on a background thread (checkpoint/async_writer.py).
 """
 from __future__ import annotations
 
@@ -27,7 +30,7 @@ class Supervisor:
     def __init__(self, backend: Backend, is_chief: bool, logdir: Optional[str] = "/tmp/train_logs",
                  save_model_secs: float = 600.0, saver: Optional[Saver] = None, init_seed: int = 0,
                  checkpoint_basename: str = "model.ckpt", log: Callable[[str], None] = print,
-                 adam_betas=(0.9, 0.999)):
+                 adam_betas=(0.9, 0.999), save_optimizer_state: bool = True):
         self.b = backend
         self.is_chief = is_chief
         self.logdir = logdir
@@ -37,7 +40,10 @@ class Supervisor:
         self.basename = checkpoint_basename
         self.log = log
         self.betas = adam_betas
+        self.save_optimizer_state = save_optimizer_state   # False in async mode: the slots live on the ps tasks
+        self.pre_save_check: Optional[Callable[[], None]] = None   # raises if the state must not be checkpointed
         self._stop = False
+        self._strategy = None
         self._last_save = time.monotonic()
         self.restored_from: Optional[str] = None
         self.saved: list = []
@@ -65,6 +71,7 @@ class Supervisor:
     @contextlib.contextmanager
     def managed_session(self, strategy, final_save: bool = True):
         """Init/restore on the chief, hand the state to everyone, run the block, stop cleanly."""
+        self._strategy = strategy
         try:
             if self.is_chief:
                 self.init_or_restore()
@@ -82,10 +89,19 @@ class Supervisor:
 
     # -- stop coordination ---------------------------------------------------
     def should_stop(self) -> bool:
+        st = self._strategy
+        if not self._stop and st is not None and getattr(st, "coordinated_stop", False) and st.poll_stop():
+            self._stop = True
         return self._stop
 
     def request_stop(self):
-        self._stop = True
+        """Ask the job to stop.  Synchronous workers stop together (after the next step at which the flag is
+        read); everything else stops this task at once."""
+        st = self._strategy
+        if st is not None and getattr(st, "coordinated_stop", False):
+            st.request_stop()
+        else:
+            self._stop = True
 
     def stop(self):
         self._stop = True
@@ -95,8 +111,10 @@ class Supervisor:
         if not (self.is_chief and self.logdir):
             return None
         self.b.synchronize()
+        if self.pre_save_check is not None:
+            self.pre_save_check()
         step = self.b.get_global_step()
-        opt = self.b.export_optimizer_state()
+        opt = self.b.export_optimizer_state() if self.save_optimizer_state else None
         tensors = to_tf_names(self.b.export_params(), global_step=step,
                               adam=opt, adam_t=(opt or {}).get("t", 0), betas=self.betas)
         prefix = self.saver.save(tensors, os.path.join(self.logdir, self.basename), global_step=step)

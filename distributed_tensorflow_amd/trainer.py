@@ -28,6 +28,7 @@ from .cluster import ClusterSpec, TaskInfo, single_process_cluster
 from .data.mnist import read_data_sets
 from .models.spec import ModelSpec
 from .parallel import comm
+from .parallel.liveness import EXIT_PEER_LOST, Liveness, PeerLost
 from .parallel.strategies import (AsyncP2PServer, AsyncP2PWorker, AsyncRounds, LocalStrategy, SyncAllReduce)
 from .checkpoint import Saver
 from .supervisor import Supervisor
@@ -82,6 +83,7 @@ def run(F, log=print) -> dict:
     else:
         device = torch.device("cpu")
 
+    live = None
     if world > 1:
         host, port = task.cluster.master()
         cb = getattr(F, "comm_backend", "auto")
@@ -92,6 +94,15 @@ def run(F, log=print) -> dict:
         backend_name = "gloo" if (kind == "cpu" or cb == "gloo") else ("nccl" if cb == "nccl" else "cpu:gloo,cuda:nccl")
         comm.init_process_group(backend_name, task.rank, world, master_addr=host, master_port=port,
                                 device=device if (kind != "cpu" and backend_name != "gloo") else None, timeout_s=F.comm_timeout)
+        # Failure detection on a control plane of its own.  Synchronous jobs: every task depends on
+        # every worker (a lost worker can never be waited out) and on the task hosting the store.  Asynchronous jobs
+        # keep the reference's contract: workers come and go, only the ps tasks are indispensable.
+        if mode == "sync":
+            watch = task.cluster.worker_ranks() + [0]
+        else:
+            watch = task.cluster.ps_ranks() if task.is_worker else []
+        live = Liveness(host, port, task.rank, watch, name=f"{task.job_name}/{task.task_index}",
+                        timeout_s=F.heartbeat_timeout, grace_s=min(10.0, F.heartbeat_timeout), log=log)
 
     spec = ModelSpec.from_name(getattr(F, "width", "") or F.model)
     data = read_data_sets(F.data_dir, one_hot=(kind == "cpu"), synthetic=F.synthetic,
@@ -124,17 +135,25 @@ def run(F, log=print) -> dict:
             result["global_step"] = srv.serve()
             result["applied"], result["dropped_workers"] = srv.applied, srv.dropped
         elif mode == "async":
-            srv = AsyncRounds(backend, task, chief_rank, staleness=F.staleness)
+            srv = AsyncRounds(backend, task, chief_rank, staleness=F.staleness, optimizer=F.optimizer)
             srv.broadcast_initial()
             result["global_step"] = srv.serve(F.training_iter)
         else:
             # sync mode: parameters are replicated on the workers; the ps task has nothing to
             # serve.  It takes part in the initial broadcast and then blocks like server.join()
             # (reference M:105-106) until the workers are done.
+            # (on a store key, not in a collective: a barrier parked for the whole run would hit the collective
+            # timeout of a long job and turn a good run into a failed one)
             from .parallel.strategies import broadcast_state
             broadcast_state(backend, chief_rank)
-            dist.barrier()
+            try:
+                live.wait_flag("workers_done")
+            except PeerLost as e:
+                log(f"ps/{task.task_index}: {e}; the synchronous job cannot continue -- exiting")
+                live.close(orderly=False)
+                raise SystemExit(EXIT_PEER_LOST)
         log(f"ps/{task.task_index}: done")
+        _finish_control_plane(live, task, world)
         comm.shutdown()
         return result
 
@@ -143,24 +162,105 @@ def run(F, log=print) -> dict:
         strategy = LocalStrategy(backend)
     elif mode == "sync":
         strategy = SyncAllReduce(backend, task, worker_group, chief_rank, tail_group=tail_group,
-                                 p2p=bool(getattr(F, "p2p_allreduce", False)), log=log)
+                                 p2p=bool(getattr(F, "p2p_allreduce", False)), log=log,
+                                 stop_check_steps=F.health_check_steps)
     elif async_impl == "p2p":
         strategy = AsyncP2PWorker(backend, task, chief_rank)
     else:
-        strategy = AsyncRounds(backend, task, chief_rank, staleness=F.staleness)
+        strategy = AsyncRounds(backend, task, chief_rank, staleness=F.staleness, optimizer=F.optimizer)
 
+    if mode == "async" and F.optimizer == "adam" and task.is_chief:
+        log("note: in asynchronous mode the Adam moments live on the ps tasks and are not part of the chief's "
+            "checkpoints; a restarted job resumes the weights and global_step with fresh moments")
     sv = Supervisor(backend, is_chief=task.is_chief, logdir=F.logdir or None, save_model_secs=F.save_model_secs,
-                    saver=Saver(write_version=getattr(F, "saver_write_version", 2)), init_seed=F.seed, log=log)
+                    saver=Saver(write_version=getattr(F, "saver_write_version", 2)), init_seed=F.seed, log=log,
+                    save_optimizer_state=(mode != "async"))
+    health = getattr(strategy, "check_health", None)
+    sv.pre_save_check = health       # never checkpoint parameters that a timed-out peer-to-peer sum may have touched
+    _install_signal_handlers(sv, log, task)
     timer = StepTimer()
     eval_every = int(getattr(F, "eval_every", 0) or 0)
     tracing = trace.set_enabled(True) if getattr(F, "trace", False) else trace.enabled()
     images_per_step = F.batch_size * (task.num_workers if mode == "sync" else 1)
+    t_start = time.perf_counter()
+    try:
+        _train_loop(F, task, mode, backend, strategy, sv, live, timer, metrics, result, images_per_step, eval_every,
+                    tracing, health, log)
+    except SystemExit:
+        raise
+    except BaseException as e:
+        # Tell the peers now (they would otherwise find out after the heartbeat timeout), say what happened in one
+        # line, and leave with a status of its own.  A lost peer surfaces here either as PeerLost (the monitor saw
+        # it first) or as the collective's own error (gloo: connection reset; RCCL: watchdog timeout).
+        if live is not None:
+            live.announce_death(f"{type(e).__name__}: {e}")
+            lost = isinstance(e, PeerLost) or (mode == "sync" and isinstance(e, RuntimeError))
+            if lost:
+                log(f"{task.job_name}/{task.task_index}: lost contact with a peer in {mode} mode ({type(e).__name__}: "
+                    f"{str(e).splitlines()[0][:200]}); aborting.  Restart the job: it resumes from the last checkpoint "
+                    f"in {F.logdir or '<no logdir>'}.")
+                live.close(orderly=False)
+                sys.stdout.flush()
+                os._exit(EXIT_PEER_LOST)      # a wedged communicator must not be waited for in destructors
+            live.close(orderly=False)
+        raise
+    result["saved"] = list(sv.saved)
+    result["restored_from"] = sv.restored_from
+    if world > 1:
+        if mode == "sync" and task.is_chief:
+            live.set_flag("workers_done")            # releases the ps tasks blocked in their join
+        _finish_control_plane(live, task, world)
+        comm.shutdown()
+    metrics.close()
+    log("Optimization Finished!")    # reference M:193
+    return result
+
+
+def _finish_control_plane(live, task: TaskInfo, world: int):
+    """Orderly exit: mark this task done; the task hosting the store (rank 0) leaves last."""
+    if live is None:
+        return
+    live.close(orderly=True)
+    if task.rank == 0:
+        t0 = time.monotonic()
+        while time.monotonic() - t0 < 20.0:
+            try:
+                if all(live.store.check([f"dtf/done/{r}"]) for r in range(world)):
+                    break
+            except Exception:
+                break
+            time.sleep(0.05)
+
+
+def _install_signal_handlers(sv, log, task: TaskInfo):
+    """SIGTERM / SIGINT ask for an orderly stop (checkpoint, then exit) instead of killing the job mid-step: in
+    synchronous mode the request is job-wide (every worker stops after the same step)."""
+    import signal
+    import threading
+    if threading.current_thread() is not threading.main_thread():
+        return
+
+    def handler(signum, _frame):
+        log(f"{task.job_name}/{task.task_index}: signal {signum}: requesting stop")
+        sv.request_stop()
+
+    for sig in (signal.SIGTERM, signal.SIGINT):
+        try:
+            signal.signal(sig, handler)
+        except (ValueError, OSError):
+            pass
+
+
+def _train_loop(F, task, mode, backend, strategy, sv, live, timer, metrics, result, images_per_step, eval_every,
+                tracing, health, log):
     t_start = time.perf_counter()
     with sv.managed_session(strategy):
         step = strategy.step_count
         result["start_step"] = step
         local_steps = 0
         while not sv.should_stop() and step < F.training_iter:
+            if live is not None:
+                live.raise_if_failed()
             prev = step
             if tracing: trace.push(f"step {prev}")
             step = strategy.step()
@@ -171,14 +271,19 @@ def run(F, log=print) -> dict:
                     (F.fault_inject_task < 0 or F.fault_inject_task == task.task_index):
                 log(f"worker/{task.task_index}: injected fault at local step {local_steps}")
                 os._exit(17)
-            if getattr(strategy, "stop", False):
+            if F.request_stop_step >= 0 and local_steps == F.request_stop_step and \
+                    (F.request_stop_task < 0 or F.request_stop_task == task.task_index):
+                log(f"worker/{task.task_index}: requesting stop at local step {local_steps}")
                 sv.request_stop()
+            if not getattr(strategy, "coordinated_stop", False) and getattr(strategy, "stop", False):
+                sv.stop()                                  # async: the ps says the step budget is used up
+            if health is not None and local_steps % F.health_check_steps == 0:
+                health()                                   # a timed-out peer-to-peer wait ends the run, not the epoch
             if prev % F.display_step == 0:
                 loss, acc = backend.last_metrics()       # batch `prev`, pre-update weights (= ref. M:182)
                 log(format_display_line(task.job_name, task.task_index, prev, loss, acc))
                 lap = timer.lap()
                 metrics.log(step=prev, loss=loss, accuracy=acc, role=result["role"], **lap)
-                health = getattr(strategy, "check_health", None)
                 if health is not None:
                     health()
             if eval_every > 0 and task.is_chief and step // eval_every != prev // eval_every \
@@ -193,6 +298,9 @@ def run(F, log=print) -> dict:
             if tracing: trace.pop()
         strategy.finish()
         backend.synchronize()
+        if getattr(F, "dump_params", ""):
+            import numpy as np
+            np.save(F.dump_params, backend.params.detach().cpu().numpy()[:backend.layout.ctrl])
         result["global_step"] = step
         result["local_steps"] = local_steps
         result["train_seconds"] = time.perf_counter() - t_start
@@ -204,12 +312,3 @@ def run(F, log=print) -> dict:
             result["test_loss"], result["test_accuracy"] = tl, ta
             log(f"test accuracy: {ta:.4f}  test loss: {tl:.4f}  (global_step {step})")
             metrics.log(step=step, test_loss=tl, test_accuracy=ta, role=result["role"])
-    result["saved"] = list(sv.saved)
-    result["restored_from"] = sv.restored_from
-    if world > 1:
-        if mode == "sync" and task.num_ps > 0:
-            dist.barrier()            # releases the ps tasks blocked in their join
-        comm.shutdown()
-    metrics.close()
-    log("Optimization Finished!")    # reference M:193
-    return result

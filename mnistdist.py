@@ -50,7 +50,11 @@ flags.DEFINE_integer("seed", 0, "base random seed")
 flags.DEFINE_boolean("hip_graph", True, "allow replaying the single-GPU step as a captured HIP graph (used above 1024 images/step, where it measured faster than eager launches)")
 flags.DEFINE_string("dtype", "bf16", "precision of the hip backend: bf16 (bf16 MFMA kernels, fp32 accumulation + fp32 master weights) | fp32 (exact-fp32 MFMA kernel set: the reference's float32 end to end)")
 flags.DEFINE_integer("local_rank", -1, "GPU index for this process (default: LOCAL_RANK or rank % device_count)")
-flags.DEFINE_float("comm_timeout", 1800.0, "collective timeout in seconds (failure detection in sync mode)")
+flags.DEFINE_float("comm_timeout", 120.0, "collective timeout in seconds (backstop of the failure detection in sync mode)")
+flags.DEFINE_float("heartbeat_timeout", 15.0, "a task whose heartbeat on the rendezvous store stops for this long is taken for lost "
+                   "(sync mode: the job aborts with a clear message and exit status 3; async mode: only ps tasks are watched)")
+flags.DEFINE_integer("health_check_steps", 20, "sync mode on GPUs: every N steps read the job-wide stop flag and the "
+                     "peer-to-peer kernels' timeout status (one device sync each)")
 flags.DEFINE_string("metrics_file", "", "append JSONL metrics here")
 flags.DEFINE_string("comm_backend", "auto", "auto (gloo for the cpu backend, RCCL for GPU tensors) | nccl | gloo "
                     "(gloo also carries GPU tensors, staged through the host: several tasks sharing ONE GPU, which RCCL refuses)")
@@ -59,6 +63,9 @@ flags.DEFINE_boolean("p2p_allreduce", False, "sync mode, hip backend: both gradi
 flags.DEFINE_boolean("trace", False, "roctx ranges around steps/collectives/checkpoints (rocprofv3 --marker-trace)")
 flags.DEFINE_integer("fault_inject_step", -1, "test hook: crash this worker after N local steps")
 flags.DEFINE_integer("fault_inject_task", -1, "test hook: which worker task crashes (-1 = any)")
+flags.DEFINE_string("dump_params", "", "test hook: write this task's flat fp32 parameter arena to this .npy file at the end")
+flags.DEFINE_integer("request_stop_step", -1, "test hook: this worker calls Supervisor.request_stop() after N local steps")
+flags.DEFINE_integer("request_stop_task", -1, "test hook: which worker task requests the stop (-1 = any)")
 
 FLAGS = flags.FLAGS
 

@@ -163,3 +163,72 @@ def test_resumes_from_a_logdir_left_by_the_tf_0x_reference(tmp_path):
     assert int(got["Variable_8"]) == 50 and got["Variable_2"].shape == (3136, 1024)
     assert not np.array_equal(got["Variable_1"], params["wc2"])          # it trained on from the restored weights
     assert np.abs(got["Variable_1"] - params["wc2"]).max() < 0.05
+
+
+def test_sync_aborts_cleanly_on_worker_loss_and_restart_resumes(tmp_path):
+    """Synchronous mode cannot outlive a worker: when worker 1 dies hard mid-run, the surviving worker
+    and the ps task notice within the heartbeat timeout, say so in one line and exit with status 3 -- they do not
+    sit in a collective until its timeout.  A restarted job resumes from the last timed checkpoint."""
+    logdir = str(tmp_path / "logs")
+    common = ["--mode=sync", "--batch_size=16", "--display_step=5", "--learning_rate=0.01", "--noeval",
+              "--save_model_secs=0.05", "--heartbeat_timeout=6"]
+    t0 = time.time()
+    out = launch(1, 2, common + ["--steps=400"], logdir, per_task_extra={("worker", 1): ["--fault_inject_step=12"]},
+                 timeout=150)
+    took = time.time() - t0
+    assert out[("worker", 1)][0] == 17                                   # injected crash (os._exit, no goodbye)
+    rc0, o0 = out[("worker", 0)]
+    assert rc0 == 3, o0
+    assert "lost contact with a peer" in o0 or "aborting" in o0, o0
+    assert "resumes from the last checkpoint" in o0
+    assert out[("ps", 0)][0] == 3, out[("ps", 0)][1]
+    assert took < 100, took                                              # nowhere near --comm_timeout
+    saved = sorted(int(f.split("-")[1].split(".")[0]) for f in os.listdir(logdir) if f.endswith(".index"))
+    assert saved and saved[-1] <= 13, saved                              # timed saves happened before the loss
+    # restart: resumes at the last checkpoint and finishes
+    out2 = launch(1, 2, common + [f"--steps={saved[-1] + 10}"], logdir)
+    for key, (rc, o) in out2.items():
+        assert rc == 0, (key, o)
+    assert f"model.ckpt-{saved[-1]}" in out2[("worker", 0)][1] and "Restored from checkpoint" in out2[("worker", 0)][1]
+    assert f"model.ckpt-{saved[-1] + 10}.index" in os.listdir(logdir)
+
+
+def test_sync_stop_request_is_job_wide(tmp_path):
+    """sv.request_stop() on ONE synchronous worker (here a test hook; in production SIGTERM) stops EVERY worker
+    after the same step, the chief checkpoints that step, and every task exits 0 (reference: sv.should_stop(),
+    M:173 -- a worker that just left the loop would strand the other one in the next all-reduce)."""
+    logdir = str(tmp_path / "logs")
+    out = launch(1, 2, ["--mode=sync", "--batch_size=16", "--steps=500", "--display_step=1", "--learning_rate=0.01",
+                        "--noeval"], logdir, per_task_extra={("worker", 1): ["--request_stop_step=7"]})
+    for key, (rc, o) in out.items():
+        assert rc == 0, (key, o)
+    steps = [[int(m.group(2)) for m in DISPLAY.finditer(out[("worker", w)][1])] for w in (0, 1)]
+    assert steps[0] == steps[1]
+    assert 7 <= len(steps[0]) <= 9, steps                                # stopped right after the request, together
+    assert f"model.ckpt-{len(steps[0])}.index" in os.listdir(logdir)
+    assert "Optimization Finished!" in out[("worker", 0)][1]
+
+
+def test_sync_adam_restore_keeps_replicas_identical(tmp_path):
+    """A restored Adam run: the chief loads m / v / t from the checkpoint and must hand them to the other workers with
+    the parameters, or the replicas apply different updates to the same gradient.  Each worker dumps its
+    parameters at the end; they must be bitwise equal after training on from the restored state."""
+    logdir = str(tmp_path / "logs")
+    args = ["--mode=sync", "--optimizer=adam", "--batch_size=16", "--display_step=5", "--learning_rate=0.001", "--noeval"]
+    out = launch(0, 2, args + ["--steps=6"], logdir)
+    for key, (rc, o) in out.items():
+        assert rc == 0, (key, o)
+    dumps = {w: str(tmp_path / f"params_w{w}.npy") for w in (0, 1)}
+    out = launch(0, 2, args + ["--steps=14"], logdir,
+                 per_task_extra={("worker", w): [f"--dump_params={dumps[w]}"] for w in (0, 1)})
+    for key, (rc, o) in out.items():
+        assert rc == 0, (key, o)
+    assert "Restored from checkpoint" in out[("worker", 0)][1]
+    a, b = np.load(dumps[0]), np.load(dumps[1])
+    assert a.shape == b.shape and np.array_equal(a, b)
+
+
+def test_async_rounds_rejects_adam(tmp_path):
+    out = launch(1, 1, ["--mode=async", "--async_impl=broadcast", "--optimizer=adam", "--steps=4", "--noeval"],
+                 str(tmp_path / "logs"))
+    assert any(rc != 0 and "SGD only" in o for rc, o in out.values()), out
