@@ -237,7 +237,6 @@ def main():
         except Exception as e:      # collectives inside are unanimous (max over ranks), so every rank lands here together
             print(f"[bench] rank {rank}: path selection failed ({type(e).__name__}: {e}); both messages on RCCL", file=sys.stderr)
             dp.tail_p2p = dp.dense_p2p = None
-            dp.fuse_tail = False
             tail_p2p = dense_p2p = None
             tail_how = dense_how = f"rccl (path selection failed: {type(e).__name__})"
             try:
@@ -274,7 +273,6 @@ def main():
         torch.distributed.all_reduce(bad, op=torch.distributed.ReduceOp.MAX)
         if int(bad.item()):
             dp.tail_p2p = dp.dense_p2p = None
-            dp.fuse_tail = False
             for p in (tail_p2p, dense_p2p):
                 if p is not None:
                     p.close()
@@ -363,9 +361,9 @@ def main():
                     if not (skip_tail if is_tail else skip_dense):
                         real(lo, hi, group)
                 dp._allreduce = ar
-                p2p_real = (dp.tail_p2p, dp.dense_p2p, dp.fuse_tail)     # a skipped message must not go peer-to-peer either
+                p2p_real = (dp.tail_p2p, dp.dense_p2p)     # a skipped message must not go peer-to-peer either
                 if skip_tail:
-                    dp.tail_p2p, dp.fuse_tail = None, False      # -> process-group path, where ar() drops the message
+                    dp.tail_p2p = None      # -> process-group path, where ar() drops the message
                 if skip_dense:
                     dp.dense_p2p = None
                 for _ in range(20):
@@ -376,7 +374,7 @@ def main():
                     step()
                 barrier()
                 ms = max_over_ranks((time.perf_counter() - t1) * 1e3 / n)
-                dp._allreduce, (dp.tail_p2p, dp.dense_p2p, dp.fuse_tail) = real, p2p_real
+                dp._allreduce, (dp.tail_p2p, dp.dense_p2p) = real, p2p_real
                 return round(ms, 4)
 
             if tail_p2p is not None:

@@ -64,12 +64,6 @@ int dtf_fused_reduce_adam(int count, const void** part, const int* G, const int*
                           long dense_lo, long dense_hi, void* wc2T, long wc2_off, int c1, int c2, void* out_wT,
                           long out_w_off, int H, void* state, int adam_slot, long cursor_inc, long step_inc,
                           long drop_inc, hipStream_t s);
-int dtf_fused_reduce_p2p(int adam, int count, const void** part, const int* G, const int* n, const long* stride,
-                         const long* seg_off, void* w, void* g, void* m, void* v, void* shadow, const void* hyper,
-                         void* wc2T, long wc2_off, int c1, int c2, void* out_wT, long out_w_off, int H, void* state,
-                         int adam_slot, long cursor_inc, long step_inc, long drop_inc, void* const* bases, int world,
-                         int rank, long n_max, unsigned seq, int* status, double timeout_s, long tail_off,
-                         hipStream_t s);
 int dtf_p2p_tail_update(int adam, void* w, void* g, void* m, void* v, void* shadow, const void* hyper, void* wc2T,
                         long wc2_off, int c1, int c2, void* out_wT, long out_w_off, int H, void* state, int adam_slot,
                         long cursor_inc, long step_inc, long drop_inc, void* const* bases, int world, int rank, long n,

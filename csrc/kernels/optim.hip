@@ -193,12 +193,7 @@ struct FusedSgdArgs {
   const int64_t* adam_t;
 };
 
-// Data-parallel variant: between the slab sum and the update, the summed gradient of this workgroup's 64 elements
-// makes one peer-to-peer round trip (the one-shot protocol of p2p.hip, per workgroup: push into the slot (parity,
-// rank) of every rank, raise flag (parity, rank, workgroup) there, wait for the flags of the same workgroup of every
-// rank, sum the slots in rank order).  The whole tail of a data-parallel step -- slab reduction, all-reduce, update,
-// shadows, packs -- is then ONE launch, as on a single GPU.  All workgroups of the launch are co-resident (<= 1024 of
-// 256 threads), and a workgroup only ever waits for the SAME workgroup of its peers, so there is no ordering hazard.
+// One-shot peer-to-peer exchange state of the data-parallel tail (p2p_tail_allreduce_update below; protocol in p2p.hip).
 constexpr int kTailFlagSlots = 1024;   // flag slots per (parity, rank): p2p.hip sizes its allocation for this
 struct TailP2P {
   float* stage[8];      // [2][world][n_max] of every rank, as mapped here
@@ -270,10 +265,9 @@ __device__ __forceinline__ void tail_update4(const FusedSgdArgs& a, long e0, f32
   }
 }
 
-template <bool ADAM, bool P2P>
-__global__ __launch_bounds__(256) void fused_reduce_sgd(FusedSgdArgs a, TailP2P pp) {
+template <bool ADAM>
+__global__ __launch_bounds__(256) void fused_reduce_sgd(FusedSgdArgs a) {
   __shared__ f32x4 red[16][17];
-  __shared__ int p2p_bad;
   const float lr = a.hyper[0] * a.hyper[4];
   float lr_t = 0.f, b1 = 0.f, b2 = 0.f, eps = 0.f, gsc = 0.f;
   if (ADAM) {
@@ -336,40 +330,6 @@ __global__ __launch_bounds__(256) void fused_reduce_sgd(FusedSgdArgs a, TailP2P 
       gs = red[0][col];
 #pragma unroll
       for (int t = 1; t < 16; ++t) gs += red[t][col];
-    }
-    if (P2P) {
-      const int par = pp.seq & 1u, W = pp.world;
-      const size_t slot = ((size_t)par * W + pp.rank) * pp.n_max + (size_t)(e0 - pp.tail_off);
-      if (grp == 0 && i4 * 4 < sg.n) {
-#pragma unroll 1
-        for (int k = 0; k < W; ++k) *reinterpret_cast<f32x4*>(pp.stage[(pp.rank + k) % W] + slot) = gs;
-      }
-      if (threadIdx.x < 64) __threadfence_system();   // only wave 0 (grp 0..3) stored anything
-      if (threadIdx.x == 0) p2p_bad = 0;
-      __syncthreads();
-      if ((int)threadIdx.x < W) {
-        __hip_atomic_store(pp.flags[threadIdx.x] + ((size_t)par * W + pp.rank) * kTailFlagSlots + blockIdx.x, pp.seq,
-                           __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
-        const unsigned* f = pp.flags[pp.rank] + ((size_t)par * W + threadIdx.x) * kTailFlagSlots + blockIdx.x;
-        const long long t0 = wall_clock64();
-        while (__hip_atomic_load(f, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) != pp.seq) {
-          if (wall_clock64() - t0 > pp.timeout_ticks) {
-            *pp.status = 1;
-            p2p_bad = 1;
-            break;
-          }
-          __builtin_amdgcn_s_sleep(2);
-        }
-      }
-      __syncthreads();
-      // a peer never arrived: the sum would be incomplete.  Leave parameters, moments and step state untouched
-      // (the host sees *status at its next health check and ends the run; a checkpoint taken meanwhile is clean)
-      if (p2p_bad) return;
-      if (grp == 0 && i4 * 4 < sg.n) {
-        const float* mine = pp.stage[pp.rank] + (size_t)par * W * pp.n_max + (size_t)(e0 - pp.tail_off);
-        gs = *reinterpret_cast<const f32x4*>(mine);
-        for (int q = 1; q < W; ++q) gs += *reinterpret_cast<const f32x4*>(mine + (size_t)q * pp.n_max);
-      }
     }
     if (grp == 0 && i4 * 4 < sg.n) {
       tail_update4<ADAM>(a, e0, gs, wv, lr, lr_t, b1, b2, eps, gsc);
@@ -442,7 +402,9 @@ __global__ __launch_bounds__(256) void p2p_tail_allreduce_update(FusedSgdArgs a,
     }
   }
   __syncthreads();
-  if (p2p_bad) return;   // incomplete sum: no update, no state advance (see fused_reduce_sgd)
+  // a peer never arrived: the sum would be incomplete.  Leave parameters, moments and step state untouched (the host
+  // sees *status at its next health check and ends the run; a checkpoint taken meanwhile is clean)
+  if (p2p_bad) return;
   const float* mine = pp.stage[pp.rank] + (size_t)par * W * pp.n_max;
   for (int i = lo4 + tid; i < hi4; i += 256) {
     const long e0 = pp.tail_off + 4L * i;
@@ -530,7 +492,7 @@ static int fused_tail_launch(bool adam, void* m, void* v, int adam_slot, int cou
                              const int* n, const long* stride, const long* seg_off, void* w, void* g, void* shadow,
                              const void* hyper, long dense_lo, long dense_hi, void* wc2T, long wc2_off, int c1, int c2,
                              void* out_wT, long out_w_off, int H, void* state, long cursor_inc, long step_inc,
-                             long drop_inc, hipStream_t s, const TailP2P* p2p = nullptr) {
+                             long drop_inc, hipStream_t s) {
   if (count < 1 || count > 3 || (dense_lo & 3) || (dense_hi & 3) || (wc2_off & 3)) return -3;
   if (adam && (!m || !v || !state || adam_slot < 3 || adam_slot > 6)) return -3;
   if (wc2T && ((c1 % 32) || (c2 % 32))) return -3;
@@ -567,14 +529,8 @@ static int fused_tail_launch(bool adam, void* m, void* v, int adam_slot, int cou
   a.adam_t = adam ? (const int64_t*)state + adam_slot : nullptr;
   if (adam) hipLaunchKernelGGL(advance_state_kernel, dim3(1), dim3(1), 0, s, StepAdvance{(int64_t*)state, 0, 0, 0, adam_slot});
   const int dense_blocks = dense_hi > dense_lo ? grid_for((dense_hi - dense_lo) / 4) : 0;
-  if (p2p) {
-    if (blocks > kTailFlagSlots || dense_blocks != 0) return -1;   // every workgroup needs its own flag slot
-    if (adam) hipLaunchKernelGGL((fused_reduce_sgd<true, true>), dim3(blocks), dim3(256), 0, s, a, *p2p);
-    else hipLaunchKernelGGL((fused_reduce_sgd<false, true>), dim3(blocks), dim3(256), 0, s, a, *p2p);
-    return (int)hipGetLastError();
-  }
-  if (adam) hipLaunchKernelGGL((fused_reduce_sgd<true, false>), dim3(blocks + dense_blocks), dim3(256), 0, s, a, TailP2P{});
-  else hipLaunchKernelGGL((fused_reduce_sgd<false, false>), dim3(blocks + dense_blocks), dim3(256), 0, s, a, TailP2P{});
+  if (adam) hipLaunchKernelGGL(fused_reduce_sgd<true>, dim3(blocks + dense_blocks), dim3(256), 0, s, a);
+  else hipLaunchKernelGGL(fused_reduce_sgd<false>, dim3(blocks + dense_blocks), dim3(256), 0, s, a);
   return (int)hipGetLastError();
 }
 
@@ -595,35 +551,6 @@ int dtf_fused_reduce_adam(int count, const void** part, const int* G, const int*
                           long drop_inc, hipStream_t s) {
   return fused_tail_launch(true, m, v, adam_slot, count, part, G, n, stride, seg_off, w, g, shadow, hyper, dense_lo,
                            dense_hi, wc2T, wc2_off, c1, c2, out_wT, out_w_off, H, state, cursor_inc, step_inc, drop_inc, s);
-}
-
-// The data-parallel tail in one launch (fused_reduce_sgd<.., P2P>): the segments are the slab-backed tail of the arena
-// (tail_off = its first float), bases[r] = rank r's p2p allocation (p2p.hip: dtf_p2p_alloc/import; stage
-// [2][world][n_max] floats, then the flags).  adam != 0: m, v, state[adam_slot] as in dtf_fused_reduce_adam.
-int dtf_fused_reduce_p2p(int adam, int count, const void** part, const int* G, const int* n, const long* stride,
-                         const long* seg_off, void* w, void* g, void* m, void* v, void* shadow, const void* hyper,
-                         void* wc2T, long wc2_off, int c1, int c2, void* out_wT, long out_w_off, int H, void* state,
-                         int adam_slot, long cursor_inc, long step_inc, long drop_inc, void* const* bases, int world,
-                         int rank, long n_max, unsigned seq, int* status, double timeout_s, long tail_off,
-                         hipStream_t s) {
-  if (world < 1 || world > 8 || rank < 0 || rank >= world || (n_max & 3) || seq == 0 || (tail_off & 3)) return -2;
-  for (int k = 0; k < count; ++k)
-    if (seg_off[k] < tail_off || seg_off[k] + n[k] > tail_off + n_max) return -2;
-  TailP2P pp;
-  for (int r = 0; r < 8; ++r) {
-    char* base = static_cast<char*>(bases[r < world ? r : rank]);
-    pp.stage[r] = reinterpret_cast<float*>(base);
-    pp.flags[r] = reinterpret_cast<unsigned*>(base + 2L * world * n_max * 4);
-  }
-  pp.status = status;
-  pp.world = world;
-  pp.rank = rank;
-  pp.n_max = (int)n_max;
-  pp.seq = seq;
-  pp.timeout_ticks = (long long)(timeout_s * 1e8);
-  pp.tail_off = tail_off;
-  return fused_tail_launch(adam != 0, m, v, adam_slot, count, part, G, n, stride, seg_off, w, g, shadow, hyper, 0, 0, wc2T,
-                           wc2_off, c1, c2, out_wT, out_w_off, H, state, cursor_inc, step_inc, drop_inc, s, &pp);
 }
 
 // Data-parallel tail, coarse-grained (p2p_tail_allreduce_update): g[tail_off, tail_off + n) holds this rank's reduced

@@ -364,7 +364,6 @@ int dtf_engine_dp_phase1(const DtfEngineDesc* e, int wait_dense_updated, hipStre
   return (int)hipStreamWaitEvent(comm, e->ev_dense_ready, 0);
 }
 
-// reduce_tail == 0: the head/conv slabs are left unreduced for dtf_engine_dp_phase3_p2p (which sums them itself)
 int dtf_engine_dp_phase2(const DtfEngineDesc* e, long dense_hi, int dense_adam_slot, int reduce_tail,
                          const void* dense_grad_src, hipStream_t s, hipStream_t comm, hipStream_t tail) {
   DTF_TRY(backward_conv_impl(e, e->ds_images, e->idx, 1, reduce_tail ? 2 : 0, 1, s));
@@ -413,27 +412,16 @@ int dtf_engine_dp_phase3(const DtfEngineDesc* e, long dense_hi, int tail_adam_sl
   return 0;
 }
 
-// phase 3 with the tail all-reduce and the tail update in ONE launch on the compute stream (optim.hip), two variants:
+// phase 3 with the tail all-reduce and the tail update in ONE launch on the compute stream (optim.hip
+// p2p_tail_allreduce_update): the reduced tail (phase 2 with reduce_tail == 1) goes through 64 fat workgroups that
+// exchange it peer to peer and apply the update to what they have just summed
 int dtf_engine_dp_phase3_p2p(const DtfEngineDesc* e, int tail_adam_slot, long step_inc, int wait_dense, hipStream_t s,
                              void* const* bases, int world, int rank, long n_max, unsigned seq, int* status,
-                             double timeout_s, int slabs) {
-  if (slabs) {
-    // (a) everything in the fused tail kernel, one exchange per workgroup (needs phase 2 with reduce_tail == 0)
-    const void* part[3] = {e->head_part, e->c2_part, e->c1_part};
-    int G[3] = {e->head_ks, e->c2_g, e->c1_g}, n[3] = {(int)e->head_stride, (int)e->c2_stride, (int)e->c1_stride};
-    long st[3] = {e->head_stride, e->c2_stride, e->c1_stride};
-    long off[3] = {e->off_out_w, e->off_wc2, e->off_wc1};
-    DTF_TRY(dtf_fused_reduce_p2p(e->optimizer != 0, 3, part, G, n, st, off, e->params, e->grads, e->adam_m, e->adam_v,
-                                 shadow_of(e), e->hyper, e->wc2T, e->off_wc2, e->c1, e->c2, e->out_wT, e->off_out_w, e->hidden,
-                                 e->state, tail_adam_slot, e->B, step_inc, 1, bases, world, rank, n_max, seq, status,
-                                 timeout_s, e->off_out_w, s));
-  } else {
-    // (b) the reduced tail (phase 2 with reduce_tail == 1) through 64 fat workgroups that also apply the update
-    DTF_TRY(dtf_p2p_tail_update(e->optimizer != 0, e->params, e->grads, e->adam_m, e->adam_v, shadow_of(e), e->hyper, e->wc2T,
-                                e->off_wc2, e->c1, e->c2, e->out_wT, e->off_out_w, e->hidden, e->state, tail_adam_slot,
-                                e->B, step_inc, 1, bases, world, rank, e->n_total - e->off_out_w, n_max, seq, status,
-                                timeout_s, e->off_out_w, s));
-  }
+                             double timeout_s) {
+  DTF_TRY(dtf_p2p_tail_update(e->optimizer != 0, e->params, e->grads, e->adam_m, e->adam_v, shadow_of(e), e->hyper, e->wc2T,
+                              e->off_wc2, e->c1, e->c2, e->out_wT, e->off_out_w, e->hidden, e->state, tail_adam_slot,
+                              e->B, step_inc, 1, bases, world, rank, e->n_total - e->off_out_w, n_max, seq, status,
+                              timeout_s, e->off_out_w, s));
   if (wait_dense) HIP_TRY(hipStreamWaitEvent(s, e->ev_dense_updated, 0));
   return 0;
 }

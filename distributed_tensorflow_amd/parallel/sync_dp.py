@@ -70,8 +70,7 @@ class SyncDataParallel:
     DENSE_SLOT, TAIL_SLOT = 3, 4   # per-range Adam step counters in the device state
 
     def __init__(self, engine: HipEngine, bucket_mb: float = 64.0, group=None, tail_group=None,
-                 defer_dense_update: bool = True, tail_p2p=None, dense_p2p=None,
-                 fuse_tail_p2p: bool = False, p2p_tail_update: bool = True):
+                 defer_dense_update: bool = True, tail_p2p=None, dense_p2p=None, p2p_tail_update: bool = True):
         self.eng = engine
         self.group = group
         self.tail_group = tail_group if tail_group is not None else group
@@ -85,16 +84,14 @@ class SyncDataParallel:
         # tail_p2p (parallel/p2p.py): the tail goes through the one-shot peer-to-peer kernel instead of RCCL, also on
         # the compute stream.
         self.tail_p2p = tail_p2p
-        # fuse_tail_p2p: the exchange INSIDE the fused tail kernel (slab sums -> peer exchange -> update + shadows + packs in
-        # one launch, csrc/kernels/optim.hip fused_reduce_sgd<.., P2P>) instead of {slab reduce, all-reduce, update}.
-        # Correct (tests) but OFF: each of its ~1000 workgroups pays a system-scope release fence (an L2 write-back),
-        # measured +22 us per step at world 1 against -2 launches; the 64-workgroup stand-alone kernel pays 64.
+        # (A variant with the exchange INSIDE the fused tail kernel -- ~1000 workgroups each doing their own peer
+        # round trip -- was removed: +22 us per step at world 1 from the per-workgroup system-scope fences, and it
+        # needs every one of those spinning workgroups co-resident next to the overlapped dense kernel, which held
+        # only by accident of the stream -> hardware-queue mapping.)
         # p2p_tail_update (default with tail_p2p): the exchange kernel also applies the tail update to what it has just
         # summed (csrc/kernels/optim.hip p2p_tail_allreduce_update: 64 fat workgroups, 64 fences), so the step ends
         # {slab reduce, exchange + update} instead of {slab reduce, exchange, update}.
         self.p2p_tail_update = bool(p2p_tail_update) and tail_p2p is not None
-        tail_blocks = sum((n // 4 + 15) // 16 for n in (engine.head_stride, engine.c2_stride, engine.c1_stride))
-        self.fuse_tail = bool(fuse_tail_p2p) and tail_p2p is not None and tail_blocks <= 1024
         # dense_p2p: the 12.8 MB message through the two-shot peer-to-peer kernel (on the comm stream, like RCCL's)
         self.dense_p2p = dense_p2p
         self.tail_stream = None if (tail_group is not None or tail_p2p is not None) else self.comm_stream
@@ -144,15 +141,14 @@ class SyncDataParallel:
                 for lo, hi in self.dense_buckets:
                     self._allreduce(lo, hi, self.group)
         if tr: tr.pop(); tr.push("dp_phase2: conv backward")
-        check(lib.dtf_engine_dp_phase2(d, self.n_dense, self.DENSE_SLOT, 0 if self.fuse_tail else 1, dense_src, cur, comm,
+        check(lib.dtf_engine_dp_phase2(d, self.n_dense, self.DENSE_SLOT, 1, dense_src, cur, comm,
                                        tail), "dp_phase2")
-        if self.tail_p2p is not None and (self.fuse_tail or self.p2p_tail_update):
+        if self.tail_p2p is not None and self.p2p_tail_update:
             if tr: tr.pop(); tr.push("dp_phase3: p2p all-reduce + update (one launch)")
             p = self.tail_p2p
             p.seq += 1
             check(lib.dtf_engine_dp_phase3_p2p(d, self.TAIL_SLOT, eng.step_inc, int(not self.defer), cur, p._bases, p.world,
-                                               p.rank, p.n_max, p.seq, p._status.data_ptr(), p.timeout_s,
-                                               int(self.fuse_tail)), "dp_phase3_p2p")
+                                               p.rank, p.n_max, p.seq, p._status.data_ptr(), p.timeout_s), "dp_phase3_p2p")
             if tr: tr.pop()
             self._have_pending_dense = self.defer
             return

@@ -35,7 +35,7 @@ if tail.startswith("p2p"):     # both messages through the peer-to-peer kernels 
     tail_p2p = P2PAllReduce(eng.layout.total - n_dense, eng.device)
     dense_p2p = P2PAllReduce(n_dense, eng.device, two_shot=True)
 dp = SyncDataParallel(eng, tail_group=dist.new_group(), tail_p2p=tail_p2p, dense_p2p=dense_p2p,
-                      fuse_tail_p2p=(tail == "p2p-fused"), p2p_tail_update=(tail != "p2p-plain"))
+                      p2p_tail_update=(tail != "p2p-plain"))
 dp.broadcast_parameters()
 
 refs = [engine(1000 + q) for q in (0, 1)]

@@ -54,7 +54,7 @@ def test_async_parameter_server_hip_backend_over_gloo(gpu_lib, tmp_path, impl):
 
 
 @pytest.mark.parametrize("optimizer,tail", [("sgd", "pg"), ("adam", "pg"), ("sgd", "p2p"), ("adam", "p2p"),
-                                            ("sgd", "p2p-plain"), ("sgd", "p2p-fused"), ("adam", "p2p-fused")])
+                                            ("sgd", "p2p-plain")])
 def test_overlapped_dp_schedule_world2_over_gloo(gpu_lib, optimizer, tail):
     """parallel/sync_dp.py (the schedule bench.py runs on N GPUs: deferred dense update, two communicators,
     1/world scaling in the optimizer kernels) with TWO ranks, each feeding different batches: against a replay
