@@ -175,6 +175,34 @@ __global__ __launch_bounds__(256) void transpose_head_w(const float* __restrict_
   if (i < H * kCls) out[i] = in[(size_t)(i % H) * kCls + i / H];
 }
 
+// K9: batch reductions of the per-row loss / correctness the head kernel leaves behind (reference .idea/MNISTDist.py:148
+// reduce_mean(cost), :153 reduce_mean(cast(correct_pred))).  One workgroup, fixed order (deterministic), fp64 partial
+// sums; acc[0] = sum of losses, acc[1] = number of correct rows.  accumulate != 0 adds to acc (evaluation walks a
+// dataset in chunks and reads acc once at the end: one host synchronisation per evaluation).
+__global__ __launch_bounds__(256) void metrics_reduce(const float* __restrict__ loss_rows, const float* __restrict__ correct_rows,
+                                                      int n, double* __restrict__ acc, int accumulate) {
+  __shared__ double red[2][256];
+  double l = 0.0, c = 0.0;
+  for (int i = threadIdx.x; i < n; i += 256) {
+    l += (double)loss_rows[i];
+    c += (double)correct_rows[i];
+  }
+  red[0][threadIdx.x] = l;
+  red[1][threadIdx.x] = c;
+  __syncthreads();
+  for (int h = 128; h >= 1; h >>= 1) {
+    if ((int)threadIdx.x < h) {
+      red[0][threadIdx.x] += red[0][threadIdx.x + h];
+      red[1][threadIdx.x] += red[1][threadIdx.x + h];
+    }
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) {
+    acc[0] = (accumulate ? acc[0] : 0.0) + red[0][0];
+    acc[1] = (accumulate ? acc[1] : 0.0) + red[1][0];
+  }
+}
+
 // grid = (H/256, KS).  slab layout per k-split: [H*10 dW_out][12: db_out padded][H db_d1]
 // (body in head_wgrad_core.hpp: the training step runs it inside the fc1 dgrad GEMM launch instead)
 template <typename AT>
@@ -246,6 +274,14 @@ int dtf_head_f32_fused_fwd_bwd(const void* part, int S, const void* bias1, float
   Fc1Epilogue epi{(const float*)part, (const float*)bias1, S, DropoutArgs{keep_prob, seed, (const int64_t*)state}};
   return head_launch<float>(h1, epi, wT, bias, labels, idx, logits_out, loss_rows, correct_rows, dlogits, da, B, H,
                             grad_scale, inv_keep, backward, s);
+}
+
+// acc (2 doubles) = [sum loss_rows[0..n), sum correct_rows[0..n)]; accumulate != 0: added to what acc holds
+int dtf_metrics_reduce(const void* loss_rows, const void* correct_rows, int n, void* acc, int accumulate, hipStream_t s) {
+  if (n < 0 || !acc) return -2;
+  hipLaunchKernelGGL(metrics_reduce, dim3(1), dim3(256), 0, s, (const float*)loss_rows, (const float*)correct_rows, n,
+                     (double*)acc, accumulate);
+  return (int)hipGetLastError();
 }
 
 // wT[10][H] = w[H][10]^T (fp32)

@@ -57,6 +57,14 @@ class Backend:
     def export_optimizer_state(self) -> Optional[dict]: return None
     def load_optimizer_state(self, state: dict): pass
 
+    def snapshot(self, with_optimizer: bool = True):
+        """A consistent copy of (parameters, global_step, optimizer slots) taken BETWEEN two steps without waiting
+        for it: returns ``finish() -> (params by name, global_step, optimizer state or None)``, to be called from
+        the checkpoint writer thread (it blocks there until the copy has landed in host memory)."""
+        params, step = self.export_params(), self.get_global_step()
+        opt = self.export_optimizer_state() if with_optimizer else None
+        return lambda: (params, step, opt)
+
     # coordinated stop (SURVEY X6): the last 4 floats of the gradient arena travel in every synchronous step's
     # all-reduce; a worker that wants the job to stop raises its flag there and every worker reads the same sum
     def raise_stop_flag(self):
@@ -215,6 +223,48 @@ class HipBackend(Backend):
 
     def synchronize(self):
         torch.cuda.synchronize(self.engine.device)
+
+    def snapshot(self, with_optimizer: bool = True):
+        """Device-side snapshot on a side stream: D2D copy of the arenas (the training stream only waits for THAT,
+        a few microseconds), then an asynchronous D2H copy into pinned memory that overlaps the following steps."""
+        e = self.engine
+        dev = e.device
+        adam = with_optimizer and e.optimizer == "adam"
+        if getattr(self, "_snap", None) is None:
+            n = self.layout.total
+            k = 3 if e.optimizer == "adam" else 1
+            self._snap = dict(stream=torch.cuda.Stream(dev), dev=torch.empty((k, n), dtype=torch.float32, device=dev),
+                              host=torch.empty((k, n), dtype=torch.float32).pin_memory(),
+                              st_dev=torch.empty_like(e.state), st_host=torch.empty(e.state.shape, dtype=e.state.dtype).pin_memory(),
+                              copied=torch.cuda.Event(), landed=torch.cuda.Event())
+        sn = self._snap
+        cur = torch.cuda.current_stream(dev)
+        sn["stream"].wait_stream(cur)
+        with torch.cuda.stream(sn["stream"]):
+            sn["dev"][0].copy_(e.params, non_blocking=True)
+            if adam:
+                sn["dev"][1].copy_(e.adam_m, non_blocking=True)
+                sn["dev"][2].copy_(e.adam_v, non_blocking=True)
+            sn["st_dev"].copy_(e.state, non_blocking=True)
+            sn["copied"].record()
+            sn["host"].copy_(sn["dev"], non_blocking=True)
+            sn["st_host"].copy_(sn["st_dev"], non_blocking=True)
+            sn["landed"].record()
+        cur.wait_event(sn["copied"])          # the next step may overwrite the arenas once the D2D copy is done
+        lay = self.layout
+
+        def finish():
+            sn["landed"].synchronize()        # on the writer thread
+            host, st = sn["host"], sn["st_host"]
+            params = {nm: lay.view(host[0], nm).numpy().copy() for nm in lay.names()}
+            step = int(st[e.STATE_STEP])
+            opt = None
+            if adam:
+                opt = {"m": {nm: lay.view(host[1], nm).numpy().copy() for nm in lay.names()},
+                       "v": {nm: lay.view(host[2], nm).numpy().copy() for nm in lay.names()},
+                       "t": int(st[e.STATE_ADAM_T])}
+            return params, step, opt
+        return finish
 
     def get_global_step(self): return self.engine.global_step
     def set_global_step(self, v):

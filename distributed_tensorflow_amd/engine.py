@@ -156,6 +156,8 @@ class HipEngine:
         self.loss_rows = torch.empty(B, **f32)
         self.correct_rows = torch.empty(B, **f32)
         self.dlogits = torch.empty((B, spec.classes), **f32)
+        self._metrics_acc = torch.zeros(2, dtype=torch.float64, device=dev)          # K9 accumulator [sum loss, #correct]
+        self._metrics_host = torch.zeros(2, dtype=torch.float64).pin_memory()
         self.da = torch.empty((B, H), **act)
         self.dflat = torch.empty((B, FLAT), **act)
         self.dp1 = torch.empty((B, 14, 14, C1), **act)
@@ -410,21 +412,34 @@ class HipEngine:
         else:
             self.launch_train_step()
 
+    def _metrics(self, n: int, accumulate: bool):
+        """K9: reduce loss_rows / correct_rows[0..n) into the device accumulator (one tiny launch, no ATen)."""
+        check(self.lib.dtf_metrics_reduce(ptr(self.loss_rows), ptr(self.correct_rows), n, ptr(self._metrics_acc),
+                                          int(accumulate), self._s()), "metrics_reduce")
+
+    def _read_metrics(self):
+        """One 16-byte device-to-host copy into pinned memory + one stream synchronisation."""
+        self._metrics_host.copy_(self._metrics_acc, non_blocking=True)
+        torch.cuda.current_stream(self.device).synchronize()
+        return float(self._metrics_host[0]), float(self._metrics_host[1])
+
     def last_metrics(self):
         """(mean loss, accuracy) of the most recent forward; forces a device sync."""
-        return float(self.loss_rows.mean().item()), float(self.correct_rows.mean().item())
+        self._metrics(self.B, accumulate=False)
+        sl, sc = self._read_metrics()
+        return sl / self.B, sc / self.B
 
     @torch.no_grad()
     def evaluate(self, images: torch.Tensor, labels: torch.Tensor):
-        """Mean loss / accuracy over an arbitrary number of rows (chunks of the engine batch)."""
+        """Mean loss / accuracy over an arbitrary number of rows (chunks of the engine batch): every chunk's forward
+        and reduction are enqueued back to back, the host synchronises ONCE at the end."""
         n = images.shape[0]
-        tot_loss, tot_ok = 0.0, 0.0
         for lo in range(0, n, self.B):
             hi = min(n, lo + self.B)
             self.launch_forward(images[lo:hi], labels[lo:hi], None, backward=False, n=hi - lo, train_mode=False)
-            tot_loss += float(self.loss_rows[:hi - lo].sum().item())
-            tot_ok += float(self.correct_rows[:hi - lo].sum().item())
-        return tot_loss / n, tot_ok / n
+            self._metrics(hi - lo, accumulate=lo > 0)
+        sl, sc = self._read_metrics()
+        return sl / n, sc / n
 
     @torch.no_grad()
     def predict_logits(self, images: torch.Tensor) -> torch.Tensor:

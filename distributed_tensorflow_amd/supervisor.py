@@ -24,6 +24,7 @@ from typing import Callable, Optional
 
 from .backends import Backend
 from .checkpoint import Saver, from_tf_names, latest_checkpoint, to_tf_names
+from .checkpoint.async_writer import AsyncCheckpointWriter
 
 
 class Supervisor:
@@ -42,6 +43,8 @@ class Supervisor:
         self.betas = adam_betas
         self.save_optimizer_state = save_optimizer_state   # False in async mode: the slots live on the ps tasks
         self.pre_save_check: Optional[Callable[[], None]] = None   # raises if the state must not be checkpointed
+        self._writer: Optional[AsyncCheckpointWriter] = None
+        self.save_wait_seconds = 0.0      # time the training thread spent inside save() (snapshot + queueing only)
         self._stop = False
         self._strategy = None
         self._last_save = time.monotonic()
@@ -59,7 +62,13 @@ class Supervisor:
             if step is not None:
                 self.b.set_global_step(step)
             if adam:
+                # Adam's step count comes from the saved beta1_power (= beta1^(t+1), TF's slot variable), not from
+                # global_step: the two differ whenever global_step does not advance by one per Adam update
                 t = step or 0
+                b1p = adam.get("beta1_power")
+                if b1p is not None and 0.0 < b1p < 1.0 and 0.0 < self.betas[0] < 1.0:
+                    import math
+                    t = max(0, int(round(math.log(b1p) / math.log(self.betas[0]))) - 1)
                 self.b.load_optimizer_state({"m": adam["m"], "v": adam["v"], "t": t})
             self.restored_from = prefix
             self.log(f"Restored from checkpoint {prefix} (global_step={self.b.get_global_step()})")
@@ -86,6 +95,9 @@ class Supervisor:
                 self.save()
         finally:
             self._stop = True
+            if self._writer is not None:
+                self._writer.close()          # every queued checkpoint is on disk before the session ends
+                self._writer = None
 
     # -- stop coordination ---------------------------------------------------
     def should_stop(self) -> bool:
@@ -107,20 +119,34 @@ class Supervisor:
         self._stop = True
 
     # -- checkpoints ---------------------------------------------------------
-    def save(self) -> Optional[str]:
+    def save(self, block: bool = False) -> Optional[str]:
+        """Snapshot the state now (between two steps) and write it in the background; returns the checkpoint prefix
+        the files will have.  ``block`` waits for the files (the final save does, through the writer's close)."""
         if not (self.is_chief and self.logdir):
             return None
-        self.b.synchronize()
+        t0 = time.monotonic()
         if self.pre_save_check is not None:
-            self.pre_save_check()
-        step = self.b.get_global_step()
-        opt = self.b.export_optimizer_state() if self.save_optimizer_state else None
-        tensors = to_tf_names(self.b.export_params(), global_step=step,
-                              adam=opt, adam_t=(opt or {}).get("t", 0), betas=self.betas)
-        prefix = self.saver.save(tensors, os.path.join(self.logdir, self.basename), global_step=step)
+            self.pre_save_check()             # e.g. a timed-out peer-to-peer sum: raise instead of checkpointing it
+        st = self._strategy
+        if st is not None and getattr(st, "_dp", None) is not None:
+            st._dp.flush()                    # a deferred dense update is ordered before the snapshot (GPU-side wait)
+        if self._writer is None:
+            self._writer = AsyncCheckpointWriter(self.log)
+        self._writer.wait()                   # one snapshot buffer: the previous save must have been written
+        finish = self.b.snapshot(with_optimizer=self.save_optimizer_state)
+        base = os.path.join(self.logdir, self.basename)
+
+        def job():
+            params, step, opt = finish()
+            tensors = to_tf_names(params, global_step=step, adam=opt, adam_t=(opt or {}).get("t", 0), betas=self.betas)
+            self.saved.append(self.saver.save(tensors, base, global_step=step))
+
+        self._writer.submit(job)
         self._last_save = time.monotonic()
-        self.saved.append(prefix)
-        return prefix
+        self.save_wait_seconds += self._last_save - t0
+        if block:
+            self._writer.wait()
+        return base
 
     def maybe_save(self) -> Optional[str]:
         """Timed save (chief): call between steps."""
