@@ -3,7 +3,11 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include "diag.hpp"
+
 extern "C" {
+// "release" for the shipped build, "diag" for a library compiled with -DDTF_DIAG=1 (csrc/kernels/diag.hpp)
+const char* dtf_build_flavour();
 int dtf_conv1_fwd(const void* images, const void* idx, const void* w, const void* bias, void* pooled, void* arg,
                   int B, int cout, int grid, hipStream_t s);
 int dtf_conv1_fwd_sampled(const void* images, void* idx_out, const void* state, unsigned n, unsigned hb,

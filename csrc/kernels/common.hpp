@@ -9,6 +9,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include "diag.hpp"
+
 namespace dtf {
 
 typedef __bf16 bf16;

@@ -30,15 +30,9 @@
 // the shipped library always has 0): 1 = no B global loads in the k-loop, 2 = no A LDS reads,
 // 4 = no MFMAs, 8 = no staging loads, 16 = no epilogue stores; wgrad: 32 = no x staging,
 // 64 = no MFMAs, 128 = no dY staging/expansion, 256 = no k-loop at all, 512 = no slab write.
-#ifndef DTF_ABLATE
-#define DTF_ABLATE 0
-#endif
 // Tile configuration of the 32->64 layer: KTOT, KC, NC, IMGS, NW, MODE, min waves/SIMD
 // (overridable so tools/conv_ablate.py can sweep it)
 // Diagnostic: delay the second half of the grid by DTF_STAGGER microseconds (tools/conv_ablate.py stagger)
-#ifndef DTF_STAGGER
-#define DTF_STAGGER 0
-#endif
 #ifndef DTF_FWD_CFG
 #define DTF_FWD_CFG 32, 32, 64, 2, 2, MODE_FWD, 4
 #endif
@@ -48,9 +42,6 @@
 
 // Diagnostic (-DDTF_TIMING=1, tools/conv_timeline.py): wave 0 of every igemm workgroup stamps the 100 MHz wall
 // clock at its phase boundaries into a buffer registered with dtf_conv2_set_timing_buf
-#ifndef DTF_TIMING
-#define DTF_TIMING 0
-#endif
 
 namespace dtf {
 
@@ -152,9 +143,6 @@ __global__ __launch_bounds__(IMGS * 2 * NW * 64, MINW) void conv5x5_igemm(
   DTF_STAMP(0);
 #if DTF_TIMING
   if (threadIdx.x == 0 && g_timing_buf) g_timing_buf[(size_t)blockIdx.x * 16 + 6] = clock64();
-#endif
-#ifndef DTF_STAGGER_MODE
-#define DTF_STAGGER_MODE 0
 #endif
   if (DTF_STAGGER > 0 && (DTF_STAGGER_MODE == 0 ? blockIdx.x >= gridDim.x / 2
                           : DTF_STAGGER_MODE == 1 ? (blockIdx.x & 1) != 0
@@ -692,9 +680,6 @@ __global__ __launch_bounds__(512, 2) void conv5x5_wgrad(
     // (tools/conv_timeline.py: 9.1 us of staging on the critical path of a 31 us kernel).
 #if DTF_TIMING
     { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); long long t = wall_clock64(); t_v += t - t_prev; t_prev = t; }
-#endif
-#ifndef DTF_WGRAD_STAGE_LAST
-#define DTF_WGRAD_STAGE_LAST 0   // diagnostic: 1 = the old order (k-loop first)
 #endif
     if (!DTF_WGRAD_STAGE_LAST && b + 1 < b_end) {
       stage(kBufElems - boff);

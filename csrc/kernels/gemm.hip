@@ -43,9 +43,6 @@ enum { EPI_STORE = 0, EPI_BIAS_RELU_DROPOUT = 1, EPI_NOSTORE_DIAG = 2 };
 // ---------------------------------------------------------------------------------------------
 // Diagnostic (-DDTF_TIMING=1, tools/conv_timeline.py run .. gemm): thread 0 of every workgroup stamps the
 // 100 MHz wall clock: 0 start, 1 first tile in LDS, 2 main loop left, 3 epilogue done
-#ifndef DTF_TIMING
-#define DTF_TIMING 0
-#endif
 #if DTF_TIMING
 __device__ long long* g_gemm_timing = nullptr;
 #define DTF_GSTAMP(slot)                                                                          \
@@ -84,9 +81,6 @@ __device__ __forceinline__ void gemm_pipeline(int T, GL&& gload, SW&& swrite, CP
 // HEADW: the launch is a 1-D grid of the GEMM's tiles FOLLOWED by hw.nbx * KS workgroups that compute the
 // output-layer weight gradient (head_wgrad_core.hpp) -- independent work that fills the CUs this GEMM
 // leaves idle (fc1 dgrad: 200 tiles on 256 CUs) instead of paying for a launch of its own.
-#ifndef DTF_GEMM_MINW
-#define DTF_GEMM_MINW 1   // diagnostic: minimum waves per SIMD the GEMM kernels are compiled for
-#endif
 template <int BM, int BN, int NW, int EPI, bool HEADW = false>
 __global__ __launch_bounds__(NW * 64, DTF_GEMM_MINW) void gemm_nt_bf16(const bf16* A, const bf16* Bm, bf16* __restrict__ C,
                                                         const float* __restrict__ bias, int M, int N, int K,

@@ -19,9 +19,6 @@
 
 // Diagnostic (-DDTF_TIMING=1, tools/conv_timeline.py run .. head): thread 0 of every workgroup stamps the 100 MHz
 // wall clock at the phase boundaries of its first row
-#ifndef DTF_TIMING
-#define DTF_TIMING 0
-#endif
 
 namespace dtf {
 

@@ -50,6 +50,8 @@ static inline bool is_f32(const DtfEngineDesc* e) { return e->dtype == 1; }
 // the fp32 configuration keeps no bf16 copies: optimizer kernels are told so with shadow == NULL
 static inline void* shadow_of(const DtfEngineDesc* e) { return is_f32(e) ? nullptr : e->shadow; }
 
+const char* dtf_build_flavour() { return DTF_DIAG ? "diag" : "release"; }
+
 int dtf_engine_init(DtfEngineDesc* e) {
   // side streams only for the backward fork/join (multi_stream): a process has 4 hardware queues by default
   // (GPU_MAX_HW_QUEUES), and the data-parallel step already uses compute + comm + RCCL's own streams
@@ -193,9 +195,6 @@ static int fc1_dgrad(const DtfEngineDesc* e, int head_w, hipStream_t s) {
                      e->hidden, e->flat, 0, 1.0f, 0, nullptr, 0, s);
 }
 
-#ifndef DTF_EXP_DP
-#define DTF_EXP_DP 0   // timing experiments only (break the step!): 1 = no ev_dgrad record/wait, 2 = no dense update, 4 = dense update on s
-#endif
 static int backward_conv_impl(const DtfEngineDesc* e, const void* images, const void* idx, int record_dgrad,
                               int reduce, int head_w, hipStream_t s) {
   DTF_TRY(fc1_dgrad(e, head_w, s));

@@ -176,8 +176,20 @@ def load() -> ctypes.CDLL:
         fn = getattr(lib, name)
         fn.argtypes = argtypes
         fn.restype = c_long if name in ("dtf_p2p_bytes", "dtf_p2p2_bytes") else c_int
+    lib.dtf_build_flavour.restype = c_char_p
+    lib.dtf_build_flavour.argtypes = []
+    flavour = lib.dtf_build_flavour().decode()
+    if os.environ.get("DTF_KERNELS_LIB") or flavour != "release":
+        import sys
+        print(f"[dtf] kernel library: {p} (flavour: {flavour})"
+              + ("  -- DIAGNOSTIC build: timings / results of this process are not production numbers" if flavour != "release" else
+                 "  -- loaded through DTF_KERNELS_LIB instead of the in-tree build"), file=sys.stderr, flush=True)
     _lib = lib
     return lib
+
+
+def build_flavour() -> str:
+    return load().dtf_build_flavour().decode()
 
 
 def ptr(t) -> Optional[int]:

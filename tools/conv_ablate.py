@@ -20,7 +20,7 @@ if sys.argv[1] == "buildcfg":
     for kind, lst in CFGS.items():
         for i, c in enumerate(lst):
             subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",
-                                   f"-DDTF_{kind.upper()}_CFG={c}", "-I", ROOT + "/csrc/kernels", ROOT + "/csrc/kernels/conv2.hip",
+                                   f"-DDTF_{kind.upper()}_CFG={c}", "-DDTF_DIAG=1", "-I", ROOT + "/csrc/kernels", ROOT + "/csrc/kernels/conv2.hip",
                                    "-o", f"{OUT}/conv2_{kind}{i}.so"])
     print("built cfgs")
 elif sys.argv[1] == "buildstagger":
@@ -28,14 +28,14 @@ elif sys.argv[1] == "buildstagger":
     mode = os.environ.get("STAGGER_MODE", "0")
     for d in STAGGER:
         subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",
-                               f"-DDTF_STAGGER={d}", f"-DDTF_STAGGER_MODE={mode}", "-I", ROOT + "/csrc/kernels", ROOT + "/csrc/kernels/conv2.hip",
+                               f"-DDTF_STAGGER={d}", f"-DDTF_STAGGER_MODE={mode}", "-DDTF_DIAG=1", "-I", ROOT + "/csrc/kernels", ROOT + "/csrc/kernels/conv2.hip",
                                "-o", f"{OUT}/conv2_st{d}.so"])
     print("built stagger")
 elif sys.argv[1] == "build":
     os.makedirs(OUT, exist_ok=True)
     for v in sorted(set(WG) | set(IG)):
         subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",
-                               f"-DDTF_ABLATE={v}", "-I", ROOT + "/csrc/kernels", ROOT + "/csrc/kernels/conv2.hip",
+                               f"-DDTF_ABLATE={v}", "-DDTF_DIAG=1", "-I", ROOT + "/csrc/kernels", ROOT + "/csrc/kernels/conv2.hip",
                                "-o", f"{OUT}/conv2_ab{v}.so"])
     print("built", len(set(WG) | set(IG)))
 else:

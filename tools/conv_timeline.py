@@ -10,13 +10,13 @@ OUT = os.path.join(ROOT, "diag_build")
 if sys.argv[1] == "build":
     os.makedirs(OUT, exist_ok=True)
     subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",
-                           "-DDTF_TIMING=1", "-I", ROOT + "/csrc/kernels", ROOT + "/csrc/kernels/conv2.hip",
+                           "-DDTF_TIMING=1", "-DDTF_DIAG=1", "-I", ROOT + "/csrc/kernels", ROOT + "/csrc/kernels/conv2.hip",
                            "-o", f"{OUT}/conv2_timing.so"])
     subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",
-                           "-DDTF_TIMING=1", "-I", ROOT + "/csrc/kernels", ROOT + "/csrc/kernels/head.hip",
+                           "-DDTF_TIMING=1", "-DDTF_DIAG=1", "-I", ROOT + "/csrc/kernels", ROOT + "/csrc/kernels/head.hip",
                            "-o", f"{OUT}/head_timing.so"])
     subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",
-                           "-DDTF_TIMING=1", "-I", ROOT + "/csrc/kernels", ROOT + "/csrc/kernels/gemm.hip",
+                           "-DDTF_TIMING=1", "-DDTF_DIAG=1", "-I", ROOT + "/csrc/kernels", ROOT + "/csrc/kernels/gemm.hip",
                            ROOT + "/csrc/kernels/head.hip", "-o", f"{OUT}/gemm_timing.so"])
     print("built")
 elif len(sys.argv) > 3 and sys.argv[3] == "gemm":
