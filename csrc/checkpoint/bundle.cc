@@ -28,6 +28,7 @@
 #include <cstdint>
 #include <cstdio>
 #include <cstring>
+#include <exception>
 #include <map>
 #include <memory>
 #include <string>
@@ -407,6 +408,7 @@ static bool read_file(const std::string& path, std::string* out) {
   fseek(f, 0, SEEK_END);
   long n = ftell(f);
   fseek(f, 0, SEEK_SET);
+  if (n < 0) { fclose(f); return false; }   // a directory, a pipe
   out->resize((size_t)n);
   size_t got = n ? fread(&(*out)[0], 1, (size_t)n, f) : 0;
   fclose(f);
@@ -415,12 +417,17 @@ static bool read_file(const std::string& path, std::string* out) {
 
 static bool read_block(const std::string& file, uint64_t off, uint64_t size, std::string* contents,
                        std::string* err) {
-  if (off + size + 5 > file.size()) { *err = "block handle out of range"; return false; }
+  // written so that a crafted handle cannot wrap the uint64 sum past the check
+  if (file.size() < 5 || size > file.size() - 5 || off > file.size() - 5 - size) { *err = "block handle out of range"; return false; }
   const uint8_t* p = (const uint8_t*)file.data() + off;
   uint8_t type = p[size];
   uint32_t want = crc_unmask(get_fixed32(p + size + 1));
   uint32_t got = crc32c_extend(0, p, size + 1);
+#ifndef DTF_CKPT_FUZZ   // the damaged-file harness (fuzz_main.cc) lets damage through to the parsers behind the checksum
   if (want != got) { *err = "block checksum mismatch"; return false; }
+#else
+  (void)want; (void)got;
+#endif
   if (type != 0) { *err = "compressed table blocks are not supported (TF writes bundles uncompressed)"; return false; }
   contents->assign((const char*)p, size);
   return true;
@@ -443,7 +450,8 @@ static bool parse_block(const std::string& b, std::vector<std::pair<std::string,
     p += n;
     if (!(n = get_varint64(p, end, &vlen))) { *err = "bad entry"; return false; }
     p += n;
-    if (shared > key.size() || non_shared + vlen > (uint64_t)(end - p)) { *err = "bad entry lengths"; return false; }
+    const uint64_t rem = (uint64_t)(end - p);   // compared piecewise: the sum of two crafted lengths can wrap
+    if (shared > key.size() || non_shared > rem || vlen > rem - non_shared) { *err = "bad entry lengths"; return false; }
     key.resize((size_t)shared);
     key.append((const char*)p, (size_t)non_shared);
     p += non_shared;
@@ -529,6 +537,24 @@ static size_t dtype_size(int dt) {
     case 4: case 10: return 1;  // DT_UINT8, DT_BOOL
     default: return 0;
   }
+}
+
+// bytes of a tensor of `dims` x `es`, refused when a dimension is negative or the product passes `limit`
+// (sizes in a file are untrusted: a crafted shape must not overflow int64 or ask for an absurd allocation)
+static bool checked_bytes(const std::vector<int64_t>& dims, size_t es, uint64_t limit, int64_t* out) {
+  uint64_t n = es;
+  bool zero = false;
+  for (int64_t d : dims) {
+    if (d < 0) return false;
+    if (d == 0) zero = true;
+  }
+  if (zero) { *out = 0; return true; }
+  for (int64_t d : dims) {
+    if (n > limit / (uint64_t)d) return false;
+    n *= (uint64_t)d;
+  }
+  *out = (int64_t)n;
+  return true;
 }
 
 struct Extent {
@@ -617,8 +643,8 @@ static bool copy_slice(std::string* dst, const std::vector<int64_t>& dims, const
   for (size_t d = 0; d < nd; ++d) {
     start[d] = ex[d].length < 0 ? 0 : ex[d].start;
     len[d] = ex[d].length < 0 ? dims[d] : ex[d].length;
-    if (start[d] < 0 || len[d] < 0 || start[d] + len[d] > dims[d]) return false;
-    n *= len[d];
+    if (start[d] < 0 || len[d] < 0 || start[d] > dims[d] || len[d] > dims[d] - start[d]) return false;
+    n *= len[d];   // <= the product of dims, which the caller has bounded
   }
   if ((uint64_t)n * es != src.size()) return false;
   if (n == 0) return true;
@@ -648,6 +674,7 @@ static bool load_v1(const std::string& file, Reader* r) {
   if (!read_table(file, &kv, &r->err)) return false;
   std::map<std::string, size_t> by_name;
   bool have_meta = false;
+  uint64_t declared = 0;
   // pass 1: the meta entry (key "") names every tensor with its full shape and type
   for (auto& e : kv) {
     if (!e.first.empty()) continue;
@@ -676,9 +703,12 @@ static bool load_v1(const std::string& file, Reader* r) {
         if (!t.ok) { r->err = "bad SavedSliceMeta"; return false; }
         const size_t es = dtype_size(en.dtype);
         if (!es) { r->err = "unsupported dtype in V1 checkpoint for " + en.name; return false; }
-        int64_t n = 1;
-        for (int64_t d : en.dims) n *= d;
-        en.size = n * (int64_t)es;
+        // a V1 file holds every tensor inline; packed varints shrink an element to no less than one byte
+        if (!checked_bytes(en.dims, es, 8 * (uint64_t)file.size() + 64, &en.size) ||
+            (declared += (uint64_t)en.size) > 8 * (uint64_t)file.size() + 64) {
+          r->err = "tensor " + en.name + " declares more data than the file can hold";
+          return false;
+        }
         by_name[en.name] = r->entries.size();
         r->entries.push_back(en);
         r->mem.emplace_back((size_t)en.size, '\0');
@@ -875,9 +905,23 @@ int dtf_ckpt_reader_is_v1(void* rp) { return ((Reader*)rp)->v1 ? 1 : 0; }
 const char* dtf_ckpt_writer_error(void* wp) { return ((Writer*)wp)->err.c_str(); }
 void dtf_ckpt_writer_free(void* wp) { delete (Writer*)wp; }
 
+static Reader* reader_open(Reader* r);
+
+// Never throws across the C boundary: an allocation a damaged file provokes becomes a reader error.
 void* dtf_ckpt_reader_open(const char* prefix) {
   Reader* r = new Reader();
   r->prefix = prefix;
+  try {
+    reader_open(r);
+  } catch (const std::exception& ex) {
+    r->entries.clear();
+    r->mem.clear();
+    r->err = std::string("cannot load checkpoint: ") + ex.what();
+  }
+  return r;
+}
+
+static Reader* reader_open(Reader* r) {
   std::string file;
   if (!read_file(r->prefix + ".index", &file)) {
     // no bundle index: a Saver V1 checkpoint is the single file <prefix> itself
@@ -909,9 +953,36 @@ void* dtf_ckpt_reader_open(const char* prefix) {
       r->err = "bad BundleEntryProto for " + e.first;
       return r;
     }
+    int64_t want = 0;
+    const size_t es = dtype_size(en.dtype);
+    if (en.size < 0 || en.offset < 0 || en.offset > INT64_MAX - en.size || en.shard_id < 0 ||
+        (have_header && en.shard_id >= r->num_shards) ||
+        !checked_bytes(en.dims, es ? es : 1, (uint64_t)INT64_MAX, &want) ||
+        (es && !en.has_slices && want != en.size)) {
+      r->err = "inconsistent BundleEntryProto for " + e.first + " (shape, size, offset or shard)";
+      return r;
+    }
     r->entries.push_back(en);
   }
-  if (!have_header) r->err = "bundle header (empty key) missing";
+  if (!have_header) { r->err = "bundle header (empty key) missing"; return r; }
+  // an entry must lie inside its shard (checked when the shard is there: listing variables needs only the index)
+  std::map<int, int64_t> shard_bytes;
+  for (const Entry& en : r->entries) {
+    if (en.shard_id >= r->num_shards) { r->err = "entry " + en.name + " names a shard the header does not have"; return r; }
+    auto it = shard_bytes.find(en.shard_id);
+    if (it == shard_bytes.end()) {
+      int64_t n = -1;
+      if (FILE* f = fopen(shard_name(r->prefix, en.shard_id, r->num_shards).c_str(), "rb")) {
+        if (fseek(f, 0, SEEK_END) == 0) n = (int64_t)ftell(f);
+        fclose(f);
+      }
+      it = shard_bytes.emplace(en.shard_id, n).first;
+    }
+    if (it->second >= 0 && en.offset + en.size > it->second) {
+      r->err = "entry " + en.name + " reaches past the end of its data shard (truncated checkpoint?)";
+      return r;
+    }
+  }
   return r;
 }
 
@@ -926,9 +997,10 @@ int dtf_ckpt_reader_entry(void* rp, int i, char* name, int name_cap, int* dtype,
   if (i < 0 || i >= (int)r->entries.size()) return -1;
   const Entry& e = r->entries[i];
   snprintf(name, (size_t)name_cap, "%s", e.name.c_str());
+  if (e.dims.size() > 8) return -2;   // the caller's dims[] holds 8: refuse rather than report a rank it cannot see
   *dtype = e.dtype;
   *ndim = (int)e.dims.size();
-  for (size_t k = 0; k < e.dims.size() && k < 8; ++k) dims[k] = e.dims[k];
+  for (size_t k = 0; k < e.dims.size(); ++k) dims[k] = e.dims[k];
   *nbytes = e.size;
   *sliced = e.has_slices ? 1 : 0;
   return 0;

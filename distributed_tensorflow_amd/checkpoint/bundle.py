@@ -135,9 +135,12 @@ def _read(prefix: str, data: bool):
         dims = (c_int64 * 8)()
         nbytes = c_int64()
         for i in range(lib.dtf_ckpt_reader_num(r)):
-            lib.dtf_ckpt_reader_entry(r, i, name, 1024, ctypes.byref(dtype), ctypes.byref(ndim), dims,
-                                      ctypes.byref(nbytes), ctypes.byref(sliced))
-            key = name.value.decode()
+            rc = lib.dtf_ckpt_reader_entry(r, i, name, 1024, ctypes.byref(dtype), ctypes.byref(ndim), dims,
+                                           ctypes.byref(nbytes), ctypes.byref(sliced))
+            key = name.value.decode(errors="replace")
+            if rc != 0:
+                raise CheckpointError(f"{prefix}: cannot describe entry {i} ({key!r}): "
+                                      + ("more than 8 dimensions" if rc == -2 else f"code {rc}"))
             if sliced.value:
                 raise CheckpointError(f"{key}: partitioned (sliced) variables are not supported")
             if dtype.value not in _DT_TO_NP:
@@ -147,7 +150,10 @@ def _read(prefix: str, data: bool):
             if not data:
                 out[key] = (npdt, shape)
                 continue
-            arr = np.empty(shape, dtype=npdt)
+            try:
+                arr = np.empty(shape, dtype=npdt)
+            except (MemoryError, ValueError) as e:
+                raise CheckpointError(f"{key}: cannot allocate shape {shape}: {e}") from None
             if arr.nbytes != nbytes.value:
                 raise CheckpointError(f"{key}: entry size {nbytes.value} != shape bytes {arr.nbytes}")
             rc = lib.dtf_ckpt_reader_read(r, i, arr.ctypes.data_as(c_void_p), arr.nbytes)

@@ -57,7 +57,7 @@ def build_kernels(force: bool = False, verbose: bool = True) -> Path:
         o = BUILD / (s.stem + ".o")
         objs.append(o)
         if force or _newer([s] + headers, o):
-            jobs.append([hipcc, f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-fPIC", "-I", str(CSRC / "kernels"),
+            jobs.append([hipcc, f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wextra", "-Werror", "-I", str(CSRC / "kernels"),
                          "-c", str(s), "-o", str(o)])
     with cf.ThreadPoolExecutor(max_workers=min(8, max(1, len(jobs)))) as ex:
         list(ex.map(_run, jobs))
@@ -71,11 +71,11 @@ def build_kernels(force: bool = False, verbose: bool = True) -> Path:
 
 def build_ckpt(force: bool = False, verbose: bool = True) -> Path:
     OUT.mkdir(parents=True, exist_ok=True)
-    srcs = sorted((CSRC / "checkpoint").glob("*.cc"))
+    srcs = [s for s in sorted((CSRC / "checkpoint").glob("*.cc")) if s.name != "fuzz_main.cc"]   # the sanitizer harness
     hdrs = list((CSRC / "checkpoint").glob("*.h"))
     lib = OUT / "libdtf_ckpt.so"
     if srcs and (force or _newer(srcs + hdrs, lib)):
-        _run(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-Wall", "-o", str(lib)] + [str(s) for s in srcs])
+        _run(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-Wall", "-Wextra", "-Werror", "-o", str(lib)] + [str(s) for s in srcs])
     if verbose and srcs:
         print(f"[build] {lib}")
     return lib
