@@ -45,6 +45,9 @@ def main():
     ap.add_argument("--multi_stream", action="store_true", help="force the fork/join side streams (default: by batch size)")
     ap.add_argument("--no_graph", action="store_true", help="eager launches instead of HIP-graph replay (1 GPU)")
     ap.add_argument("--graph", action="store_true", help="force HIP-graph replay (default: only above 1024 images/GPU)")
+    ap.add_argument("--dense", choices=["auto", "allreduce", "sharded"], default="auto",
+                    help="N > 1, dense (fc1) gradient over RCCL: all-reduce + replicated update, or reduce-scatter + "
+                         "update of 1/N + all-gather of the compute copy; auto times one 50-step trial of each")
     ap.add_argument("--force_dp", action="store_true",
                     help="diagnostic: run the data-parallel schedule (process group, two communicators, comm_diag) "
                          "even at --gpus 1, to exercise the N>1 code path on a one-GPU box")
@@ -138,7 +141,9 @@ def main():
             dense_cand, why = bring_up(n_dense_arena, True)
             if dense_cand is None:
                 dense_how = why
-        dp = SyncDataParallel(eng, tail_group=tail_group, tail_p2p=tail_p2p, dense_p2p=dense_p2p)
+        dp = SyncDataParallel(eng, tail_group=tail_group, tail_p2p=tail_p2p, dense_p2p=dense_p2p,
+                              shard_dense={"auto": None, "allreduce": False, "sharded": True}[args.dense])
+        dense_how = "rccl reduce-scatter + sharded update + all-gather" if dp.shard else "rccl all-reduce"
         dp.broadcast_parameters()
         step = dp.train_step
     else:
@@ -187,10 +192,21 @@ def main():
 
     def select_paths():
         nonlocal dense_p2p, dense_how, tail_p2p, tail_how, p2p_blocks_us, tail_trials
+        if world > 1 and args.dense == "auto" and dp.can_shard():
+            # the dense message over RCCL: sharded (reduce-scatter / update of 1/N / all-gather) or plain all-reduce
+            dp.set_shard(True)
+            t_sh = step_ms(TRIAL_STEPS)
+            dp.set_shard(False)            # gathers the master weights first (collective)
+            t_ar = step_ms(TRIAL_STEPS)
+            dp.set_shard(t_sh <= t_ar)
+            dense_how = ("rccl reduce-scatter + sharded update + all-gather" if dp.shard else "rccl all-reduce") + \
+                f" ({t_sh:.4f} sharded vs {t_ar:.4f} all-reduce ms/step)"
         if dense_cand is not None:
+            rccl_how, want_shard = dense_how, dp.shard
             trials = {"rccl": step_ms(TRIAL_STEPS)}
+            dp.set_shard(False)            # the peer-to-peer kernel all-reduces: full masters needed on every rank
             dp.dense_p2p = dense_cand
-            for nb in (32, 64):
+            for nb in (64,):
                 dense_cand.blocks = nb
                 if not probe_ok(dense_cand):
                     dense_cand._status.fill_(1)      # disqualified below (and the ranks re-aligned)
@@ -206,9 +222,10 @@ def main():
                 dp.dense_p2p = None
                 if st:
                     dp.broadcast_parameters()      # sums may have been wrong on the way: re-align the ranks
+                dp.set_shard(want_shard)
                 others = [v for k, v in trials.items() if k != "rccl"]
-                dense_how = f"rccl ({trials['rccl']:.4f} ms/step" + (f" vs best p2p two-shot {min(others):.4f})" if others else
-                                                                      "; p2p two-shot waits timed out)")
+                dense_how = rccl_how + f"; {trials['rccl']:.4f} ms/step" + (f" vs p2p two-shot {min(others):.4f}" if others else
+                                                                             "; p2p two-shot waits timed out")
                 barrier()
                 dense_cand.close()
         if tail_p2p is not None:
@@ -231,12 +248,34 @@ def main():
                 tail_p2p = None
                 tail_how = f"rccl ({t_pg:.4f} ms/step" + (", p2p waits timed out)" if st else f" vs p2p {t_p2p:.4f})")
 
+    def prewarm():
+        """Time-based warm-up, outside the timed region and reported: the requested --warmup / --steps may be a few
+        milliseconds of GPU time in total (the driver runs 5 + 20 steps), which would otherwise be measured on a cold,
+        low-clocked device with lazily set kernel attributes.  Runs before the path-selection trials as well: the first
+        candidate must not be the one that is timed while the clocks ramp."""
+        nonlocal prewarm_steps
+        t_pw = time.perf_counter()
+        while args.prewarm_s > 0:
+            for _ in range(10):
+                step()
+            prewarm_steps += 10
+            torch.cuda.synchronize()
+            more = time.perf_counter() - t_pw < args.prewarm_s
+            if dp_path:      # every rank must run the same number of steps: rank 0's clock decides
+                more = max_over_ranks(1.0 if (rank == 0 and more) else 0.0) > 0
+            if not more:
+                break
+
+    prewarm_steps = 0
     if dp_path:
         try:
+            prewarm()
             select_paths()
         except Exception as e:      # collectives inside are unanimous (max over ranks), so every rank lands here together
             print(f"[bench] rank {rank}: path selection failed ({type(e).__name__}: {e}); both messages on RCCL", file=sys.stderr)
             dp.tail_p2p = dp.dense_p2p = None
+            dp.shard, dp.master_stale = False, False      # plain all-reduce; broadcast_parameters below re-aligns everything
+            dp.shard_lo, dp.shard_hi = 0, dp.n_dense
             tail_p2p = dense_p2p = None
             tail_how = dense_how = f"rccl (path selection failed: {type(e).__name__})"
             try:
@@ -244,21 +283,7 @@ def main():
             except Exception:
                 pass
 
-    # ---- time-based pre-warm, outside the timed region and reported: the requested --warmup / --steps may be a few
-    # milliseconds of GPU time in total (the driver runs 5 + 20 steps), which would otherwise be measured on a cold,
-    # low-clocked device with lazily set kernel attributes. ----
-    prewarm_steps = 0
-    t_pw = time.perf_counter()
-    while args.prewarm_s > 0:
-        for _ in range(10):
-            step()
-        prewarm_steps += 10
-        torch.cuda.synchronize()
-        more = time.perf_counter() - t_pw < args.prewarm_s
-        if dp_path:      # every rank must run the same number of steps: rank 0's clock decides
-            more = max_over_ranks(1.0 if (rank == 0 and more) else 0.0) > 0
-        if not more:
-            break
+    prewarm()
     for _ in range(args.warmup):
         step()
     barrier()
@@ -354,6 +379,7 @@ def main():
             # ... and the data-parallel step with one or both collectives left out (ranks then drift apart, which
             # no longer matters here): which of the two is exposed, and what the schedule costs without either
             real, tail_bucket = dp._allreduce, tuple(dp.tail_bucket)
+            real_rs, real_ag = dp._reduce_scatter, dp._all_gather
 
             def timed(skip_dense, skip_tail, n=100):
                 def ar(lo, hi, group):
@@ -361,6 +387,8 @@ def main():
                     if not (skip_tail if is_tail else skip_dense):
                         real(lo, hi, group)
                 dp._allreduce = ar
+                if skip_dense:
+                    dp._reduce_scatter = dp._all_gather = lambda: None
                 p2p_real = (dp.tail_p2p, dp.dense_p2p)     # a skipped message must not go peer-to-peer either
                 if skip_tail:
                     dp.tail_p2p = None      # -> process-group path, where ar() drops the message
@@ -375,6 +403,7 @@ def main():
                 barrier()
                 ms = max_over_ranks((time.perf_counter() - t1) * 1e3 / n)
                 dp._allreduce, (dp.tail_p2p, dp.dense_p2p) = real, p2p_real
+                dp._reduce_scatter, dp._all_gather = real_rs, real_ag
                 return round(ms, 4)
 
             if tail_p2p is not None:

@@ -29,6 +29,8 @@ int dtf_conv2_wgrad(const void* x, const void* gpool, const void* arg, void* par
                     int cout, int G, hipStream_t s);
 int dtf_gemm_nt(const void* A, const void* B, void* C, const void* bias, int M, int N, int K, int lda, int ldb,
                 int ldc, int epi, float keep_prob, uint64_t seed, const void* state, int tile, hipStream_t s);
+int dtf_gemm_tn_ev(const void* A, const void* B, void* C, int M, int N, int K, int lda, int ldb, int ldc, int tile,
+                   hipEvent_t done, hipStream_t s);
 int dtf_gemm_tn(const void* A, const void* B, void* C, int M, int N, int K, int lda, int ldb, int ldc, int tile,
                 hipStream_t s);
 int dtf_gemm_tn_sgd(const void* A, const void* B, void* W, void* shadow, const void* hyper, int M, int N, int K,
@@ -95,6 +97,8 @@ int dtf_conv2_f32_wgrad(const void* x, const void* gpool, const void* arg, void*
 int dtf_gemm_f32_nn_partial(const void* A, const void* B, void* part, int M, int N, int K, int lda, int ldb, int S,
                             hipStream_t s);
 int dtf_gemm_f32_nt(const void* A, const void* B, void* C, int M, int N, int K, int lda, int ldb, int ldc, hipStream_t s);
+int dtf_gemm_f32_tn_ev(const void* A, const void* B, void* C, int M, int N, int K, int lda, int ldb, int ldc,
+                       const void* hyper, hipEvent_t done, hipStream_t s);
 int dtf_gemm_f32_tn(const void* A, const void* B, void* C, int M, int N, int K, int lda, int ldb, int ldc,
                     const void* hyper, hipStream_t s);
 int dtf_head_f32_fwd_bwd(const void* h1, const void* wT, const void* bias, const void* labels, const void* idx,

@@ -41,5 +41,5 @@
 #define DTF_GEMM_MINW 1
 #endif
 #ifndef DTF_EXP_DP
-#define DTF_EXP_DP 0   // 1 = no ev_dgrad record/wait, 2 = no dense update, 4 = dense update on the compute stream
+#define DTF_EXP_DP 0   // 2 = no dense update, 4 = dense update on the compute stream, 8 = events with the default (system-scope) release, 16 = ev_dense_ready as a marker behind the fc1 wgrad, 32 = no ev_dense_ready at all
 #endif

@@ -19,6 +19,7 @@
 //       bijection of k is a valid GEMM), which makes the transposed reads
 //       bank-conflict free.
 #include "common.hpp"
+#include <hip/hip_ext.h>
 #include "head_wgrad_core.hpp"
 
 namespace dtf {
@@ -594,19 +595,28 @@ int dtf_gemm_nt_head_wgrad(const void* A, const void* Bw, void* C, int M, int N,
 }
 
 // C[M,N] fp32 = A[K,M]^T . B[K,N]
-int dtf_gemm_tn(const void* A, const void* B, void* C, int M, int N, int K, int lda, int ldb, int ldc,
-                int tile, hipStream_t s) {
+// done != NULL: the event is bound to the kernel itself (its own completion signal), which is what a
+// hipEventRecord behind it would say, minus the marker packet that record puts into the stream -- measured as a
+// ~7 us hole in the compute stream of the data-parallel step, whose fc1 wgrad hands the gradient to the comm stream.
+int dtf_gemm_tn_ev(const void* A, const void* B, void* C, int M, int N, int K, int lda, int ldb, int ldc,
+                   int tile, hipEvent_t done, hipStream_t s) {
   if ((lda & 7) || (ldb & 7) || (M & 7) || (N & 7)) return -3;
   if (tile == 0) tile = ((long)((M + 127) / 128) * ((N + 127) / 128) >= 192) ? 128 : 64;
   if (tile == 128)
-    hipLaunchKernelGGL((gemm_tn_bf16<128, 128, 8>), dim3((N + 127) / 128, (M + 127) / 128), dim3(512), 0, s,
-                       (const bf16*)A, (const bf16*)B, (float*)C, M, N, K, lda, ldb, ldc);
+    hipExtLaunchKernelGGL((gemm_tn_bf16<128, 128, 8>), dim3((N + 127) / 128, (M + 127) / 128), dim3(512), 0, s, nullptr,
+                          done, 0, (const bf16*)A, (const bf16*)B, (float*)C, M, N, K, lda, ldb, ldc, (bf16*)nullptr,
+                          (const float*)nullptr);
   else if (tile == 64)
-    hipLaunchKernelGGL((gemm_tn_bf16<64, 64, 4>), dim3((N + 63) / 64, (M + 63) / 64), dim3(256), 0, s,
-                       (const bf16*)A, (const bf16*)B, (float*)C, M, N, K, lda, ldb, ldc);
+    hipExtLaunchKernelGGL((gemm_tn_bf16<64, 64, 4>), dim3((N + 63) / 64, (M + 63) / 64), dim3(256), 0, s, nullptr, done, 0,
+                          (const bf16*)A, (const bf16*)B, (float*)C, M, N, K, lda, ldb, ldc, (bf16*)nullptr,
+                          (const float*)nullptr);
   else
     return -1;
   return (int)hipGetLastError();
+}
+int dtf_gemm_tn(const void* A, const void* B, void* C, int M, int N, int K, int lda, int ldb, int ldc,
+                int tile, hipStream_t s) {
+  return dtf_gemm_tn_ev(A, B, C, M, N, K, lda, ldb, ldc, tile, nullptr, s);
 }
 
 // W[M,N] -= lr * (A[K,M]^T . B[K,N]), shadow = bf16(W); lr = hyper[0] * hyper[4]  (see gemm_tn_bf16<SGD>)

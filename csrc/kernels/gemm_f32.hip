@@ -16,6 +16,7 @@
 // Register-prefetched double buffering, one barrier per K tile: a tile is 2048 cycles of MFMA per wave
 // against ~150 cycles of LDS traffic, so this simple pipeline already leaves the matrix pipe as the bound.
 #include "f32_common.hpp"
+#include <hip/hip_ext.h>
 
 namespace dtf {
 
@@ -177,7 +178,7 @@ __global__ __launch_bounds__(512) void gemm_f32(const float* A, const float* Bm,
 
 template <int LA, int LB, int EPI>
 static int launch_gemm_f32(const void* A, const void* B, void* C, int M, int N, int K, int lda, int ldb, int ldc, int S,
-                           int tps, const void* hyper, hipStream_t s) {
+                           int tps, const void* hyper, hipStream_t s, hipEvent_t done = nullptr) {
   constexpr int PK = 36;
   constexpr size_t lds = (2 * ((LA == F32_KCONTIG) ? 128 * PK : 32 * 128) + 2 * ((LB == F32_KCONTIG) ? 128 * PK : 32 * 128)) * 4;
   auto kern = gemm_f32<LA, LB, EPI>;
@@ -186,8 +187,9 @@ static int launch_gemm_f32(const void* A, const void* B, void* C, int M, int N, 
     (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     attr_set = true;
   }
-  hipLaunchKernelGGL(kern, dim3((N + 127) / 128, (M + 127) / 128, S), dim3(512), lds, s, (const float*)A, (const float*)B,
-                     (float*)C, M, N, K, lda, ldb, ldc, tps, (const float*)hyper);
+  // done: bound to the kernel's own completion (see dtf_gemm_tn_ev in gemm.hip)
+  hipExtLaunchKernelGGL(kern, dim3((N + 127) / 128, (M + 127) / 128, S), dim3(512), lds, s, nullptr, done, 0, (const float*)A,
+                        (const float*)B, (float*)C, M, N, K, lda, ldb, ldc, tps, (const float*)hyper);
   return (int)hipGetLastError();
 }
 
@@ -223,12 +225,16 @@ int dtf_gemm_f32_nt(const void* A, const void* B, void* C, int M, int N, int K, 
 
 // C[M,N] = A[K,M]^T . B[K,N]  (fc1 wgrad: A = flat, B = dh1, K = batch); hyper != NULL: C is the fp32 weight and the
 // product its gradient, applied in place as w -= hyper[0] * hyper[4] * g (single-GPU SGD; the gradient is not stored)
-int dtf_gemm_f32_tn(const void* A, const void* B, void* C, int M, int N, int K, int lda, int ldb, int ldc,
-                    const void* hyper, hipStream_t s) {
+int dtf_gemm_f32_tn_ev(const void* A, const void* B, void* C, int M, int N, int K, int lda, int ldb, int ldc,
+                       const void* hyper, hipEvent_t done, hipStream_t s) {
   if ((lda & 3) || (ldb & 3) || (M & 3) || (N & 3)) return -3;
   const int T = (K + 31) / 32;
-  if (hyper) return launch_gemm_f32<F32_KSLOW, F32_KSLOW, F32_EPI_SGD>(A, B, C, M, N, K, lda, ldb, ldc, 1, T, hyper, s);
-  return launch_gemm_f32<F32_KSLOW, F32_KSLOW, F32_EPI_STORE>(A, B, C, M, N, K, lda, ldb, ldc, 1, T, nullptr, s);
+  if (hyper) return launch_gemm_f32<F32_KSLOW, F32_KSLOW, F32_EPI_SGD>(A, B, C, M, N, K, lda, ldb, ldc, 1, T, hyper, s, done);
+  return launch_gemm_f32<F32_KSLOW, F32_KSLOW, F32_EPI_STORE>(A, B, C, M, N, K, lda, ldb, ldc, 1, T, nullptr, s, done);
+}
+int dtf_gemm_f32_tn(const void* A, const void* B, void* C, int M, int N, int K, int lda, int ldb, int ldc,
+                    const void* hyper, hipStream_t s) {
+  return dtf_gemm_f32_tn_ev(A, B, C, M, N, K, lda, ldb, ldc, hyper, nullptr, s);
 }
 
 }  // extern "C"

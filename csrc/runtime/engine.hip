@@ -62,7 +62,11 @@ int dtf_engine_init(DtfEngineDesc* e) {
   }
   hipEvent_t* evs[9] = {&e->ev_head,        &e->ev_fork,          &e->ev_join1,      &e->ev_join2,       &e->ev_dgrad,
                         &e->ev_dense_ready, &e->ev_dense_updated, &e->ev_tail_ready, &e->ev_tail_reduced};
-  for (auto ev : evs) HIP_TRY(hipEventCreateWithFlags(ev, hipEventDisableTiming));
+  // Every one of these events orders streams of THIS device only, so a device-scope release is all it has to do.
+  // The default (system-scope) release writes the caches back when the event is recorded: measured as a 5.5-7.5 us
+  // hole in the compute stream behind each record that follows a 12.8 MB producer (the fc1 GEMMs).
+  const unsigned flags = hipEventDisableTiming | ((DTF_EXP_DP & 8) ? 0u : (unsigned)hipEventReleaseToDevice);
+  for (auto ev : evs) HIP_TRY(hipEventCreateWithFlags(ev, flags));
   return 0;
 }
 
@@ -160,7 +164,8 @@ static int dgrad_conv1_wgrad(const DtfEngineDesc* e, const void* images, const v
 // reduce == 0 leaves the head slabs unreduced (the fused single-GPU SGD tail sums them itself);
 // reduce == -1 does not compute them either: the training step runs the head wgrad inside the fc1
 // dgrad launch (backward_conv_impl with head_w != 0).
-static int backward_dense_impl(const DtfEngineDesc* e, int reduce, hipStream_t s) {
+// done != NULL: that event is complete when the fc1 wgrad GEMM is (bound to the kernel: no marker in the stream).
+static int backward_dense_impl(const DtfEngineDesc* e, int reduce, hipStream_t s, hipEvent_t done = nullptr) {
   if (reduce >= 0)
     DTF_TRY((is_f32(e) ? dtf_head_f32_wgrad : dtf_head_wgrad)(e->h1, e->dlogits, e->da, e->head_part, e->B, e->hidden,
                                                               e->head_ks, s));
@@ -172,10 +177,10 @@ static int backward_dense_impl(const DtfEngineDesc* e, int reduce, hipStream_t s
     DTF_TRY(dtf_reduce_segments(1, part, out, G, n, st, s));
   }
   if (is_f32(e))
-    return dtf_gemm_f32_tn(e->p2, e->da, f32at(e->grads, e->off_wd1), e->flat, e->hidden, e->B, e->flat, e->hidden,
-                           e->hidden, nullptr, s);
-  return dtf_gemm_tn(e->p2, e->da, f32at(e->grads, e->off_wd1), e->flat, e->hidden, e->B, e->flat, e->hidden,
-                     e->hidden, 0, s);
+    return dtf_gemm_f32_tn_ev(e->p2, e->da, f32at(e->grads, e->off_wd1), e->flat, e->hidden, e->B, e->flat, e->hidden,
+                              e->hidden, nullptr, done, s);
+  return dtf_gemm_tn_ev(e->p2, e->da, f32at(e->grads, e->off_wd1), e->flat, e->hidden, e->B, e->flat, e->hidden,
+                        e->hidden, 0, done, s);
 }
 int dtf_engine_backward_dense(const DtfEngineDesc* e, hipStream_t s) { return backward_dense_impl(e, 1, s); }
 
@@ -195,10 +200,11 @@ static int fc1_dgrad(const DtfEngineDesc* e, int head_w, hipStream_t s) {
                      e->hidden, e->flat, 0, 1.0f, 0, nullptr, 0, s);
 }
 
+// head_w < 0: fc1 dgrad (and with it the head wgrad) has already been issued by the caller
 static int backward_conv_impl(const DtfEngineDesc* e, const void* images, const void* idx, int record_dgrad,
                               int reduce, int head_w, hipStream_t s) {
-  DTF_TRY(fc1_dgrad(e, head_w, s));
-  if (record_dgrad && !(DTF_EXP_DP & 1)) HIP_TRY(hipEventRecord(e->ev_dgrad, s));
+  if (head_w >= 0) DTF_TRY(fc1_dgrad(e, head_w, s));
+  if (record_dgrad) HIP_TRY(hipEventRecord(e->ev_dgrad, s));
   hipStream_t s2 = s;
   if (e->multi_stream) {
     HIP_TRY(hipEventRecord(e->ev_fork, s));
@@ -213,11 +219,15 @@ static int backward_conv_impl(const DtfEngineDesc* e, const void* images, const 
   if (!reduce) return 0;
   // reduce == 2: the head slabs (written by backward_dense with reduce == 0) are summed here too, in
   // the same launch -- the data-parallel step needs head + conv reduced only for its tail collective
-  const void* part[3] = {e->c2_part, e->c1_part, e->head_part};
-  void* out[3] = {f32at(e->grads, e->off_wc2), f32at(e->grads, e->off_wc1), f32at(e->grads, e->off_out_w)};
-  int G[3] = {e->c2_g, e->c1_g, e->head_ks}, n[3] = {(int)e->c2_stride, (int)e->c1_stride, (int)e->head_stride};
-  long st[3] = {e->c2_stride, e->c1_stride, e->head_stride};
-  return dtf_reduce_segments(reduce == 2 ? 3 : 2, part, out, G, n, st, s);
+  // ... and, as a fourth "segment" of one 4-float slab, this rank's control flags (hyper[8..12): stop / gather
+  // requests) are published into the control block at the end of the gradient arena, where the tail collective
+  // sums them over the ranks: fresh every step, no launch of their own
+  const void* part[4] = {e->c2_part, e->c1_part, e->head_part, f32at(e->hyper, 8)};
+  void* out[4] = {f32at(e->grads, e->off_wc2), f32at(e->grads, e->off_wc1), f32at(e->grads, e->off_out_w),
+                  f32at(e->grads, e->n_total - 4)};
+  int G[4] = {e->c2_g, e->c1_g, e->head_ks, 1}, n[4] = {(int)e->c2_stride, (int)e->c1_stride, (int)e->head_stride, 4};
+  long st[4] = {e->c2_stride, e->c1_stride, e->head_stride, 4};
+  return dtf_reduce_segments(reduce == 2 ? 4 : 2, part, out, G, n, st, s);
 }
 int dtf_engine_backward_conv(const DtfEngineDesc* e, const void* images, const void* idx, int record_dgrad,
                              hipStream_t s) {
@@ -349,28 +359,42 @@ int dtf_engine_train_step(const DtfEngineDesc* e, long step_inc, hipStream_t s) 
 // 3 foreign calls + 2 all-reduce enqueues.  s = compute stream, comm = dense all-reduce + dense
 // update stream, tail = conv-tail all-reduce stream (may equal comm).
 //   phase1: sampler+conv forward | wait(dense params of the previous step) | dense forward, head,
-//           dense wgrads -> ev_dense_ready ; comm waits for it.         [Python: all-reduce dense on comm]
-//   phase2: fc1 dgrad (-> ev_dgrad), conv backward ; comm: wait ev_dgrad, update dense range ->
-//           ev_dense_updated.                       [Python: all-reduce tail, on s itself by default]
+//           fc1 dgrad (+ head wgrad), fc1 wgrad -> ev_dense_ready ; comm waits for it.
+//           (dgrad BEFORE wgrad: it is the last reader of the old bf16 wd1, so the one event that releases the
+//           gradient to the comm stream also orders the dense update behind it; every event recorded on the compute
+//           stream costs a hole in it, and this order needs one per step instead of two.)
+//                                                                       [Python: all-reduce dense on comm]
+//   phase2: conv backward ; comm: update dense range [dense_lo, dense_hi) -> ev_dense_updated.
+//           Sharded dense update (sync_dp.py shard_dense): Python has reduce-scattered the gradient, [dense_lo,
+//           dense_hi) is this rank's shard, record_updated == 0, and Python all-gathers the updated weights on comm
+//           before it records ev_dense_updated itself.
+//                                                   [Python: all-reduce tail, on s itself by default]
 //   phase3: updates the tail (+ state advance), repacks wc2.  (With a separate tail stream: two event pairs.)
 // ---------------------------------------------------------------------------------------------
 int dtf_engine_dp_phase1(const DtfEngineDesc* e, int wait_dense_updated, hipStream_t s, hipStream_t comm) {
   DTF_TRY(forward_conv_impl(e, e->ds_images, nullptr, 1, e->B, s));
   if (wait_dense_updated) HIP_TRY(hipStreamWaitEvent(s, e->ev_dense_updated, 0));
   DTF_TRY(dtf_engine_forward_dense(e, e->ds_labels, e->idx, 1, e->B, 1, s));
-  DTF_TRY(backward_dense_impl(e, -1, s));   // fc1 wgrad only: the head wgrad rides in phase 2's fc1 dgrad launch
-  HIP_TRY(hipEventRecord(e->ev_dense_ready, s));
+  DTF_TRY(fc1_dgrad(e, 1, s));              // + the head wgrad as extra workgroups of the same launch
+  if (DTF_EXP_DP & 32) {        // no hand-over at all (the dense update then races with its producer: timing only)
+    return backward_dense_impl(e, -1, s);
+  } else if (DTF_EXP_DP & 16) {
+    DTF_TRY(backward_dense_impl(e, -1, s));
+    HIP_TRY(hipEventRecord(e->ev_dense_ready, s));
+  } else {
+    DTF_TRY(backward_dense_impl(e, -1, s, e->ev_dense_ready));   // fc1 wgrad only; the event rides on the kernel
+  }
   return (int)hipStreamWaitEvent(comm, e->ev_dense_ready, 0);
 }
 
-int dtf_engine_dp_phase2(const DtfEngineDesc* e, long dense_hi, int dense_adam_slot, int reduce_tail,
-                         const void* dense_grad_src, hipStream_t s, hipStream_t comm, hipStream_t tail) {
-  DTF_TRY(backward_conv_impl(e, e->ds_images, e->idx, 1, reduce_tail ? 2 : 0, 1, s));
-  // the dense update overwrites the bf16 wd1 that fc1 dgrad reads: order it after that kernel
-  if (!(DTF_EXP_DP & 1)) HIP_TRY(hipStreamWaitEvent(comm, e->ev_dgrad, 0));
+int dtf_engine_dp_phase2(const DtfEngineDesc* e, long dense_lo, long dense_hi, int dense_adam_slot, int reduce_tail,
+                         const void* dense_grad_src, int record_updated, hipStream_t s, hipStream_t comm,
+                         hipStream_t tail) {
+  DTF_TRY(backward_conv_impl(e, e->ds_images, e->idx, 0, reduce_tail ? 2 : 0, -1, s));
+  // (the dense update overwrites the bf16 wd1 that fc1 dgrad reads: that kernel ran before ev_dense_ready)
   if (!(DTF_EXP_DP & 2))
-    DTF_TRY(update_range_src(e, 0, dense_hi, 0, 0, 0, dense_adam_slot, dense_grad_src, (DTF_EXP_DP & 4) ? s : comm));
-  HIP_TRY(hipEventRecord(e->ev_dense_updated, comm));
+    DTF_TRY(update_range_src(e, dense_lo, dense_hi, 0, 0, 0, dense_adam_slot, dense_grad_src, (DTF_EXP_DP & 4) ? s : comm));
+  if (record_updated) HIP_TRY(hipEventRecord(e->ev_dense_updated, comm));
   // tail == s: the tail collective is issued on the compute stream itself (everything after it depends on
   // it anyway), which needs no events at all; a separate tail stream is ordered behind the conv backward
   if (tail != s) {
@@ -423,6 +447,10 @@ int dtf_engine_dp_phase3_p2p(const DtfEngineDesc* e, int tail_adam_slot, long st
                               timeout_s, e->off_out_w, s));
   if (wait_dense) HIP_TRY(hipStreamWaitEvent(s, e->ev_dense_updated, 0));
   return 0;
+}
+
+int dtf_engine_dp_record_updated(const DtfEngineDesc* e, hipStream_t comm) {
+  return (int)hipEventRecord(e->ev_dense_updated, comm);
 }
 
 // make the deferred dense update of the last step visible to s

@@ -65,14 +65,36 @@ class Backend:
         opt = self.export_optimizer_state() if with_optimizer else None
         return lambda: (params, step, opt)
 
-    # coordinated stop: the last 4 floats of the gradient arena travel in every synchronous step's
-    # all-reduce; a worker that wants the job to stop raises its flag there and every worker reads the same sum
+    # Job-wide control flags: the last 4 floats of the gradient arena travel in every synchronous step's
+    # (tail) all-reduce.  Each worker publishes ITS flags there every step -- slot 0: stop request, slot 1: "gather the
+    # sharded master weights" request -- and every worker reads the same sums after the same step.
+    CTRL_STOP, CTRL_GATHER = 0, 1
+
+    @property
+    def ctrl_src(self) -> torch.Tensor:
+        """This rank's own 4 control flags (the source that is published every step)."""
+        if getattr(self, "_ctrl_src", None) is None:
+            self._ctrl_src = torch.zeros(4, dtype=torch.float32, device=self.params.device)
+        return self._ctrl_src
+
+    def set_control(self, slot: int, value: float):
+        self.ctrl_src[slot:slot + 1].fill_(float(value))
+
+    def publish_control(self):
+        """Copy this rank's flags into the control block of the gradient arena (before the all-reduce).  The native
+        data-parallel step does this inside its slab reduction; the generic path calls it."""
+        self.grads[self.layout.ctrl:self.layout.ctrl + 4].copy_(self.ctrl_src)
+
+    def control_sums(self):
+        """The 4 summed flags of the last step's all-reduce (reads device memory: synchronises the stream on the GPU)."""
+        return self.grads[self.layout.ctrl:self.layout.ctrl + 4].tolist()
+
     def raise_stop_flag(self):
-        self.grads[self.layout.ctrl:self.layout.ctrl + 1].fill_(1.0)
+        self.set_control(self.CTRL_STOP, 1.0)
 
     def stop_flag_sum(self) -> float:
-        """> 0 once any worker has raised its flag (reads device memory: synchronises the stream on the GPU)."""
-        return float(self.grads[self.layout.ctrl].item())
+        """> 0 once any worker has raised its flag."""
+        return float(self.control_sums()[self.CTRL_STOP])
 
     # optimizer slots as flat arenas, for the chief -> workers broadcast after a restore (None: no slots)
     def adam_arenas(self) -> Optional[Tuple[torch.Tensor, torch.Tensor]]: return None
@@ -177,6 +199,7 @@ class HipBackend(Backend):
 
     params = property(lambda self: self.engine.params)
     grads = property(lambda self: self.engine.grads)
+    ctrl_src = property(lambda self: self.engine.ctrl_src)
 
     def init_params(self, seed: int):
         self.engine.init_params(seed)

@@ -140,8 +140,12 @@ class HipEngine:
         elif optimizer != "sgd":
             raise ValueError(f"unknown optimizer {optimizer!r}")
         self.state = torch.zeros(8, dtype=torch.int64, device=dev)
-        self.hyper = torch.tensor([learning_rate, adam_betas[0], adam_betas[1], adam_eps, grad_scale, 0.0, 0.0, 0.0],
-                                  **f32)
+        # [lr, beta1, beta2, eps, gradient scale, -, -, - | 4 control flags of this rank: stop request, gather request, -, -]
+        # The control flags are published into the control block of the gradient arena by the step's slab reduction
+        # and summed over the ranks by the tail collective (csrc/runtime/engine.hip backward_conv_impl).
+        self.hyper = torch.tensor([learning_rate, adam_betas[0], adam_betas[1], adam_eps, grad_scale, 0.0, 0.0, 0.0,
+                                   0.0, 0.0, 0.0, 0.0], **f32)
+        self.ctrl_src = self.hyper[8:12]
 
         self.idx = torch.zeros(B, dtype=torch.int32, device=dev)
         self.p1 = torch.empty((B, 14, 14, C1), **act)

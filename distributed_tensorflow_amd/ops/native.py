@@ -144,7 +144,8 @@ _ENGINE_SIGS = {
     "dtf_engine_transposes": [_EP, c_int, c_void_p],
     "dtf_engine_train_step": [_EP, c_long, c_void_p],
     "dtf_engine_dp_phase1": [_EP, c_int, c_void_p, c_void_p],
-    "dtf_engine_dp_phase2": [_EP, c_long, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p],
+    "dtf_engine_dp_phase2": [_EP, c_long, c_long, c_int, c_int, c_void_p, c_int, c_void_p, c_void_p, c_void_p],
+    "dtf_engine_dp_record_updated": [_EP, c_void_p],
     "dtf_engine_dp_phase3_p2p": [_EP, c_int, c_long, c_int, c_void_p, ctypes.POINTER(c_void_p), c_int, c_int, c_long, c_uint,
                                  c_void_p, c_double],
     "dtf_engine_dp_phase3": [_EP, c_long, c_int, c_long, c_int, c_void_p, c_void_p],

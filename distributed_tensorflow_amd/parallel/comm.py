@@ -65,6 +65,32 @@ def broadcast(t: torch.Tensor, src: int, group=None):
         dist.broadcast(t, src=src, group=group)
 
 
+def reduce_scatter_sum_inplace(t: torch.Tensor, rank: int, world: int, group=None):
+    """``t`` is ``world`` equal slices; on return slice ``rank`` holds the sum over the ranks of that slice (the other
+    slices are unspecified).  RCCL reduces in place (output = the rank's slice of the input).  gloo has no
+    reduce-scatter: there (tests, one-GPU rehearsals) the whole range is all-reduced, which gives the same slice."""
+    per = t.numel() // world
+    if dist.get_backend(group) == "gloo":
+        all_reduce_sum(t, group=group)
+    else:
+        dist.reduce_scatter_tensor(t[rank * per:(rank + 1) * per], t, op=dist.ReduceOp.SUM, group=group)
+
+
+def all_gather_inplace(t: torch.Tensor, rank: int, world: int, group=None):
+    """``t`` is ``world`` equal slices and slice ``rank`` is valid here: afterwards every slice is, on every rank."""
+    per = t.numel() // world
+    if dist.get_backend(group) == "gloo":
+        h = t[rank * per:(rank + 1) * per].cpu() if t.is_cuda else t[rank * per:(rank + 1) * per].clone()
+        if h.dtype == torch.bfloat16:          # gloo moves bytes; bf16 is not among its types
+            h = h.view(torch.uint8)
+        parts = [torch.empty_like(h) for _ in range(world)]
+        dist.all_gather(parts, h, group=group)
+        out = torch.cat(parts)
+        t.copy_(out.view(t.dtype) if out.dtype != t.dtype else out)
+    else:
+        dist.all_gather_into_tensor(t, t[rank * per:(rank + 1) * per], group=group)
+
+
 def reduce_sum(t: torch.Tensor, dst: int, group=None):
     if staged(t, group):
         h = t.cpu()

@@ -112,7 +112,7 @@ class SyncAllReduce:
     coordinated_stop = True
 
     def __init__(self, backend: Backend, task: TaskInfo, worker_group, chief_rank: int, tail_group=None,
-                 p2p: bool = False, log=None, stop_check_steps: int = 20):
+                 p2p: bool = False, log=None, stop_check_steps: int = 20, shard_dense=None):
         self.b, self.task, self.group, self.chief_rank = backend, task, worker_group, chief_rank
         self.world = task.num_workers
         self.step_count = backend.get_global_step()
@@ -120,19 +120,29 @@ class SyncAllReduce:
         self._p2p = []
         self._stop_requested = False
         self.stop = False
+        # Sharded dense update (parallel/sync_dp.py): the chief's timed checkpoints need every worker to join a
+        # gather of the master weights first.  The request rides in the control block like the stop flag; every worker
+        # sees it after the same step, gathers, and the chief saves right there (Supervisor.should_stop()).
+        self._gather_requested = False
+        self.gather_done = False
         # the GPU path reads the flag (a device sync) only every stop_check_steps global steps; the CPU path every step
         self.stop_check_steps = max(1, int(stop_check_steps))
         # The overlapped schedule (parallel/sync_dp.py) needs collectives that run on streams: RCCL, or the
         # peer-to-peer kernels (--p2p_allreduce; these also work between tasks that share one GPU over gloo).
-        if backend.name == "hip" and (dist.get_backend(worker_group) != "gloo" or p2p):
+        # (an explicit --dense_update=sharded also selects it over gloo, staged through the host: tests, rehearsals)
+        if backend.name == "hip" and (dist.get_backend(worker_group) != "gloo" or p2p or shard_dense):
             from .sync_dp import SyncDataParallel
             tail_p2p = dense_p2p = None
             if p2p:
-                tail_p2p, dense_p2p = self._bring_up_p2p(backend.engine, worker_group, log or (lambda *a: None))
+                tail_p2p, dense_p2p = self._bring_up_p2p(backend.engine, worker_group, log or (lambda *a: None),
+                                                         dense=not shard_dense)
             self._dp = SyncDataParallel(backend.engine, group=worker_group, tail_group=tail_group, tail_p2p=tail_p2p,
-                                        dense_p2p=dense_p2p)
+                                        dense_p2p=dense_p2p, shard_dense=shard_dense)
+            if self._dp.shard and log:
+                log(f"worker/{task.task_index}: dense update sharded over {self.world} workers "
+                    f"(reduce-scatter -> update of 1/{self.world} -> all-gather of the compute copy)")
 
-    def _bring_up_p2p(self, eng, group, log):
+    def _bring_up_p2p(self, eng, group, log, dense: bool = True):
         """Both messages through csrc/kernels/p2p.hip if the kernels reproduce the process group's sums here
         (collective decisions: every worker ends up with the same pair)."""
         from .p2p import P2PAllReduce
@@ -140,6 +150,9 @@ class SyncAllReduce:
         out = []
         for name, n, two_shot in (("tail", eng.layout.total - n_dense, False), ("dense", n_dense, True)):
             obj = None
+            if name == "dense" and not dense:      # an explicitly sharded dense update goes through the process group
+                out.append(None)
+                continue
             try:
                 if n % (4 * self.world if two_shot else 4) == 0:
                     # generous bound: the chief's checkpoint writes and evaluations stall its peers inside the kernel
@@ -170,31 +183,52 @@ class SyncAllReduce:
     def request_stop(self):
         self._stop_requested = True
 
+    @property
+    def sharded(self) -> bool:
+        """True when checkpoints need a job-wide gather first (the dense update is sharded over the workers)."""
+        return self._dp is not None and self._dp.shard and self.b.engine.dtype != "fp32" and self.world > 1
+
+    def request_gather(self):
+        """Chief: ask every worker to join a gather of the master weights at the next control poll."""
+        self._gather_requested = True
+
     def poll_stop(self) -> bool:
-        """True on every worker after the same step once any worker has requested a stop."""
+        """True on every worker after the same step once any worker has requested a stop.  The same read serves the
+        gather request: when its sum is up, every worker gathers here, after the same step (``gather_done``)."""
         if self.stop:
             return True
         if self._dp is None or self.step_count % self.stop_check_steps == 0:
-            self.stop = self.b.stop_flag_sum() > 0.0
+            sums = self.b.control_sums()
+            self.stop = sums[Backend.CTRL_STOP] > 0.0
+            if self._dp is not None and sums[Backend.CTRL_GATHER] > 0.0:
+                self._dp.gather_master()
+                self.gather_done = True
+                if self._gather_requested:
+                    self._gather_requested = False
+                    self.b.set_control(Backend.CTRL_GATHER, 0.0)
         return self.stop
 
     def step(self) -> int:
+        # this rank's flags go out with the step's (tail) all-reduce
+        if self._stop_requested:
+            self.b.set_control(Backend.CTRL_STOP, 1.0)
+        if self._gather_requested:
+            self.b.set_control(Backend.CTRL_GATHER, 1.0)
         if self._dp is not None:
-            if self._stop_requested:
-                self.b.raise_stop_flag()       # before the step's tail all-reduce reads the control block
-            self._dp.train_step()
+            self._dp.train_step()              # the control flags are published by the step's slab reduction
         else:
             self.b.compute_gradients()
-            if self._stop_requested:
-                self.b.raise_stop_flag()
+            self.b.publish_control()
             comm.all_reduce_sum(self.b.grads, group=self.group)
             self.b.apply_gradients(scale=1.0 / self.world)
         self.step_count += 1
         return self.step_count
 
     def finish(self):
+        """Every worker calls this after the same last step."""
         if self._dp is not None:
             self._dp.flush()
+            self._dp.gather_master()           # collective; no-op unless the dense update is sharded
         self.check_health()
 
 

@@ -22,7 +22,14 @@ Design for xGMI (point-to-point links, ring collectives are per-link bound):
     pass touches the gradients;
   * the update of the dense (wd1) range runs on the comm stream right behind
     its all-reduce and is only waited for by the NEXT step's fc1 forward, so the
-    big all-reduce also hides behind the next step's sampler + conv forward.
+    big all-reduce also hides behind the next step's sampler + conv forward;
+  * ``shard_dense`` (default at world > 1 over RCCL): the dense message is a REDUCE-SCATTER, each rank applies the
+    optimizer to its 1/world shard of wd1 only (fp32 master + moments of that shard), and the updated weights come
+    back as an ALL-GATHER of what the kernels actually read -- the bf16 copy (fp32 configuration: the fp32 weights).
+    Per rank that is (N-1)/N x (12.8 + 6.4) MB on the links instead of 2 (N-1)/N x 12.8 MB, and the dense update
+    kernel touches 1/N of the arena.  The fp32 master weights (and Adam moments) of the other ranks' shards go stale in
+    between; ``gather_master()`` (a collective: every rank calls it) brings them up to date before anything reads
+    them -- checkpoints, parameter dumps, the end of training (parallel/strategies.py arranges the agreement).
 """
 from __future__ import annotations
 
@@ -70,7 +77,8 @@ class SyncDataParallel:
     DENSE_SLOT, TAIL_SLOT = 3, 4   # per-range Adam step counters in the device state
 
     def __init__(self, engine: HipEngine, bucket_mb: float = 64.0, group=None, tail_group=None,
-                 defer_dense_update: bool = True, tail_p2p=None, dense_p2p=None, p2p_tail_update: bool = True):
+                 defer_dense_update: bool = True, tail_p2p=None, dense_p2p=None, p2p_tail_update: bool = True,
+                 shard_dense=None):
         self.eng = engine
         self.group = group
         self.tail_group = tail_group if tail_group is not None else group
@@ -103,6 +111,27 @@ class SyncDataParallel:
         self.tail_bucket = (self.n_dense, lay.total)
         engine.set_grad_scale(1.0 / self.world)
         self._have_pending_dense = False
+        # sharded dense update (module docstring): needs equal, 32-byte aligned shards and the process group path
+        self.rank = dist.get_rank(group)
+        # what the all-gather carries: the tensor the fc1 kernels read
+        self._dense_weights = (engine.params if engine.dtype == "fp32" else engine.shadow)[0:self.n_dense]
+        self.master_stale = False      # True while other ranks' shards of the fp32 master / moments are out of date
+        self.shard = False
+        self.shard_lo, self.shard_hi = 0, self.n_dense
+        self.set_shard(self.world > 1 if shard_dense is None else bool(shard_dense))
+
+    def can_shard(self) -> bool:
+        return self.n_dense % (8 * self.world) == 0
+
+    def set_shard(self, on: bool):
+        """Switch the dense message between all-reduce and reduce-scatter / sharded update / all-gather.  Collective
+        when it switches sharding OFF after sharded steps (the master weights are gathered first)."""
+        on = bool(on) and self.can_shard()
+        if not on and self.shard:
+            self.gather_master()
+        self.shard = on
+        per = self.n_dense // self.world
+        self.shard_lo, self.shard_hi = (self.rank * per, (self.rank + 1) * per) if on else (0, self.n_dense)
 
     def broadcast_parameters(self, src: int = 0):
         """Chief initialises, everybody else receives (reference: chief runs init_op)."""
@@ -116,6 +145,12 @@ class SyncDataParallel:
         # RCCL reduces in place on the current stream; over gloo (ranks sharing one GPU in tests and rehearsals)
         # parallel/comm.py stages the range through the host -- correct, nothing overlaps
         _pg.all_reduce_sum(self.eng.grads[lo:hi], group=group)
+
+    def _reduce_scatter(self):
+        _pg.reduce_scatter_sum_inplace(self.eng.grads[0:self.n_dense], self.rank, self.world, group=self.group)
+
+    def _all_gather(self):
+        _pg.all_gather_inplace(self._dense_weights, self.rank, self.world, group=self.group)
 
     def train_step(self):
         """One synchronous step.  All launches, stream waits and event records of the schedule above
@@ -133,7 +168,13 @@ class SyncDataParallel:
         check(lib.dtf_engine_dp_phase1(d, int(self._have_pending_dense), cur, comm), "dp_phase1")
         if tr: tr.pop(); tr.push("allreduce dense (enqueue)")
         dense_src = None     # where the deferred dense update reads the summed gradient (None: the gradient arena)
-        if self.dense_p2p is not None:
+        if self.master_stale and not (self.shard and self.dense_p2p is None):
+            raise RuntimeError("sharded dense updates were followed by an unsharded step without gather_master(): "
+                               "use set_shard(False)")
+        if self.shard and self.dense_p2p is None:
+            with torch.cuda.stream(self.comm_stream):
+                self._reduce_scatter()
+        elif self.dense_p2p is not None:
             # the result stays in the kernel's staging buffer: no copy back into the arena (a third of its local traffic)
             dense_src = self.dense_p2p.allreduce(eng.grads[0:self.n_dense], comm, gather=False)
         else:
@@ -141,8 +182,16 @@ class SyncDataParallel:
                 for lo, hi in self.dense_buckets:
                     self._allreduce(lo, hi, self.group)
         if tr: tr.pop(); tr.push("dp_phase2: conv backward")
-        check(lib.dtf_engine_dp_phase2(d, self.n_dense, self.DENSE_SLOT, 1, dense_src, cur, comm,
-                                       tail), "dp_phase2")
+        shard = self.shard and self.dense_p2p is None
+        lo, hi = (self.shard_lo, self.shard_hi) if shard else (0, self.n_dense)
+        check(lib.dtf_engine_dp_phase2(d, lo, hi, self.DENSE_SLOT, 1, dense_src, int(not shard), cur, comm, tail),
+              "dp_phase2")
+        if shard:
+            if tr: tr.pop(); tr.push("all-gather dense weights (enqueue)")
+            with torch.cuda.stream(self.comm_stream):
+                self._all_gather()
+            check(lib.dtf_engine_dp_record_updated(d, comm), "dp_record_updated")
+            self.master_stale = eng.dtype != "fp32" and self.world > 1
         if self.tail_p2p is not None and self.p2p_tail_update:
             if tr: tr.pop(); tr.push("dp_phase3: p2p all-reduce + update (one launch)")
             p = self.tail_p2p
@@ -165,6 +214,18 @@ class SyncDataParallel:
               "dp_phase3")
         if tr: tr.pop()
         self._have_pending_dense = self.defer
+
+    def gather_master(self):
+        """Collective (every rank of the group): bring the fp32 master weights -- and the Adam moments -- of the dense
+        range up to date on every rank after sharded updates.  No-op when nothing is stale."""
+        if not self.master_stale:
+            return
+        self.flush()
+        eng = self.eng
+        arenas = [eng.params] + ([eng.adam_m, eng.adam_v] if eng.optimizer == "adam" else [])
+        for a in arenas:
+            _pg.all_gather_inplace(a[0:self.n_dense], self.rank, self.world, group=self.group)
+        self.master_stale = False
 
     def flush(self):
         """Make every pending update visible to the current stream (call before reading parameters)."""

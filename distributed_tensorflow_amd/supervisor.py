@@ -104,6 +104,12 @@ class Supervisor:
         st = self._strategy
         if not self._stop and st is not None and getattr(st, "coordinated_stop", False) and st.poll_stop():
             self._stop = True
+        if st is not None and getattr(st, "gather_done", False):
+            # sharded dense update: every worker has just gathered the master weights after the same step, at the
+            # chief's request (maybe_save) -- the one moment a checkpoint of them is consistent
+            st.gather_done = False
+            if self.is_chief and self.logdir and not self._stop:     # (a stopping job saves once, at the end)
+                self.save()
         return self._stop
 
     def request_stop(self):
@@ -129,6 +135,9 @@ class Supervisor:
             self.pre_save_check()             # e.g. a timed-out peer-to-peer sum: raise instead of checkpointing it
         st = self._strategy
         if st is not None and getattr(st, "_dp", None) is not None:
+            if st._dp.master_stale:
+                raise RuntimeError("the dense update is sharded over the workers and this task's copy of the other "
+                                   "shards is stale: save through maybe_save() (job-wide gather) or after finish()")
             st._dp.flush()                    # a deferred dense update is ordered before the snapshot (GPU-side wait)
         if self._writer is None:
             self._writer = AsyncCheckpointWriter(self.log)
@@ -152,5 +161,9 @@ class Supervisor:
         """Timed save (chief): call between steps."""
         if self.is_chief and self.logdir and self.save_model_secs > 0 and \
                 time.monotonic() - self._last_save >= self.save_model_secs:
+            st = self._strategy
+            if st is not None and getattr(st, "sharded", False):
+                st.request_gather()           # the save happens in should_stop(), when every worker has gathered
+                return None
             return self.save()
         return None

@@ -163,7 +163,9 @@ def run(F, log=print) -> dict:
     elif mode == "sync":
         strategy = SyncAllReduce(backend, task, worker_group, chief_rank, tail_group=tail_group,
                                  p2p=bool(getattr(F, "p2p_allreduce", False)), log=log,
-                                 stop_check_steps=F.health_check_steps)
+                                 stop_check_steps=F.health_check_steps,
+                                 shard_dense={"auto": None, "sharded": True, "replicated": False}[
+                                     getattr(F, "dense_update", "auto")])
     elif async_impl == "p2p":
         strategy = AsyncP2PWorker(backend, task, chief_rank)
     else:

@@ -60,6 +60,9 @@ flags.DEFINE_string("comm_backend", "auto", "auto (gloo for the cpu backend, RCC
                     "(gloo also carries GPU tensors, staged through the host: several tasks sharing ONE GPU, which RCCL refuses)")
 flags.DEFINE_boolean("p2p_allreduce", False, "sync mode, hip backend: both gradient messages through the peer-to-peer "
                      "push kernels (one-shot tail, two-shot dense) instead of RCCL, after a self-check")
+flags.DEFINE_string("dense_update", "auto", "sync mode, hip backend over RCCL: auto | sharded (reduce-scatter the fc1 gradient, "
+                    "each worker updates 1/N of wd1, all-gather the compute copy) | replicated (all-reduce, every worker "
+                    "updates all of it); auto = sharded when there is more than one worker")
 flags.DEFINE_boolean("trace", False, "roctx ranges around steps/collectives/checkpoints (rocprofv3 --marker-trace)")
 flags.DEFINE_integer("fault_inject_step", -1, "test hook: crash this worker after N local steps")
 flags.DEFINE_integer("fault_inject_task", -1, "test hook: which worker task crashes (-1 = any)")

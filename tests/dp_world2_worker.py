@@ -15,15 +15,25 @@ from distributed_tensorflow_amd.parallel import comm  # noqa: E402
 from distributed_tensorflow_amd.parallel.sync_dp import SyncDataParallel  # noqa: E402
 
 rank, port, optimizer, tail = int(sys.argv[1]), int(sys.argv[2]), sys.argv[3], sys.argv[4]
+WORLD = int(sys.argv[5]) if len(sys.argv) > 5 else 2
+DTYPE = sys.argv[6] if len(sys.argv) > 6 else "bf16"
 B, STEPS, LR = 64, 5, (0.01 if optimizer == "sgd" else 1e-3)
+if WORLD > 2 and optimizer == "sgd":
+    LR = 0.002      # gentler first steps: rounding differences of the sums grow ~10x per step at 0.01 from this init
+# two addends commute, so world 2 reproduces the replay's sums exactly; from three on the collective's order of
+# additions differs from the replay's ((g0 + g1) + g2) + g3 by fp32 rounding, which five steps amplify a little
+# (the steep first steps at this learning rate amplify it: 1e-4 relative on the loss after four steps); the exact checks
+# at world > 2 are rank against rank (bitwise) and compute copy against master
+TOL = 2e-6 if WORLD == 2 else 1e-3
+LOSS_TOL = 1e-5 if WORLD == 2 else 1e-3
 torch.cuda.set_device(0)
-comm.init_process_group("gloo", rank, 2, "127.0.0.1", port, timeout_s=90)
-ds = DeviceDataset.synthetic(4096, seed=1234)
+comm.init_process_group("gloo", rank, WORLD, "127.0.0.1", port, timeout_s=90)
+ds = DeviceDataset.synthetic(4096, seed=1234, dtype=DTYPE)
 
 
 def engine(seed):
     return HipEngine(ModelSpec(), B, ds, optimizer=optimizer, learning_rate=LR, seed=seed, multi_stream=False,
-                     fuse_dense_update=False)
+                     fuse_dense_update=False, dtype=DTYPE)
 
 
 eng = engine(1000 + rank)
@@ -34,14 +44,17 @@ if tail.startswith("p2p"):     # both messages through the peer-to-peer kernels 
     n_dense = eng.layout.segment("wd1", "wd1")[1]
     tail_p2p = P2PAllReduce(eng.layout.total - n_dense, eng.device)
     dense_p2p = P2PAllReduce(n_dense, eng.device, two_shot=True)
+# "pg": both messages as all-reduces of the process group; "pg-sharded": the dense one as reduce-scatter -> update of
+# this rank's 1/WORLD of wd1 -> all-gather of the compute copy
 dp = SyncDataParallel(eng, tail_group=dist.new_group(), tail_p2p=tail_p2p, dense_p2p=dense_p2p,
-                      p2p_tail_update=(tail != "p2p-plain"))
+                      p2p_tail_update=(tail != "p2p-plain"), shard_dense=(tail == "pg-sharded"))
+assert dp.shard == (tail == "pg-sharded")
 dp.broadcast_parameters()
 
-refs = [engine(1000 + q) for q in (0, 1)]
+refs = [engine(1000 + q) for q in range(WORLD)]
 for e in refs:
     e.init_params(seed=7)
-    e.set_grad_scale(0.5)
+    e.set_grad_scale(1.0 / WORLD)
 assert torch.equal(eng.params, refs[0].params), "broadcast_parameters did not install rank 0's weights"
 
 losses = []
@@ -52,23 +65,44 @@ for _ in range(STEPS):
         e.launch_forward(ds.images, ds.labels, e.idx, backward=True)
         e.launch_backward_dense()
         e.launch_backward_conv(ds.images, e.idx)
-    g = refs[0].grads + refs[1].grads
+    g = refs[0].grads.clone()
+    for e in refs[1:]:
+        g += e.grads
     for e in refs:
         e.grads.copy_(g)
         e.launch_update()
     losses.append((eng.last_metrics()[0], refs[rank].last_metrics()[0]))
 dp.flush()
+if dp.shard and DTYPE == "bf16":
+    # the other ranks' shards of the fp32 master are stale until the (collective) gather; the compute copy is not
+    assert dp.master_stale
+    lo, hi = dp.shard_lo, dp.shard_hi
+    torch.cuda.synchronize()
+    e_own = (eng.params[lo:hi] - refs[rank].params[lo:hi]).abs().max().item()
+    assert e_own <= TOL, f"own shard differs from the replay by {e_own}"
+dp.gather_master()
+assert not dp.master_stale
 torch.cuda.synchronize()
+if DTYPE == "bf16":        # after the gather the compute copy is exactly the rounded master everywhere
+    assert torch.equal(eng.shadow[0:dp.n_dense], eng.params[0:dp.n_dense].to(torch.bfloat16)), "shadow != bf16(master)"
 
 for mine, ref in losses:                  # this rank saw the batches its replayed twin saw
-    assert abs(mine - ref) <= 1e-5 * max(1.0, abs(ref)), losses
+    assert abs(mine - ref) <= LOSS_TOL * max(1.0, abs(ref)), losses
 assert losses[-1][0] < losses[0][0], losses
 err = (eng.params - refs[rank].params).abs().max().item()
-assert err <= 2e-6, f"data-parallel parameters differ from the replayed two-rank step by {err}"
+assert err <= TOL, f"data-parallel parameters differ from the replayed {WORLD}-rank step by {err}"
 assert eng.global_step == refs[rank].global_step == STEPS
-both = [torch.empty_like(eng.params) for _ in range(2)]
-dist.all_gather(both, eng.params)
-assert torch.equal(both[0], both[1]), "ranks diverged"
+if optimizer == "adam" and dp.shard:
+    em = (eng.adam_m - refs[rank].adam_m).abs().max().item()
+    assert em <= TOL, f"gathered first moments differ from the replay by {em}"
+both = [torch.empty(eng.params.shape, dtype=eng.params.dtype) for _ in range(WORLD)]
+dist.all_gather(both, eng.params.cpu())
+assert all(torch.equal(both[0], b) for b in both[1:]), "ranks diverged"
+if optimizer == "adam":    # the moments too (sharded: gathered with the master weights)
+    for arena in (eng.adam_m, eng.adam_v):
+        ms = [torch.empty(arena.shape, dtype=arena.dtype) for _ in range(WORLD)]
+        dist.all_gather(ms, arena.cpu())
+        assert all(torch.equal(ms[0], b) for b in ms[1:]), "optimizer moments diverged"
 if tail_p2p is not None:
     assert tail_p2p.status() == 0 and dense_p2p.status() == 0
     dist.barrier()

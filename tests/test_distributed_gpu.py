@@ -40,6 +40,37 @@ def test_sync_1ps_2workers_hip_backend_over_gloo(gpu_lib, tmp_path, p2p):
     assert int(ck["Variable_8"]) == 24 and ck["Variable_2"].shape == (3136, 1024)
 
 
+@pytest.mark.parametrize("optimizer", ["sgd", "adam"])
+def test_sync_sharded_dense_update_timed_checkpoints(gpu_lib, tmp_path, optimizer):
+    """--dense_update=sharded through the CLI: each worker updates half of wd1, so the chief's TIMED checkpoints need
+    the job-wide gather (requested through the control block, served at a control poll by both workers after the same
+    step).  Mid-run checkpoints must exist, and the final one must equal both workers' final parameters."""
+    import numpy as np
+    logdir = str(tmp_path / "logs")
+    dumps = [str(tmp_path / f"w{i}.npy") for i in range(2)]
+    out = launch(1, 2, ["--mode=sync", "--batch_size=64", "--steps=60", "--dense_update=sharded", "--save_model_secs=0.05",
+                        "--health_check_steps=5", f"--optimizer={optimizer}"] + COMMON, logdir, backend="hip",
+                 per_task_extra={("worker", w): [f"--dump_params={dumps[w]}"] for w in (0, 1)})
+    _ok(out)
+    assert "dense update sharded over 2 workers" in out[("worker", 0)][1]
+    from distributed_tensorflow_amd.checkpoint import read_bundle
+    from distributed_tensorflow_amd.models.spec import ArenaLayout, ModelSpec
+    files = os.listdir(logdir)
+    steps = sorted(int(f.split("-")[1].split(".")[0]) for f in files if f.endswith(".index"))
+    assert steps[-1] == 60 and len(steps) >= 2 and all(s % 5 == 0 for s in steps), steps   # saved at control polls
+    p0, p1 = (np.load(d) for d in dumps)
+    assert np.array_equal(p0, p1), "workers ended with different master weights"
+    lay = ArenaLayout(ModelSpec())
+    ck = read_bundle(os.path.join(logdir, "model.ckpt-60"))
+    o = lay.offsets["wd1"]
+    assert np.array_equal(ck["Variable_2"].ravel(), p0[o:o + lay.sizes["wd1"]])
+    # a mid-run checkpoint is complete too: no half of wd1 may be left at an older step than the other
+    mid = read_bundle(os.path.join(logdir, f"model.ckpt-{steps[0]}"))
+    assert int(mid["Variable_8"]) == steps[0]
+    if optimizer == "adam":
+        assert any(k.endswith("/Adam") for k in mid), sorted(mid)[:5]
+
+
 @pytest.mark.parametrize("impl", ["p2p", "broadcast"])
 def test_async_parameter_server_hip_backend_over_gloo(gpu_lib, tmp_path, impl):
     logdir = str(tmp_path / "logs")
@@ -53,9 +84,15 @@ def test_async_parameter_server_hip_backend_over_gloo(gpu_lib, tmp_path, impl):
     assert "checkpoint" in files and any(f.endswith(".index") for f in files)
 
 
-@pytest.mark.parametrize("optimizer,tail", [("sgd", "pg"), ("adam", "pg"), ("sgd", "p2p"), ("adam", "p2p"),
-                                            ("sgd", "p2p-plain")])
-def test_overlapped_dp_schedule_world2_over_gloo(gpu_lib, optimizer, tail):
+@pytest.mark.parametrize("optimizer,tail,world,dtype", [
+    ("sgd", "pg", 2, "bf16"), ("adam", "pg", 2, "bf16"), ("sgd", "p2p", 2, "bf16"), ("adam", "p2p", 2, "bf16"),
+    ("sgd", "p2p-plain", 2, "bf16"),
+    # dense message as reduce-scatter -> sharded update -> all-gather of the compute copy (sync_dp.py shard_dense)
+    ("sgd", "pg-sharded", 2, "bf16"), ("adam", "pg-sharded", 2, "bf16"), ("sgd", "pg-sharded", 4, "bf16"),
+    ("sgd", "pg-sharded", 2, "fp32"), ("sgd", "p2p", 4, "bf16")])
+# (Adam is compared at world 2 only, where the sums are exact: with three or more addends the rounding of a near-zero
+#  gradient sum changes m / sqrt(v) by O(1), so a replay comparison says nothing there)
+def test_overlapped_dp_schedule_world2_over_gloo(gpu_lib, optimizer, tail, world, dtype):
     """parallel/sync_dp.py (the schedule bench.py runs on N GPUs: deferred dense update, two communicators,
     1/world scaling in the optimizer kernels) with TWO ranks, each feeding different batches: against a replay
     of both ranks with plain engines, and rank against rank.  gloo stands in for RCCL (one GPU); tail = "p2p" sends
@@ -68,8 +105,8 @@ def test_overlapped_dp_schedule_world2_over_gloo(gpu_lib, optimizer, tail):
     port = s.getsockname()[1]
     s.close()
     worker = os.path.join(os.path.dirname(os.path.abspath(__file__)), "dp_world2_worker.py")
-    procs = [subprocess.Popen([sys.executable, "-u", worker, str(r), str(port), optimizer, tail], stdout=subprocess.PIPE,
-                              stderr=subprocess.STDOUT, text=True) for r in range(2)]
+    procs = [subprocess.Popen([sys.executable, "-u", worker, str(r), str(port), optimizer, tail, str(world), dtype],
+                              stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True) for r in range(world)]
     outs = []
     for p in procs:
         try:
@@ -79,8 +116,9 @@ def test_overlapped_dp_schedule_world2_over_gloo(gpu_lib, optimizer, tail):
                 q.kill()
             raise AssertionError("timed out:\n" + p.communicate()[0][-3000:])
         outs.append((p.returncode, o))
-    for r, (rc, o) in enumerate(outs):
-        assert rc == 0 and f"DPW2 rank {r} ok" in o, o[-3000:]
+    ok = all(rc == 0 and f"DPW2 rank {r} ok" in o for r, (rc, o) in enumerate(outs))
+    assert ok, "\n".join(f"--- rank {r} (rc {rc}) ---\n" + "\n".join(l for l in o.splitlines() if "Gloo" not in l)[-1500:]
+                         for r, (rc, o) in enumerate(outs))
 
 
 def _bench(args, launcher=(), env=None):
