@@ -46,6 +46,7 @@ int dtf_head_fused_fwd_bwd(const void* part, int S, const void* bias1, float kee
                            const void* idx, void* logits_out, void* loss_rows, void* correct_rows, void* dlogits,
                            void* da, int B, int H, float grad_scale, float inv_keep, int backward, hipStream_t s);
 int dtf_transpose_head_w(const void* w, void* wT, int H, hipStream_t s);
+int dtf_dropout_mask(uint64_t seed, uint64_t offset, float keep_prob, void* out, long n, hipStream_t s);
 int dtf_metrics_reduce(const void* loss_rows, const void* correct_rows, int n, void* acc, int accumulate, hipStream_t s);
 int dtf_gemm_nn_partial(const void* A, const void* B, void* part, int M, int N, int K, int lda, int ldb, int S,
                         hipStream_t s);

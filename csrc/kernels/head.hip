@@ -172,6 +172,15 @@ __global__ __launch_bounds__(256) void transpose_head_w(const float* __restrict_
   if (i < H * kCls) out[i] = in[(size_t)(i % H) * kCls + i / H];
 }
 
+// Debug export of the dropout keep mask the fused fc1 epilogue applies for (seed, offset): out[i] = 1 if element i
+// (= row * H + column) is kept.  Same dropout_scale() call as head_fwd_bwd; tests compare it with the host mirror
+// (ops/reference.py dropout_mask_reference) and feed it to the oracle.
+__global__ __launch_bounds__(256) void dropout_mask_export(DropoutArgs drop, uint64_t offset, unsigned char* __restrict__ out,
+                                                           long n) {
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256)
+    out[i] = dropout_scale(drop, offset, (uint64_t)i) != 0.f ? 1 : 0;
+}
+
 // K9: batch reductions of the per-row loss / correctness the head kernel leaves behind (reference .idea/MNISTDist.py:148
 // reduce_mean(cost), :153 reduce_mean(cast(correct_pred))).  One workgroup, fixed order (deterministic), fp64 partial
 // sums; acc[0] = sum of losses, acc[1] = number of correct rows.  accumulate != 0 adds to acc (evaluation walks a
@@ -307,6 +316,15 @@ int dtf_head_f32_wgrad(const void* h1, const void* dlogits, const void* da, void
   HeadWgradArgsT<float> a{(const float*)h1, (const float*)dlogits, (const float*)da, (float*)part, B, H, rps,
                           (H + kHeadCols - 1) / kHeadCols};
   hipLaunchKernelGGL(head_wgrad<float>, dim3(a.nbx, KS), dim3(256), 0, s, a);
+  return (int)hipGetLastError();
+}
+
+int dtf_dropout_mask(uint64_t seed, uint64_t offset, float keep_prob, void* out, long n, hipStream_t s) {
+  if (n <= 0 || !out) return -3;
+  DropoutArgs drop{keep_prob, seed, nullptr};
+  const long blocks = (n + 255) / 256;
+  hipLaunchKernelGGL(dropout_mask_export, dim3((unsigned)(blocks > 2048 ? 2048 : blocks)), dim3(256), 0, s, drop, offset,
+                     (unsigned char*)out, n);
   return (int)hipGetLastError();
 }
 

@@ -297,6 +297,17 @@ class HipEngine:
     def export_grads(self) -> Dict[str, torch.Tensor]:
         return {name: self.layout.view(self.grads, name).detach().cpu().clone() for name in self.layout.names()}
 
+    def export_dropout_mask(self, offset: Optional[int] = None, rows: Optional[int] = None) -> torch.Tensor:
+        """Debug launch: the [rows, hidden] uint8 keep mask the fc1 epilogue applies at dropout offset ``offset``
+        (default: the offset the NEXT step will use, i.e. the device counter now).  Read it BEFORE the step."""
+        rows = self.B if rows is None else rows
+        if offset is None:
+            offset = int(self.state[self.STATE_DROPOUT].item())
+        out = torch.empty((rows, self.spec.hidden), dtype=torch.uint8, device=self.device)
+        check(self.lib.dtf_dropout_mask(self.seed & (2 ** 64 - 1), int(offset), float(self.keep_prob), ptr(out),
+                                        out.numel(), self._s()), "dropout_mask")
+        return out
+
     def refresh_shadows(self, cast: bool = True):
         """bf16 compute copies: the arena itself (+ K-contiguous transposes for the NT kernels)."""
         s = self._s()

@@ -40,6 +40,7 @@ class OracleModel:
         self.global_step = 0
         self._adam_m = self._adam_v = None
         self._adam_t = 0
+        self.dropout_mask = None      # explicit [B, hidden] keep mask for the next training forward (tests)
         self.init_params()
 
     # ------------------------------------------------------------------ init
@@ -62,7 +63,11 @@ class OracleModel:
     def logits(self, x: torch.Tensor, train: bool = False, params=None) -> torch.Tensor:
         p = self.params if params is None else params
         keep = self.keep_prob if train else 1.0
-        return R.conv_net(x.to(self.device, torch.float32), p, keep)
+        mask = self.dropout_mask.to(self.device) if (train and self.dropout_mask is not None) else None
+        return self._net(x.to(self.device, torch.float32), p, keep, mask)
+
+    def _net(self, x, p, keep, mask):
+        return R.conv_net(x, p, keep, mask=mask)
 
     def loss_and_accuracy(self, x, labels, train: bool = False) -> Tuple[torch.Tensor, torch.Tensor]:
         with torch.no_grad():
@@ -107,3 +112,12 @@ class OracleModel:
         loss, acc = self.compute_gradients(x, labels)
         self.apply_gradients()
         return loss, acc
+
+
+class Bf16EmulatedOracle(OracleModel):
+    """The fp32 oracle with a bf16 rounding at every point where the mixed-precision engine stores a bf16 tensor
+    (ops/reference.py conv_net_bf16_emulated).  Engine-vs-fp32 tolerances in the tests are derived from the distance
+    between this model and the plain fp32 oracle."""
+
+    def _net(self, x, p, keep, mask):
+        return R.conv_net_bf16_emulated(x, p, keep, mask=mask)
