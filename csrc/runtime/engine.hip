@@ -96,6 +96,7 @@ int dtf_engine_sample(const DtfEngineDesc* e, hipStream_t s) {
 static int forward_conv_impl(const DtfEngineDesc* e, const void* images, const void* idx, int sampled, int n,
                              hipStream_t s) {
   const void* state = sampled ? e->state : nullptr;
+  if (n < 1 || n > e->B) return -3;      // every activation buffer holds B rows
   if (is_f32(e)) {
     if (sampled)
       DTF_TRY(dtf_conv1_f32_fwd_sampled(images, e->idx, e->state, e->ds_n, e->ds_hb, e->sample_seed, e->shuffle,
@@ -124,12 +125,28 @@ int dtf_engine_forward_conv(const DtfEngineDesc* e, const void* images, const vo
   return forward_conv_impl(e, images, idx, 0, n, s);
 }
 
+// Split-K factor of the fc1 forward GEMM for n rows.  The partial-product buffer (engine.py fc1_part) holds
+// auto_splits(B) * B rows; a ragged evaluation chunk n < B has fewer tiles and would by itself pick MORE splits than
+// fit there (e.g. hidden 4096, B = 1024: one split; n = 784: two splits of 784 rows), so the choice is capped.
+static int auto_splits(int M, int N) {
+  const int tiles = ((M + 127) / 128) * ((N + 127) / 128);
+  const int S = (256 + tiles - 1) / tiles;
+  return S > 8 ? 8 : S;
+}
+static int fc1_splits_for(const DtfEngineDesc* e, int n) {
+  const long cap_rows = (long)auto_splits(e->B, e->hidden) * e->B;
+  int S = auto_splits(n, e->hidden);
+  while (S > 1 && (long)S * n > cap_rows) --S;
+  return S;
+}
+
 int dtf_engine_forward_dense(const DtfEngineDesc* e, const void* labels, const void* idx, int backward, int n,
                              int train_mode, hipStream_t s) {
   const float keep = train_mode ? e->keep_prob : 1.0f;
+  if (n < 1 || n > e->B) return -3;
   if (is_f32(e)) {
     const int S = dtf_gemm_f32_nn_partial(e->p2, f32at(e->params, e->off_wd1), e->fc1_part, n, e->hidden, e->flat, e->flat,
-                                          e->hidden, 0, s);
+                                          e->hidden, fc1_splits_for(e, n), s);
     if (S <= 0) return S == 0 ? -1 : S;
     return dtf_head_f32_fused_fwd_bwd(e->fc1_part, S, f32at(e->params, e->off_bd1), keep, e->seed, e->state, e->h1,
                                       e->out_wT, f32at(e->params, e->off_out_b), labels, idx, e->logits, e->loss_rows,
@@ -138,7 +155,7 @@ int dtf_engine_forward_dense(const DtfEngineDesc* e, const void* labels, const v
   // wd1 is consumed in its native [in, out] layout (no transposed copy), split-K; the bias + ReLU +
   // dropout epilogue runs inside the head kernel, which turns the partial sums into h1 on the fly
   const int S = dtf_gemm_nn_partial(e->p2, bf16at(e->shadow, e->off_wd1), e->fc1_part, n, e->hidden, e->flat, e->flat,
-                                    e->hidden, 0, s);
+                                    e->hidden, fc1_splits_for(e, n), s);
   if (S <= 0) return S == 0 ? -1 : S;
   return dtf_head_fused_fwd_bwd(e->fc1_part, S, f32at(e->params, e->off_bd1), keep, e->seed, e->state, e->h1, e->out_wT,
                                 f32at(e->params, e->off_out_b), labels, idx, e->logits, e->loss_rows, e->correct_rows,

@@ -40,6 +40,7 @@ class Backend:
     def synchronize(self): pass
     # state I/O ------------------------------------------------------------
     def get_global_step(self) -> int: raise NotImplementedError
+    def set_learning_rate(self, lr: float): raise NotImplementedError
     def set_global_step(self, v: int): raise NotImplementedError
     def init_params(self, seed: int): raise NotImplementedError
 
@@ -145,6 +146,7 @@ class CpuBackend(Backend):
 
     def get_global_step(self): return self.model.global_step
     def set_global_step(self, v): self.model.global_step = int(v)
+    def set_learning_rate(self, lr: float): self.model.lr = float(lr)
 
     def adam_arenas(self):
         m = self.model
@@ -289,6 +291,7 @@ class HipBackend(Backend):
             return params, step, opt
         return finish
 
+    def set_learning_rate(self, lr: float): self.engine.set_learning_rate(float(lr))
     def get_global_step(self): return self.engine.global_step
     def set_global_step(self, v):
         self.engine.set_global_step(v)

@@ -127,6 +127,10 @@ def run(F, log=print) -> dict:
 
     # ------------------------------------------------------------------ ps role
     if task.is_ps:
+        if mode == "async" and getattr(F, "lr_scaling", "none") != "none":
+            # the ps applies the updates: the rate for one worker's batch, no warm-up (updates arrive unordered)
+            from .utils.lr_schedule import scaled_rate
+            backend.set_learning_rate(scaled_rate(F.learning_rate, F.batch_size, getattr(F, "lr_base_batch", 128), F.lr_scaling))
         log(f"ps/{task.task_index}: serving ({mode}{'/' + async_impl if mode == 'async' else ''}) "
             f"for {task.num_workers} worker(s)")
         if mode == "async" and async_impl == "p2p":
@@ -184,10 +188,20 @@ def run(F, log=print) -> dict:
     eval_every = int(getattr(F, "eval_every", 0) or 0)
     tracing = trace.set_enabled(True) if getattr(F, "trace", False) else trace.enabled()
     images_per_step = F.batch_size * (task.num_workers if mode == "sync" else 1)
+    # large-batch rule (utils/lr_schedule.py): the global batch of a synchronous job is batch_size x workers
+    from .utils.lr_schedule import LrSchedule
+    lr_sched = LrSchedule(F.learning_rate, images_per_step, getattr(F, "lr_base_batch", 128),
+                          getattr(F, "lr_scaling", "none"), getattr(F, "lr_warmup_steps", 0))
+    if lr_sched.peak_lr != F.learning_rate:
+        log(f"{task.job_name}/{task.task_index}: learning rate {F.learning_rate:g} x ({images_per_step}/"
+            f"{getattr(F, 'lr_base_batch', 128)}, {lr_sched.rule}) = {lr_sched.peak_lr:g}"
+            + (f", warm-up over {lr_sched.warmup_steps} steps" if lr_sched.warmup_steps else ""))
+    if mode == "async" and lr_sched.peak_lr != F.learning_rate:
+        log("note: asynchronous mode applies every worker's gradient separately (the global batch is one worker's batch)")
     t_start = time.perf_counter()
     try:
         _train_loop(F, task, mode, backend, strategy, sv, live, timer, metrics, result, images_per_step, eval_every,
-                    tracing, health, log)
+                    tracing, health, log, lr_sched)
     except SystemExit:
         raise
     except BaseException as e:
@@ -254,16 +268,22 @@ def _install_signal_handlers(sv, log, task: TaskInfo):
 
 
 def _train_loop(F, task, mode, backend, strategy, sv, live, timer, metrics, result, images_per_step, eval_every,
-                tracing, health, log):
+                tracing, health, log, lr_sched=None):
     t_start = time.perf_counter()
     with sv.managed_session(strategy):
         step = strategy.step_count
         result["start_step"] = step
         local_steps = 0
+        cur_lr = None
         while not sv.should_stop() and step < F.training_iter:
             if live is not None:
                 live.raise_if_failed()
             prev = step
+            if lr_sched is not None:
+                lr = lr_sched(step)            # a function of the global step: the same on every synchronous worker
+                if lr != cur_lr:
+                    backend.set_learning_rate(lr)
+                    cur_lr = lr
             if tracing: trace.push(f"step {prev}")
             step = strategy.step()
             if tracing: trace.pop()

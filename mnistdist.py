@@ -60,6 +60,10 @@ flags.DEFINE_string("comm_backend", "auto", "auto (gloo for the cpu backend, RCC
                     "(gloo also carries GPU tensors, staged through the host: several tasks sharing ONE GPU, which RCCL refuses)")
 flags.DEFINE_boolean("p2p_allreduce", False, "sync mode, hip backend: both gradient messages through the peer-to-peer "
                      "push kernels (one-shot tail, two-shot dense) instead of RCCL, after a self-check")
+flags.DEFINE_string("lr_scaling", "none", "none (reference: fixed --learning_rate) | linear | sqrt: scale --learning_rate by "
+                    "(global batch / --lr_base_batch) or its square root (utils/lr_schedule.py)")
+flags.DEFINE_integer("lr_base_batch", 128, "the batch size --learning_rate is meant for (the reference's default batch)")
+flags.DEFINE_integer("lr_warmup_steps", 0, "linear warm-up from --learning_rate to the scaled rate over this many global steps")
 flags.DEFINE_string("dense_update", "auto", "sync mode, hip backend over RCCL: auto | sharded (reduce-scatter the fc1 gradient, "
                     "each worker updates 1/N of wd1, all-gather the compute copy) | replicated (all-reduce, every worker "
                     "updates all of it); auto = sharded when there is more than one worker")

@@ -297,3 +297,33 @@ def test_evaluate_matches_oracle_with_one_sync(gpu_lib, dataset):
     m_loss, m_acc = eng.last_metrics()
     assert abs(m_loss - float(eng.loss_rows.double().mean())) < 1e-6
     assert abs(m_acc - float(eng.correct_rows.double().mean())) < 1e-9
+
+
+@pytest.mark.parametrize("dtype", ["bf16", "fp32"])
+def test_ragged_evaluation_chunk_keeps_fc1_partials_in_bounds(gpu_lib, dtype):
+    """Evaluation walks a dataset in chunks of the engine batch; the last chunk is ragged.  With 4096 rows per chunk
+    the fc1 forward GEMM runs unsplit, but a 3000-row chunk has few enough tiles that the split-K heuristic alone
+    would pick two splits of 3000 rows -- more than the 4096-row partial buffer holds (found by a memory fault in
+    tools/lr_scaling_sweep.py).  The executor caps the split count; the result must match the oracle."""
+    from distributed_tensorflow_amd.engine import DeviceDataset, HipEngine
+    from distributed_tensorflow_amd.models.oracle import Bf16EmulatedOracle
+    ds = DeviceDataset.synthetic(4096 + 3000, seed=99, dtype=dtype)
+    eng = HipEngine(ModelSpec(), 4096, ds, optimizer="sgd", learning_rate=0.01, seed=2, dtype=dtype)
+    eng.init_params(seed=5)
+    for _ in range(3):
+        eng.train_step()
+    guard = eng.logits.clone()          # allocated right behind fc1_part: an overrun would land in a neighbour
+    loss, acc = eng.evaluate(ds.images, ds.labels)
+    oracle = (OracleModel if dtype == "fp32" else Bf16EmulatedOracle)(ModelSpec(), device="cuda")
+    oracle.load_params(eng.export_params())
+    tl = ta = 0.0
+    for lo in range(0, ds.n, 1024):
+        l, a = oracle.loss_and_accuracy(ds.images[lo:lo + 1024].float(), ds.labels[lo:lo + 1024])
+        k = min(1024, ds.n - lo)
+        tl, ta = tl + float(l) * k, ta + float(a) * k
+    assert abs(acc - ta / ds.n) <= 3.0 / ds.n, (acc, ta / ds.n)
+    assert abs(loss - tl / ds.n) <= 2e-3 * max(1.0, tl / ds.n), (loss, tl / ds.n)
+    assert guard.shape == eng.logits.shape
+    # and a chunk larger than the engine batch is refused, not run
+    with pytest.raises(RuntimeError):
+        eng.launch_forward(ds.images, ds.labels, None, backward=False, n=4097, train_mode=False)
