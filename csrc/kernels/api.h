@@ -111,4 +111,19 @@ int dtf_head_f32_fused_fwd_bwd(const void* part, int S, const void* bias1, float
                                void* da, int B, int H, float grad_scale, float inv_keep, int backward, hipStream_t s);
 int dtf_head_f32_wgrad(const void* h1, const void* dlogits, const void* da, void* part, int B, int H, int KS,
                        hipStream_t s);
+// asynchronous parameter server over peer-to-peer mailboxes (ps.hip)
+int dtf_ps_blocks();
+int dtf_ps_max_workers();
+int dtf_ps_push(const void* grads, void* dst, void* flags, void* hdr, const void* version, int nr, const long* lo,
+                const long* hi, long n_total, unsigned seq, unsigned kind, hipStream_t s);
+int dtf_ps_poll(const void* flags, const void* hdr, int W, int NB, int start, const unsigned* expect, void* out,
+                double timeout_s, hipStream_t s);
+int dtf_ps_apply_push(int adam, void* w, void* m, void* v, const void* hyper, const void* grad, int nr, const long* lo,
+                      const long* hi, long n_total, int apply, double adam_t, void* box_f32, void* box_bf16, long n_dense,
+                      void* box_flags, void* box_hdr, void* full, void* full_flags, unsigned seq, unsigned long long step,
+                      unsigned stop, hipStream_t s);
+int dtf_ps_install(const void* box_flags, const void* box_hdr, const void* box_f32, const void* box_bf16, long n_dense,
+                   int nr, const long* lo, const long* hi, long n_total, unsigned seq, void* params, void* shadow,
+                   const void* full, const void* full_flags, void* state, void* version, void* host_hdr, int owner,
+                   int* status, double timeout_s, hipStream_t s);
 }

@@ -35,6 +35,10 @@ class Backend:
     # step pieces ----------------------------------------------------------
     def compute_gradients(self): raise NotImplementedError
     def apply_gradients(self, scale: float = 1.0, step_inc: int = 1): raise NotImplementedError
+    def advance_input(self):
+        """Move on to the next batch (and dropout draw) after compute_gradients() when NO local apply_gradients()
+        follows -- asynchronous workers, whose updates happen on the ps.  Backends whose input pipeline advances by
+        itself (next_batch) need nothing."""
     def last_metrics(self) -> Tuple[float, float]: raise NotImplementedError
     def evaluate(self, split: str = "test") -> Tuple[float, float]: raise NotImplementedError
     def synchronize(self): pass
@@ -215,6 +219,14 @@ class HipBackend(Backend):
         e.launch_forward(ds.images, ds.labels, e.idx, backward=True)
         e.launch_backward_dense()
         e.launch_backward_conv(ds.images, e.idx)
+
+    def advance_input(self):
+        # the sample cursor and the dropout offset live in the device step state and are normally advanced by the
+        # optimizer launch; without one, every step would draw the same batch and the same mask
+        e = self.engine
+        from .ops.native import check
+        check(e.lib.dtf_advance_state(e.state.data_ptr(), e.B, 0, 1, torch.cuda.current_stream(e.device).cuda_stream),
+              "advance_state")
 
     def apply_gradients(self, scale: float = 1.0, step_inc: int = 1):
         e = self.engine

@@ -72,6 +72,17 @@ _SIGS = {
                               c_void_p, c_long, c_long, c_void_p, c_long, c_int, c_int, c_void_p, c_long, c_int, c_void_p,
                               c_int, c_long, c_long, c_long, c_void_p],
     "dtf_p2p_bytes": [c_int, c_long],
+    "dtf_ps_blocks": [],
+    "dtf_ps_max_workers": [],
+    "dtf_ps_push": [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, ctypes.POINTER(c_long), ctypes.POINTER(c_long),
+                    c_long, c_uint, c_uint, c_void_p],
+    "dtf_ps_poll": [c_void_p, c_void_p, c_int, c_int, c_int, ctypes.POINTER(c_uint), c_void_p, c_double, c_void_p],
+    "dtf_ps_apply_push": [c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, ctypes.POINTER(c_long),
+                          ctypes.POINTER(c_long), c_long, c_int, c_double, c_void_p, c_void_p, c_long, c_void_p, c_void_p,
+                          c_void_p, c_void_p, c_uint, ctypes.c_ulonglong, c_uint, c_void_p],
+    "dtf_ps_install": [c_void_p, c_void_p, c_void_p, c_void_p, c_long, c_int, ctypes.POINTER(c_long), ctypes.POINTER(c_long),
+                       c_long, c_uint, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int,
+                       c_void_p, c_double, c_void_p],
     "dtf_p2p_alloc": [c_long, ctypes.POINTER(c_void_p)],
     "dtf_p2p_free": [c_void_p],
     "dtf_p2p_export": [c_void_p, c_char_p],

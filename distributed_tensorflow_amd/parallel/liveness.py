@@ -53,6 +53,7 @@ class Liveness:
         self._count = 0
         self._seen = {r: (None, time.monotonic()) for r in self.watch}
         self._flags_seen = set()
+        self._peers = {}          # rank -> (last heartbeat value, since when): tasks checked on demand (peer_lost)
         self._lock = threading.Lock()
         self._beat()
         self._thread = threading.Thread(target=self._run, name="dtf-liveness", daemon=True)
@@ -89,6 +90,27 @@ class Liveness:
         while not self.flag_set(name):
             self.raise_if_failed()
             time.sleep(poll_s)
+
+    def peer_lost(self, rank: int) -> bool:
+        """On-demand check of a task that is NOT in ``watch`` (the ps of an asynchronous job tolerates lost workers but
+        must stop waiting for them): True once the task has left a death note or its heartbeat has stood still for
+        ``timeout_s``.  A task that finished in an orderly way is not lost."""
+        now = time.monotonic()
+        with self._lock:
+            try:
+                if self._get(f"dtf/done/{rank}") is not None:
+                    return False
+                if self._get(f"dtf/dead/{rank}") is not None:
+                    return True
+                v = self._get(f"dtf/hb/{rank}")
+            except Exception:
+                return False
+        last, since = self._peers.get(rank, (None, now))
+        if v != last:
+            self._peers[rank] = (v, now)
+            return False
+        self._peers[rank] = (last, since)
+        return now - since > self.timeout_s
 
     # --------------------------------------------------------------- monitor
     def _run(self):

@@ -293,6 +293,7 @@ class AsyncP2PWorker:
 
     def step(self) -> int:
         self.b.compute_gradients()
+        self.b.advance_input()             # no local update follows: move on to the next batch
         self._exchange(KIND_GRAD)
         return self.step_count
 
@@ -391,6 +392,7 @@ class AsyncRounds:
     def step(self) -> int:
         b = self.b
         b.compute_gradients()
+        b.advance_input()                  # no local update follows: move on to the next batch
         self._send.copy_(b.grads)
         if self._pending is not None:                 # parameters of the previous round land now
             self._pending.wait()

@@ -134,6 +134,8 @@ class Supervisor:
         if self.pre_save_check is not None:
             self.pre_save_check()             # e.g. a timed-out peer-to-peer sum: raise instead of checkpointing it
         st = self._strategy
+        if st is not None and hasattr(st, "prepare_save"):
+            st.prepare_save()                 # asynchronous push mode: the fp32 master lives on the ps tasks
         if st is not None and getattr(st, "_dp", None) is not None:
             if st._dp.master_stale:
                 raise RuntimeError("the dense update is sharded over the workers and this task's copy of the other "

@@ -119,8 +119,36 @@ def run(F, log=print) -> dict:
         tail_group = dist.new_group(task.cluster.worker_ranks())     # 2nd communicator: concurrent small all-reduce
 
     async_impl = F.async_impl
+    if async_impl not in ("auto", "push", "p2p", "broadcast"):
+        raise SystemExit(f"--async_impl={async_impl!r}: expected auto, push, p2p or broadcast")
     if async_impl == "auto":
-        async_impl = "p2p" if kind == "cpu" else "broadcast"
+        async_impl = "p2p" if kind == "cpu" else "push"
+    staleness = int(getattr(F, "staleness", -1))
+    if mode == "async":
+        if async_impl == "push" and kind != "hip":
+            raise SystemExit("--async_impl=push moves gradients with GPU kernels: it needs --backend=hip")
+        if async_impl == "p2p" and dist.is_initialized() and dist.get_backend() != "gloo":
+            # one Python thread per worker in blocking send/recv: not something RCCL's stream-ordered send/recv supports
+            raise SystemExit("--async_impl=p2p serves every worker from a thread of its own with blocking send/recv, which "
+                             "works over gloo only: use --async_impl=push (peer-to-peer kernels) or --comm_backend=gloo")
+        if staleness < 0:
+            staleness = 0 if async_impl == "push" else 1
+    push_fallback = None
+    if mode == "async" and async_impl == "push":
+        # Bring-up is collective and unanimous (every task raises or none does), so every task falls back together.
+        from .parallel.async_push import AsyncPushServer, AsyncPushWorker
+        try:
+            if task.is_ps:
+                push_obj = AsyncPushServer(backend, task, chief_rank, F.training_iter, staleness=staleness, log=log,
+                                           peer_lost=live.peer_lost if live is not None else None)
+            else:
+                push_obj = AsyncPushWorker(backend, task, chief_rank, staleness=staleness,
+                                           timeout_s=min(float(F.comm_timeout), 30.0))
+        except RuntimeError as e:
+            push_fallback = str(e)
+            log(f"{task.job_name}/{task.task_index}: peer-to-peer parameter server unavailable ({push_fallback[:200]}); "
+                "falling back to --async_impl=broadcast")
+            async_impl, staleness = "broadcast", min(staleness, 1)
 
     metrics = MetricsLogger(F.metrics_file or None)
     result = dict(role=f"{task.job_name}/{task.task_index}", mode=mode, backend=kind)
@@ -133,13 +161,19 @@ def run(F, log=print) -> dict:
             backend.set_learning_rate(scaled_rate(F.learning_rate, F.batch_size, getattr(F, "lr_base_batch", 128), F.lr_scaling))
         log(f"ps/{task.task_index}: serving ({mode}{'/' + async_impl if mode == 'async' else ''}) "
             f"for {task.num_workers} worker(s)")
-        if mode == "async" and async_impl == "p2p":
+        if mode == "async" and async_impl == "push":
+            push_obj.broadcast_initial()
+            result["global_step"] = push_obj.serve()
+            result["applied"], result["dropped_workers"] = push_obj.applied, push_obj.dropped
+            result["staleness_hist"] = dict(push_obj.staleness_hist)
+            push_obj.fab.close()
+        elif mode == "async" and async_impl == "p2p":
             srv = AsyncP2PServer(backend, task, chief_rank, F.training_iter, log=log)
             srv.broadcast_initial()
             result["global_step"] = srv.serve()
             result["applied"], result["dropped_workers"] = srv.applied, srv.dropped
         elif mode == "async":
-            srv = AsyncRounds(backend, task, chief_rank, staleness=F.staleness, optimizer=F.optimizer)
+            srv = AsyncRounds(backend, task, chief_rank, staleness=staleness, optimizer=F.optimizer)
             srv.broadcast_initial()
             result["global_step"] = srv.serve(F.training_iter)
         else:
@@ -170,10 +204,12 @@ def run(F, log=print) -> dict:
                                  stop_check_steps=F.health_check_steps,
                                  shard_dense={"auto": None, "sharded": True, "replicated": False}[
                                      getattr(F, "dense_update", "auto")])
+    elif async_impl == "push":
+        strategy = push_obj
     elif async_impl == "p2p":
         strategy = AsyncP2PWorker(backend, task, chief_rank)
     else:
-        strategy = AsyncRounds(backend, task, chief_rank, staleness=F.staleness, optimizer=F.optimizer)
+        strategy = AsyncRounds(backend, task, chief_rank, staleness=staleness, optimizer=F.optimizer)
 
     if mode == "async" and F.optimizer == "adam" and task.is_chief:
         log("note: in asynchronous mode the Adam moments live on the ps tasks and are not part of the chief's "
@@ -222,6 +258,8 @@ def run(F, log=print) -> dict:
         raise
     result["saved"] = list(sv.saved)
     result["restored_from"] = sv.restored_from
+    if hasattr(strategy, "fab"):
+        strategy.fab.close()         # every answer has been installed and the ps tasks have this worker's goodbye
     if world > 1:
         if mode == "sync" and task.is_chief:
             live.set_flag("workers_done")            # releases the ps tasks blocked in their join

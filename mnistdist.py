@@ -33,8 +33,11 @@ flags.DEFINE_integer("display_step", 100, "display step")
 # --- extensions ---
 flags.DEFINE_alias("steps", "training_iter")
 flags.DEFINE_string("mode", "sync", "sync (RCCL all-reduce DP) | async (parameter-server semantics)")
-flags.DEFINE_string("async_impl", "auto", "auto | p2p (true async send/recv) | broadcast (reduce+broadcast rounds)")
-flags.DEFINE_integer("staleness", 1, "async broadcast rounds: gradient staleness bound in rounds (0 or 1)")
+flags.DEFINE_string("async_impl", "auto", "auto (push on the hip backend, p2p on the cpu backend) | push (GPU-native: gradients "
+                    "and parameters move through peer-to-peer mailbox kernels, csrc/kernels/ps.hip) | p2p (send/recv "
+                    "threads; gloo only) | broadcast (reduce + broadcast rounds on collectives)")
+flags.DEFINE_integer("staleness", -1, "async: how many of its own steps a worker may run ahead of the parameter server's "
+                     "answers (push: 0..8, default 0 = the reference's pull-after-push; broadcast rounds: 0 or 1, default 1)")
 flags.DEFINE_string("optimizer", "sgd", "sgd (reference) | adam (TF deep-MNIST tutorial recipe)")
 flags.DEFINE_float("keep_prob", 1.0, "dropout keep probability (the reference feeds 1.0)")
 flags.DEFINE_string("model", "deep_mnist", "deep_mnist | wide (conv 128/256, fc4096)")

@@ -71,6 +71,78 @@ def test_sync_sharded_dense_update_timed_checkpoints(gpu_lib, tmp_path, optimize
         assert any(k.endswith("/Adam") for k in mid), sorted(mid)[:5]
 
 
+@pytest.mark.parametrize("n_ps,optimizer,staleness", [(1, "sgd", 0), (1, "sgd", 2), (1, "adam", 1), (2, "sgd", 1)])
+def test_async_push_parameter_server(gpu_lib, tmp_path, n_ps, optimizer, staleness):
+    """--async_impl=push: gradients and parameters move through the peer-to-peer mailbox kernels (csrc/kernels/ps.hip),
+    here between tasks that share the one GPU (hipIpc on the same device; gloo only carries the bring-up).  The ps
+    applies every gradient in arrival order: global_step == number of applied gradients == the step budget (M:188),
+    the staleness histogram is logged, and the chief's checkpoint holds the fp32 master it fetched from the ps."""
+    import re
+    import numpy as np
+    logdir = str(tmp_path / "logs")
+    dump = str(tmp_path / "chief.npy")
+    steps = 40
+    out = launch(n_ps, 2, ["--mode=async", "--async_impl=push", f"--staleness={staleness}", "--batch_size=64",
+                           f"--steps={steps}", f"--optimizer={optimizer}"] + COMMON, logdir, backend="hip",
+                 per_task_extra={("worker", 0): [f"--dump_params={dump}"]})
+    _ok(out)
+    for p in range(n_ps):
+        o = out[("ps", p)][1]
+        assert "falling back" not in o, o
+        m = re.search(r"applied (\d+) gradients; staleness .* histogram ((?:\d+:\d+ ?)+)", o)
+        assert m and int(m.group(1)) == steps, o[-1500:]
+        hist = {int(k): int(v) for k, v in (kv.split(":") for kv in m.group(2).split())}
+        assert sum(hist.values()) == steps
+        if staleness == 0:
+            # pull-after-push with two workers: at most the other worker's update can slip in between
+            assert max(hist) <= 2, hist
+    for w in (0, 1):
+        assert "Optimization Finished!" in out[("worker", w)][1]
+    from distributed_tensorflow_amd.checkpoint import read_bundle
+    from distributed_tensorflow_amd.models.spec import ArenaLayout, ModelSpec
+    ck = read_bundle(os.path.join(logdir, f"model.ckpt-{steps}"))
+    assert int(ck["Variable_8"]) == steps
+    lay = ArenaLayout(ModelSpec())
+    flat = np.load(dump)
+    from distributed_tensorflow_amd.models.spec import TF_VARIABLE_NAMES
+    for name in lay.names():
+        o = lay.offsets[name]
+        assert np.array_equal(ck[TF_VARIABLE_NAMES[name]].ravel(), flat[o:o + lay.sizes[name]]), name
+    # the master is fp32-exact, not a widened bf16 copy: some wd1 entry has low mantissa bits set
+    wd1 = ck["Variable_2"].ravel().view(np.uint32)
+    assert np.any(wd1 & 0xFFFF), "checkpointed wd1 looks like a bf16 copy"
+
+
+@pytest.mark.parametrize("optimizer,dtype", [("sgd", "bf16"), ("adam", "bf16"), ("sgd", "fp32")])
+def test_async_push_single_worker_equals_local_training(gpu_lib, optimizer, dtype):
+    """One worker, staleness 0: the asynchronous parameter server IS sequential training.  The worker replays every
+    step on a local engine; compute copy after every step and the fetched fp32 master at the end agree bit for bit
+    (tests/async_push_worker.py)."""
+    import socket
+    import subprocess
+    import sys
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    worker = os.path.join(os.path.dirname(os.path.abspath(__file__)), "async_push_worker.py")
+    procs = [subprocess.Popen([sys.executable, "-u", worker, str(r), str(port), optimizer, dtype], stdout=subprocess.PIPE,
+                              stderr=subprocess.STDOUT, text=True) for r in range(2)]
+    outs = []
+    for p in reversed(procs):           # the worker first: if it fails, the ps only leaves at its own time limit
+        try:
+            o, _ = p.communicate(timeout=120)
+        except subprocess.TimeoutExpired:
+            for q in procs:
+                q.kill()
+            o = "TIMED OUT\n" + p.communicate()[0]
+        outs.append((p.returncode, o))
+    outs.reverse()
+    ok = all(rc == 0 and f"APUSH rank {r} ok" in o for r, (rc, o) in enumerate(outs))
+    assert ok, "\n".join(f"--- rank {r} (rc {rc}) ---\n" + "\n".join(l for l in o.splitlines() if "Gloo" not in l)[-2500:]
+                         for r, (rc, o) in enumerate(outs))
+
+
 @pytest.mark.parametrize("impl", ["p2p", "broadcast"])
 def test_async_parameter_server_hip_backend_over_gloo(gpu_lib, tmp_path, impl):
     logdir = str(tmp_path / "logs")
