@@ -82,14 +82,17 @@ __device__ __forceinline__ void gemm_pipeline(int T, GL&& gload, SW&& swrite, CP
 // HEADW: the launch is a 1-D grid of the GEMM's tiles FOLLOWED by hw.nbx * KS workgroups that compute the
 // output-layer weight gradient (head_wgrad_core.hpp) -- independent work that fills the CUs this GEMM
 // leaves idle (fc1 dgrad: 200 tiles on 256 CUs) instead of paying for a launch of its own.
-template <int BM, int BN, int NW, int EPI, bool HEADW = false>
+// WAVES_M x (NW / WAVES_M) waves.  The 256 x 128 tile runs 4 x 2 waves of 64 x 64: 8 fragment reads per 16 MFMAs
+// instead of the 128 x 128 tile's 6 per 8, and 1.5 instead of 2 staged bytes per MAC -- the 128 x 128 loop is bound
+// by the LDS (ds_write_b128 store path + fragment reads), not by the MFMA pipe.
+template <int BM, int BN, int NW, int EPI, bool HEADW = false, int WAVES_M = 2>
 __global__ __launch_bounds__(NW * 64, DTF_GEMM_MINW) void gemm_nt_bf16(const bf16* A, const bf16* Bm, bf16* __restrict__ C,
                                                         const float* __restrict__ bias, int M, int N, int K,
                                                         int lda, int ldb, int ldc, DropoutArgs drop,
                                                         HeadWgradArgs hw = HeadWgradArgs{}) {
   constexpr int BK = 64, NT = NW * 64;
-  constexpr int WAVES_N = NW / 2;
-  constexpr int WM = BM / 2, WN = BN / WAVES_N;
+  constexpr int WAVES_N = NW / WAVES_M;
+  constexpr int WM = BM / WAVES_M, WN = BN / WAVES_N;
   constexpr int MT = WM / 16, NTL = WN / 16;
   constexpr int A_CH = BM * 8 / NT, B_CH = BN * 8 / NT;  // 16-byte chunks per thread
   __shared__ __attribute__((aligned(16))) struct {   // one object: the head wgrad workgroups use it as one scratch area
@@ -550,6 +553,9 @@ int dtf_gemm_nt(const void* A, const void* B, void* C, const void* bias, int M, 
   if ((K & 63) || (lda & 7) || (ldb & 7)) return -3;  // the unguarded loader needs whole K tiles
   DropoutArgs d{keep_prob, seed, (const int64_t*)state};
   if (tile == 0) tile = ((long)((M + 127) / 128) * ((N + 127) / 128) >= 192) ? 128 : 64;
+  // 256 x 128 tiles once they fill the machine 1.5 times over (measured on MI355X: M 4096, N 3136, K 1024: 42.2 vs 49.1 us;
+  // M 1024, N 12544, K 4096: 134 vs 149 us; at M 1024, N 3136 their 100 tiles leave 60 % of the CUs idle: 21.9 vs 14.0 us)
+  if (tile == 128 && epi == 0 && (long)((M + 255) / 256) * ((N + 127) / 128) >= 384) tile = 256;
 #define NT_CASE(BMN, E)                                                                               \
   hipLaunchKernelGGL((gemm_nt_bf16<BMN, BMN, BMN / 16, E>),                                           \
                      dim3((N + BMN - 1) / BMN, (M + BMN - 1) / BMN), dim3(BMN * 4), 0, s, (const bf16*)A, \
@@ -558,6 +564,9 @@ int dtf_gemm_nt(const void* A, const void* B, void* C, const void* bias, int M, 
   else if (tile == 128 && epi == 1) NT_CASE(128, EPI_BIAS_RELU_DROPOUT);
   else if (tile == 64 && epi == 0) NT_CASE(64, EPI_STORE);
   else if (tile == 64 && epi == 1) NT_CASE(64, EPI_BIAS_RELU_DROPOUT);
+  else if (tile == 256 && epi == 0)
+    hipLaunchKernelGGL((gemm_nt_bf16<256, 128, 8, EPI_STORE, false, 4>), dim3((N + 127) / 128, (M + 255) / 256), dim3(512), 0, s,
+                       (const bf16*)A, (const bf16*)B, (bf16*)C, (const float*)bias, M, N, K, lda, ldb, ldc, d, HeadWgradArgs{});
   else if (tile == 128 && epi == 2) NT_CASE(128, EPI_NOSTORE_DIAG);
   else if (tile == 64 && epi == 2) NT_CASE(64, EPI_NOSTORE_DIAG);
   else return -1;

@@ -290,6 +290,22 @@ def test_gemm_nt(gpu_lib, M, N, K, tile):
     assert rel_err(C, F.relu(ref + bias)) < 4e-3
 
 
+@pytest.mark.parametrize("M,N,K", [(4096, 3136, 1024), (4000, 3000, 256), (300, 200, 128)])
+def test_gemm_nt_256x128_tile(gpu_lib, M, N, K):
+    """The 256 x 128 workgroup tile (4 x 2 waves of 64 x 64; selected automatically once it fills the machine 1.5
+    times over): full and ragged tiles, forced with tile = 256 and through the automatic choice."""
+    g = torch.Generator(device="cpu").manual_seed(25)
+    A = bf(torch.randn(M, K, generator=g)).to(DEV)
+    Bm = bf(torch.randn(N, K, generator=g) * 0.05 + torch.arange(N).float()[:, None] * 1e-3).to(DEV)
+    ref = A.float() @ Bm.float().t()
+    for tile in (256, 0):
+        C = torch.full((M, N), float("nan"), dtype=torch.bfloat16, device=DEV)
+        check(gpu_lib.dtf_gemm_nt(ptr(A), ptr(Bm), ptr(C), None, M, N, K, K, K, N, 0, 1.0, 0, None, tile, stream()),
+              "gemm_nt 256")
+        assert rel_err(C, ref) < 4e-3, tile
+
+
+
 @pytest.mark.parametrize("M,N,K,S", [(1024, 1024, 3136, 0), (100, 1024, 3136, 0), (257, 384, 192, 3), (64, 128, 64, 1)])
 def test_gemm_nn_splitk_forward(gpu_lib, M, N, K, S):
     g = torch.Generator(device="cpu").manual_seed(15)
