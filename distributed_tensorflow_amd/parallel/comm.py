@@ -65,15 +65,31 @@ def broadcast(t: torch.Tensor, src: int, group=None):
         dist.broadcast(t, src=src, group=group)
 
 
+_scratch = {}
+
+
+def _scratch_like(t: torch.Tensor, numel: int, tag: str) -> torch.Tensor:
+    """A persistent staging buffer per (tag, size, dtype, device): the slice collectives below hand RCCL
+    NON-overlapping send / receive buffers (in-place reduce-scatter / all-gather are legal in NCCL but are the road less
+    travelled; one small device copy per call buys the common path)."""
+    key = (tag, numel, t.dtype, t.device)
+    buf = _scratch.get(key)
+    if buf is None:
+        buf = _scratch[key] = torch.empty(numel, dtype=t.dtype, device=t.device)
+    return buf
+
+
 def reduce_scatter_sum_inplace(t: torch.Tensor, rank: int, world: int, group=None):
     """``t`` is ``world`` equal slices; on return slice ``rank`` holds the sum over the ranks of that slice (the other
-    slices are unspecified).  RCCL reduces in place (output = the rank's slice of the input).  gloo has no
-    reduce-scatter: there (tests, one-GPU rehearsals) the whole range is all-reduced, which gives the same slice."""
+    slices are unspecified).  gloo has no reduce-scatter: there (tests, one-GPU rehearsals) the whole range is
+    all-reduced, which gives the same slice."""
     per = t.numel() // world
     if dist.get_backend(group) == "gloo":
         all_reduce_sum(t, group=group)
     else:
-        dist.reduce_scatter_tensor(t[rank * per:(rank + 1) * per], t, op=dist.ReduceOp.SUM, group=group)
+        out = _scratch_like(t, per, "rs")
+        dist.reduce_scatter_tensor(out, t, op=dist.ReduceOp.SUM, group=group)
+        t[rank * per:(rank + 1) * per].copy_(out)
 
 
 def all_gather_inplace(t: torch.Tensor, rank: int, world: int, group=None):
@@ -88,7 +104,9 @@ def all_gather_inplace(t: torch.Tensor, rank: int, world: int, group=None):
         out = torch.cat(parts)
         t.copy_(out.view(t.dtype) if out.dtype != t.dtype else out)
     else:
-        dist.all_gather_into_tensor(t, t[rank * per:(rank + 1) * per], group=group)
+        send = _scratch_like(t, per, "ag")
+        send.copy_(t[rank * per:(rank + 1) * per])
+        dist.all_gather_into_tensor(t, send, group=group)
 
 
 def reduce_sum(t: torch.Tensor, dst: int, group=None):
