@@ -120,10 +120,10 @@ int dtf_ps_poll(const void* flags, const void* hdr, int W, int NB, int start, co
                 double timeout_s, hipStream_t s);
 int dtf_ps_apply_push(int adam, void* w, void* m, void* v, const void* hyper, const void* grad, int nr, const long* lo,
                       const long* hi, long n_total, int apply, double adam_t, void* box_f32, void* box_bf16, long n_dense,
-                      void* box_flags, void* box_hdr, void* full, void* full_flags, unsigned seq, unsigned long long step,
-                      unsigned stop, hipStream_t s);
+                      void* box_flags, void* box_hdr, void* full, void* full_flags, const void* full_src, unsigned adam_count,
+                      unsigned seq, unsigned long long step, unsigned stop, hipStream_t s);
 int dtf_ps_install(const void* box_flags, const void* box_hdr, const void* box_f32, const void* box_bf16, long n_dense,
                    int nr, const long* lo, const long* hi, long n_total, unsigned seq, void* params, void* shadow,
-                   const void* full, const void* full_flags, void* state, void* version, void* host_hdr, int owner,
-                   int* status, double timeout_s, hipStream_t s);
+                   const void* full, const void* full_flags, void* full_dst, void* state, void* version, void* host_hdr,
+                   int owner, int* status, double timeout_s, hipStream_t s);
 }

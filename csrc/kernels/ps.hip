@@ -84,7 +84,7 @@ struct PsPushArgs {
   unsigned* hdr;             // [4] of that slot: {version lo, version hi, kind, 0}
   const int64_t* version;    // device word: global_step of the parameters this gradient was computed with
   PsRanges r;
-  unsigned seq, kind;        // kind 1 = gradient, 2 = goodbye (no data), 3 = request for the fp32 master (no data)
+  unsigned seq, kind;        // kind 1 = gradient, 2 = goodbye, 3 / 4 / 5 = request for the fp32 master / Adam m / Adam v (no data)
 };
 
 __global__ __launch_bounds__(kPsThreads) void ps_push(PsPushArgs a) {
@@ -163,6 +163,8 @@ struct PsApplyArgs {
   unsigned* box_hdr;         // [4]: {global_step lo, hi, stop, 0}
   float* full;               // worker's fp32 "master" area (arena-indexed) or nullptr
   unsigned* full_flags;
+  const float* full_src;     // what goes into `full`: nullptr = the (updated) weights, else this arena (Adam m or v)
+  unsigned adam_count;       // header word 3: number of Adam updates applied so far (the chief checkpoints it)
   unsigned seq, step_lo, step_hi, stop;
 };
 
@@ -202,12 +204,14 @@ __global__ __launch_bounds__(kPsThreads) void ps_apply_push(PsApplyArgs a) {
       *reinterpret_cast<bf16x4*>(a.box_bf16 + off) = (bf16x4){(bf16)wv[0], (bf16)wv[1], (bf16)wv[2], (bf16)wv[3]};
     else
       *reinterpret_cast<f32x4*>(a.box_f32 + off) = wv;
-    if (a.full) *reinterpret_cast<f32x4*>(a.full + off) = wv;
+    if (a.full)
+      *reinterpret_cast<f32x4*>(a.full + off) = a.full_src ? *reinterpret_cast<const f32x4*>(a.full_src + off) : wv;
   }
   if (blockIdx.x == 0 && threadIdx.x == 0) {
     a.box_hdr[0] = a.step_lo;
     a.box_hdr[1] = a.step_hi;
     a.box_hdr[2] = a.stop;
+    a.box_hdr[3] = a.adam_count;
   }
   __threadfence_system();
   __syncthreads();
@@ -232,7 +236,8 @@ struct PsInstallArgs {
   const unsigned* full_flags;
   int64_t* state;            // device step state: state[1] = global_step   (header owner only)
   int64_t* version;          // device word: version of the installed parameters (header owner only)
-  unsigned* host_hdr;        // host-visible [4]: {global_step lo, hi, stop, seq}   (header owner only)
+  float* full_dst;           // where the `full` area goes: nullptr = params, else this arena (Adam m or v)
+  unsigned* host_hdr;        // host-visible [8]: {global_step lo, hi, stop, seq, adam updates}   (header owner only)
   int owner;                 // 1: this ps owns global_step
   int* status;
   long long timeout_ticks;
@@ -250,7 +255,8 @@ __global__ __launch_bounds__(kPsThreads) void ps_install(PsInstallArgs a) {
       *reinterpret_cast<bf16x4*>(a.shadow + off) = *reinterpret_cast<const bf16x4*>(a.box_bf16 + off);
     else
       *reinterpret_cast<f32x4*>(a.params + off) = *reinterpret_cast<const f32x4*>(a.box_f32 + off);
-    if (a.full) *reinterpret_cast<f32x4*>(a.params + off) = *reinterpret_cast<const f32x4*>(a.full + off);
+    if (a.full)
+      *reinterpret_cast<f32x4*>((a.full_dst ? a.full_dst : a.params) + off) = *reinterpret_cast<const f32x4*>(a.full + off);
   }
   if (a.owner && blockIdx.x == 0 && threadIdx.x == 0) {
     const uint64_t step = (uint64_t)a.box_hdr[0] | ((uint64_t)a.box_hdr[1] << 32);
@@ -260,6 +266,7 @@ __global__ __launch_bounds__(kPsThreads) void ps_install(PsInstallArgs a) {
     a.host_hdr[1] = a.box_hdr[1];
     a.host_hdr[2] = a.box_hdr[2];
     a.host_hdr[3] = a.seq;
+    a.host_hdr[4] = a.box_hdr[3];
     __threadfence_system();
   }
 }
@@ -293,7 +300,7 @@ int dtf_ps_max_workers() { return kPsMaxWorkers; }
 // computes them from the layout); n_total bounds every range.
 int dtf_ps_push(const void* grads, void* dst, void* flags, void* hdr, const void* version, int nr, const long* lo,
                 const long* hi, long n_total, unsigned seq, unsigned kind, hipStream_t s) {
-  if (!ranges_ok(nr, lo, hi, n_total) || seq == 0 || kind < 1 || kind > 3) return -2;
+  if (!ranges_ok(nr, lo, hi, n_total) || seq == 0 || kind < 1 || kind > 5) return -2;
   if (((uintptr_t)grads | (uintptr_t)dst) & 15) return -3;
   PsPushArgs a{(const float*)grads, (float*)dst, (unsigned*)flags, (unsigned*)hdr, (const int64_t*)version,
                make_ranges(nr, lo, hi), seq, kind};
@@ -319,8 +326,8 @@ int dtf_ps_poll(const void* flags, const void* hdr, int W, int NB, int start, co
 
 int dtf_ps_apply_push(int adam, void* w, void* m, void* v, const void* hyper, const void* grad, int nr, const long* lo,
                       const long* hi, long n_total, int apply, double adam_t, void* box_f32, void* box_bf16, long n_dense,
-                      void* box_flags, void* box_hdr, void* full, void* full_flags, unsigned seq, unsigned long long step,
-                      unsigned stop, hipStream_t s) {
+                      void* box_flags, void* box_hdr, void* full, void* full_flags, const void* full_src, unsigned adam_count,
+                      unsigned seq, unsigned long long step, unsigned stop, hipStream_t s) {
   if (!ranges_ok(nr, lo, hi, n_total) || seq == 0 || (n_dense & 3) || n_dense < 0 || n_dense > n_total) return -2;
   if (adam && (!m || !v)) return -3;
   if (apply && !grad) return -3;
@@ -340,6 +347,8 @@ int dtf_ps_apply_push(int adam, void* w, void* m, void* v, const void* hyper, co
   a.box_hdr = (unsigned*)box_hdr;
   a.full = (float*)full;
   a.full_flags = (unsigned*)full_flags;
+  a.full_src = (const float*)full_src;
+  a.adam_count = adam_count;
   a.seq = seq;
   a.step_lo = (unsigned)step;
   a.step_hi = (unsigned)(step >> 32);
@@ -351,8 +360,8 @@ int dtf_ps_apply_push(int adam, void* w, void* m, void* v, const void* hyper, co
 
 int dtf_ps_install(const void* box_flags, const void* box_hdr, const void* box_f32, const void* box_bf16, long n_dense,
                    int nr, const long* lo, const long* hi, long n_total, unsigned seq, void* params, void* shadow,
-                   const void* full, const void* full_flags, void* state, void* version, void* host_hdr, int owner,
-                   int* status, double timeout_s, hipStream_t s) {
+                   const void* full, const void* full_flags, void* full_dst, void* state, void* version, void* host_hdr,
+                   int owner, int* status, double timeout_s, hipStream_t s) {
   if (!ranges_ok(nr, lo, hi, n_total) || seq == 0 || (n_dense & 3)) return -2;
   if (box_bf16 && !shadow) return -3;
   PsInstallArgs a;
@@ -367,6 +376,7 @@ int dtf_ps_install(const void* box_flags, const void* box_hdr, const void* box_f
   a.shadow = (bf16*)shadow;
   a.full = (const float*)full;
   a.full_flags = (const unsigned*)full_flags;
+  a.full_dst = (float*)full_dst;
   a.state = (int64_t*)state;
   a.version = (int64_t*)version;
   a.host_hdr = (unsigned*)host_hdr;

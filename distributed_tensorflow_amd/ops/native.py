@@ -79,9 +79,9 @@ _SIGS = {
     "dtf_ps_poll": [c_void_p, c_void_p, c_int, c_int, c_int, ctypes.POINTER(c_uint), c_void_p, c_double, c_void_p],
     "dtf_ps_apply_push": [c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, ctypes.POINTER(c_long),
                           ctypes.POINTER(c_long), c_long, c_int, c_double, c_void_p, c_void_p, c_long, c_void_p, c_void_p,
-                          c_void_p, c_void_p, c_uint, ctypes.c_ulonglong, c_uint, c_void_p],
+                          c_void_p, c_void_p, c_void_p, c_uint, c_uint, ctypes.c_ulonglong, c_uint, c_void_p],
     "dtf_ps_install": [c_void_p, c_void_p, c_void_p, c_void_p, c_long, c_int, ctypes.POINTER(c_long), ctypes.POINTER(c_long),
-                       c_long, c_uint, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int,
+                       c_long, c_uint, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int,
                        c_void_p, c_double, c_void_p],
     "dtf_p2p_alloc": [c_long, ctypes.POINTER(c_void_p)],
     "dtf_p2p_free": [c_void_p],

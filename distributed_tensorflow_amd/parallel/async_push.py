@@ -15,8 +15,9 @@ plain stores + a system-scope fence + sequence flags.
     without further handshakes (csrc/kernels/ps.hip header);
   * variables are sharded over the ps tasks exactly as ``replica_device_setter`` places them (whole tensors,
     round-robin in creation order; cluster.py), each ps applies and answers for its own ranges;
-  * the fp32 master weights live on the ps.  The chief fetches them with a "master" request before a checkpoint
-    (``prepare_save``), the native form of the Saver reading the variables from the ps (SURVEY X5);
+  * the fp32 master weights -- and Adam's moments and update count -- live on the ps.  The chief fetches them with
+    "master" requests before a checkpoint (``prepare_save``), the native form of the Saver reading the variables from
+    the ps (SURVEY X5), so a restarted job resumes warm: the restored state reaches the ps in the initial broadcast;
   * every applied gradient's staleness (global_step now - global_step of the parameters it was computed with) is
     counted on the ps and logged as a histogram at the end.
 
@@ -37,7 +38,7 @@ from ..cluster import TaskInfo
 from ..ops import native
 from .strategies import broadcast_state, ps_shards
 
-KIND_GRAD, KIND_BYE, KIND_MASTER = 1, 2, 3
+KIND_GRAD, KIND_BYE, KIND_MASTER, KIND_ADAM_M, KIND_ADAM_V = 1, 2, 3, 4, 5
 MAX_STALENESS = 8
 
 
@@ -177,7 +178,7 @@ class AsyncPushWorker:
         dev = eng.device
         self._version = torch.zeros(1, dtype=torch.int64, device=dev)       # global_step of the installed parameters
         self._status = torch.zeros(1, dtype=torch.int32, device=dev)
-        self._hdr = torch.zeros(4, dtype=torch.int32).pin_memory()           # {step lo, step hi, stop, seq} from the owner ps
+        self._hdr = torch.zeros(8, dtype=torch.int32).pin_memory()   # {step lo, hi, stop, seq, Adam updates} from the owner ps
 
     def broadcast_initial(self):
         broadcast_state(self.b, self.chief_rank)
@@ -194,8 +195,9 @@ class AsyncPushWorker:
             native.check(f.lib.dtf_ps_push(eng.grads.data_ptr(), data, flags, hdr, self._version.data_ptr(), nr, lo, hi,
                                            f.n_total, n, kind, s), "ps_push")
 
-    def _install(self, r: int, master: bool = False):
-        """Wait for the answer to message r (bounded, on the GPU) and copy it into the arenas."""
+    def _install(self, r: int, master: bool = False, master_dst: Optional[torch.Tensor] = None):
+        """Wait for the answer to message r (bounded, on the GPU) and copy it into the arenas.  ``master``: the answer
+        also carries an fp32 arena in the box's "full" area -- the master weights, or Adam's m / v into ``master_dst``."""
         f, eng, L = self.fab, self.fab.eng, self.fab.L
         s = torch.cuda.current_stream(eng.device).cuda_stream
         own = f.bases[self.task.rank]
@@ -206,7 +208,8 @@ class AsyncPushWorker:
             nr, lo, hi = f.carr(p)
             native.check(f.lib.dtf_ps_install(flags, hdr, f32, b16 if bf16 else None, f.n_dense, nr, lo, hi, f.n_total, r,
                                               eng.params.data_ptr(), eng.shadow.data_ptr() if bf16 else None, full,
-                                              full_flags, eng.state.data_ptr(), self._version.data_ptr(),
+                                              full_flags, master_dst.data_ptr() if master_dst is not None else None,
+                                              eng.state.data_ptr(), self._version.data_ptr(),
                                               self._hdr.data_ptr(), int(p == f.step_owner), self._status.data_ptr(),
                                               self.timeout_s, s), "ps_install")
         # derived copies of the (small) tail only: bf16 copy, conv2 fragment packs, transposed output weight
@@ -250,11 +253,18 @@ class AsyncPushWorker:
         if self._closed:           # after finish(): the master is already here and the ps tasks have been told goodbye
             return
         self._catch_up(self.seq)
-        n = self.seq + 1
-        self._push(n, KIND_MASTER)
-        self.seq = n
-        self._install(n, master=True)
+        eng = self.fab.eng
+        requests = [(KIND_MASTER, None)]
+        if eng.optimizer == "adam":        # the moments live on the ps too: without them a restart would resume cold
+            requests += [(KIND_ADAM_M, eng.adam_m), (KIND_ADAM_V, eng.adam_v)]
+        for kind, dst in requests:
+            n = self.seq + 1
+            self._push(n, kind)
+            self.seq = n
+            self._install(n, master=True, master_dst=dst)
         self._read_header(sync=True)
+        if eng.optimizer == "adam":
+            self.b.set_adam_t(int(self._hdr[4]) & 0xFFFFFFFF)
 
     def finish(self):
         self._catch_up(self.seq)
@@ -334,12 +344,14 @@ class AsyncPushServer:
                 if nr:
                     _, _, data = L.mb(own, w, n % NB)
                     bflags, bhdr, b32, b16 = L.bx(f.bases[wr[w]], p, n % NB)
-                    full, full_flags = L.bx_master(f.bases[wr[w]], p) if kind == KIND_MASTER else (None, None)
+                    full, full_flags = L.bx_master(f.bases[wr[w]], p) if kind >= KIND_MASTER else (None, None)
+                    full_src = {KIND_ADAM_M: eng.adam_m, KIND_ADAM_V: eng.adam_v}.get(kind) if adam else None
                     native.check(f.lib.dtf_ps_apply_push(
                         int(adam), eng.params.data_ptr(), eng.adam_m.data_ptr() if adam else None,
                         eng.adam_v.data_ptr() if adam else None, eng.hyper.data_ptr(), data, nr, lo, hi, f.n_total,
                         int(apply), float(adam_t0 + self.applied), b32, b16 if bf16 else None, f.n_dense, bflags, bhdr,
-                        full, full_flags, n, step, int(step >= self.training_iter), s), "ps_apply_push")
+                        full, full_flags, full_src.data_ptr() if full_src is not None else None, adam_t0 + self.applied,
+                        n, step, int(step >= self.training_iter), s), "ps_apply_push")
                 expect[w] = n + 1
             start = (start + 1) % W
         stream.synchronize()

@@ -211,12 +211,13 @@ def run(F, log=print) -> dict:
     else:
         strategy = AsyncRounds(backend, task, chief_rank, staleness=staleness, optimizer=F.optimizer)
 
-    if mode == "async" and F.optimizer == "adam" and task.is_chief:
+    if mode == "async" and F.optimizer == "adam" and task.is_chief and async_impl != "push":
         log("note: in asynchronous mode the Adam moments live on the ps tasks and are not part of the chief's "
             "checkpoints; a restarted job resumes the weights and global_step with fresh moments")
     sv = Supervisor(backend, is_chief=task.is_chief, logdir=F.logdir or None, save_model_secs=F.save_model_secs,
                     saver=Saver(write_version=getattr(F, "saver_write_version", 2)), init_seed=F.seed, log=log,
-                    save_optimizer_state=(mode != "async"))
+                    # asynchronous modes: the moments live on the ps; only the push path fetches them for checkpoints
+                    save_optimizer_state=(mode != "async" or async_impl == "push"))
     health = getattr(strategy, "check_health", None)
     sv.pre_save_check = health       # never checkpoint parameters that a timed-out peer-to-peer sum may have touched
     _install_signal_handlers(sv, log, task)

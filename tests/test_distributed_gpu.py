@@ -113,6 +113,35 @@ def test_async_push_parameter_server(gpu_lib, tmp_path, n_ps, optimizer, stalene
     assert np.any(wd1 & 0xFFFF), "checkpointed wd1 looks like a bf16 copy"
 
 
+def test_async_push_adam_checkpoint_carries_the_ps_moments_and_resumes(gpu_lib, tmp_path):
+    """The Adam moments of an asynchronous job live on the ps.  In push mode the chief fetches them (and the update
+    count) with the master weights, so its checkpoint is complete and a restarted job resumes warm: the restored
+    moments reach the ps through the initial broadcast and the ps continues the update count."""
+    import math
+    import re
+    import numpy as np
+    from distributed_tensorflow_amd.checkpoint import read_bundle
+    logdir = str(tmp_path / "logs")
+    args = ["--mode=async", "--async_impl=push", "--staleness=0", "--batch_size=64", "--optimizer=adam",
+            "--learning_rate=0.001"] + [a for a in COMMON if not a.startswith("--learning_rate")]
+    out = launch(1, 2, args + ["--steps=30"], logdir, backend="hip")
+    _ok(out)
+    ck = read_bundle(os.path.join(logdir, "model.ckpt-30"))
+    m, v = ck["Variable_2/Adam"], ck["Variable_2/Adam_1"]
+    assert np.abs(m).max() > 0 and v.min() >= 0 and v.max() > 0          # the ps's moments, not the chief's zeros
+    t = round(math.log(float(ck["beta1_power"])) / math.log(0.9)) - 1
+    assert t == 30, t                                                     # 30 applied updates
+    out = launch(1, 2, args + ["--steps=50"], logdir, backend="hip")
+    _ok(out)
+    assert "Restored from checkpoint" in out[("worker", 0)][1]
+    mm = re.search(r"applied (\d+) gradients", out[("ps", 0)][1])
+    assert mm and int(mm.group(1)) == 20, out[("ps", 0)][1][-1500:]
+    ck2 = read_bundle(os.path.join(logdir, "model.ckpt-50"))
+    t2 = round(math.log(float(ck2["beta1_power"])) / math.log(0.9)) - 1
+    assert t2 == 50, t2                                                   # the count went on from 30, not from 0
+    assert not np.array_equal(ck2["Variable_2/Adam_1"], v)
+
+
 @pytest.mark.parametrize("optimizer,dtype", [("sgd", "bf16"), ("adam", "bf16"), ("sgd", "fp32")])
 def test_async_push_single_worker_equals_local_training(gpu_lib, optimizer, dtype):
     """One worker, staleness 0: the asynchronous parameter server IS sequential training.  The worker replays every
