@@ -173,3 +173,67 @@ def test_f32_sync_dp_world1_matches_plain_engine(gpu_lib, dataset):
         assert a.global_step == b.global_step == 5
     finally:
         dist.destroy_process_group()
+
+
+def test_f32_gradients_match_finite_differences(gpu_lib, dataset):
+    """SURVEY §4 "unit - gradients": central differences of the ENGINE's own loss (its forward kernels, evaluation mode)
+    against the ENGINE's gradient, a few coordinates per tensor.  Only meaningful in the exact-fp32 configuration: the
+    loss is evaluated in fp32, so the step is large (1e-2 relative to the tensor's scale) and the tolerance 5 %."""
+    from distributed_tensorflow_amd.engine import HipEngine
+    spec, B = ModelSpec(), 32
+    eng = HipEngine(spec, B, dataset, optimizer="sgd", learning_rate=0.0, seed=5, dtype="fp32")   # lr 0: the step leaves w alone
+    eng.init_params(seed=9)
+    idx = torch.as_tensor(batch_indices(0, B, dataset.n, 5), device="cuda")
+    x, y = dataset.images[idx].contiguous(), dataset.labels[idx].contiguous()
+    eng.launch_train_step()
+    torch.cuda.synchronize()
+    g = {n: t.double() for n, t in eng.export_grads().items()}
+    p0 = eng.params.clone()
+    gen = torch.Generator().manual_seed(3)
+    checked = 0
+    for name in eng.layout.names():
+        flat = g[name].reshape(-1)
+        # the coordinates with the largest gradients: differences of an fp32 loss are noise for tiny ones
+        top = torch.topk(flat.abs(), k=min(3, flat.numel())).indices.tolist()
+        for j in top:
+            off = eng.layout.offsets[name] + j
+            h = 1e-2 * max(1.0, float(p0[off].abs()))
+            vals = []
+            for sgn in (+1.0, -1.0):
+                eng.params.copy_(p0)
+                eng.params[off] += sgn * h
+                eng.refresh_shadows()
+                vals.append(eng.evaluate(x, y)[0])
+            fd = (vals[0] - vals[1]) / (2 * h)
+            an = float(flat[j])
+            assert abs(fd - an) <= 5e-2 * abs(an) + 1e-4, (name, j, fd, an)
+            checked += 1
+    eng.params.copy_(p0)
+    assert checked >= 20
+
+
+def test_f32_and_bf16_steps_are_race_free_across_repeats(gpu_lib, dataset):
+    """Race screen for the split-K / slab hand-offs: the same step from the same state, 25 times, must
+    give bitwise identical gradients, parameters and metrics in both kernel sets (no float atomics anywhere, so any
+    difference is a race)."""
+    from distributed_tensorflow_amd.engine import DeviceDataset, HipEngine
+    for dtype in ("fp32", "bf16"):
+        ds = dataset if dtype == "fp32" else DeviceDataset.synthetic(4096, seed=1234)
+        eng = HipEngine(ModelSpec(), 192, ds, optimizer="adam", learning_rate=1e-3, keep_prob=0.5, seed=7, dtype=dtype)
+        eng.init_params(seed=2)
+        for _ in range(3):
+            eng.train_step()
+        torch.cuda.synchronize()
+        snap = [t.clone() for t in (eng.params, eng.state, eng.adam_m, eng.adam_v)]
+        ref = None
+        for rep in range(25):
+            for t, s0 in zip((eng.params, eng.state, eng.adam_m, eng.adam_v), snap):
+                t.copy_(s0)
+            eng.refresh_shadows()
+            eng.train_step()
+            torch.cuda.synchronize()
+            cur = (eng.grads.clone(), eng.params.clone(), eng.last_metrics())
+            if ref is None:
+                ref = cur
+            else:
+                assert torch.equal(cur[0], ref[0]) and torch.equal(cur[1], ref[1]) and cur[2] == ref[2], (dtype, rep)
