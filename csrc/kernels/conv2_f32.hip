@@ -24,6 +24,7 @@
 //   B read (dY, shared by its 13 taps) and 13 A reads (X at 13 shifted positions), all conflict-free
 //   ds_read_b32, for 13 MFMAs (832 cycles).  The next image's global loads are in flight during the k-loop.
 //   Split-K over images into per-workgroup slabs, summed in fixed order by reduce_segments / the fused tail.
+#include <cstdlib>
 #include <type_traits>
 
 #include "f32_common.hpp"
@@ -41,11 +42,14 @@ enum { F32_MODE_FWD = 0, F32_MODE_DGRAD = 1 };
 //   in   FWD  : x     [B,14,14,KTOT] fp32          DGRAD: gpool [B,7,7,KTOT] fp32 + in_arg [B,7,7,KTOT] u8
 //   wk   fragment-ordered pack for this direction (see pack_conv2_weights_f32)
 //   out  FWD  : pooled [B,7,7,NCTOT] fp32 + out_arg u8      DGRAD: dx [B,14,14,NCTOT] fp32
-// grid = (B, NCTOT / NCW)
+// grid = (B, NCTOT / NCW, ceil(13 / MT)): MT = M tiles per workgroup.  13 is the whole image; a small batch (fewer
+// workgroups than CUs: the reference's batch 100) cuts the image into 2 or 3 M ranges (MT = 7 / 5), each workgroup
+// staging the same input tile and running its share of the MFMAs -- the kernel is bound by the per-SIMD matrix pipe,
+// so what matters is how many SIMDs work, not how much is staged twice.
 // ----------------------------------------------------------------------------------------------------
 constexpr int kF32RedBytes = 2 * 13 * 64 * 16;   // dgrad: the K-half partner's 13 accumulator tiles per n tile
 
-template <int KTOT, int NCTOT, int MODE>
+template <int KTOT, int NCTOT, int MODE, int MT>
 __global__ __launch_bounds__(256, 2) void conv5x5_igemm_f32(const float* __restrict__ in, const uint8_t* __restrict__ in_arg,
                                                          const float* __restrict__ wk, const float* __restrict__ bias,
                                                          float* __restrict__ out, uint8_t* __restrict__ out_arg, int B) {
@@ -60,14 +64,15 @@ __global__ __launch_bounds__(256, 2) void conv5x5_igemm_f32(const float* __restr
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int ntile = wave % NTN, ksp = wave / NTN;
   const int ng = blockIdx.y;
+  const int t0 = blockIdx.z * MT;   // first M tile of this workgroup
   const int l16 = lane & 15, g = lane >> 4;
 
   // A row of this lane in M tile t: window 4t + (l16 >> 2), position q = l16 & 3 (windows past 48 are clamped
   // and their results discarded)
-  int aoff[13];
+  int aoff[MT];
 #pragma unroll
-  for (int t = 0; t < 13; ++t) {
-    const int wI = min(4 * t + (l16 >> 2), 48), q = l16 & 3;
+  for (int t = 0; t < MT; ++t) {
+    const int wI = min(4 * (t0 + t) + (l16 >> 2), 48), q = l16 & 3;
     const int pos = (2 * (wI / 7) + (q >> 1)) * kF32TileW + 2 * (wI % 7) + (q & 1);
     aoff[t] = pos * kF32Pitch + 4 * g;
   }
@@ -117,9 +122,9 @@ __global__ __launch_bounds__(256, 2) void conv5x5_igemm_f32(const float* __restr
   if (b < B) issue_loads(b, 0);
 #pragma unroll 1
   for (; b < B; b += gridDim.x) {
-    f32x4 acc[13];
+    f32x4 acc[MT];
 #pragma unroll
-    for (int t = 0; t < 13; ++t) acc[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    for (int t = 0; t < MT; ++t) acc[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
 #pragma unroll 1
     for (int kc0 = 0; kc0 < KTOT; kc0 += KC) {
@@ -145,13 +150,13 @@ __global__ __launch_bounds__(256, 2) void conv5x5_igemm_f32(const float* __restr
       auto do_step = [&](int s, const f32x4& bf) {
         const int tap = step_tap(s), kb = step_kb(s);
         const float* ap = tile + ((tap / 5) * kF32TileW + tap % 5) * kF32Pitch + kb * 16;
-        f32x4 a[13];
+        f32x4 a[MT];
 #pragma unroll
-        for (int t = 0; t < 13; ++t) a[t] = *reinterpret_cast<const f32x4*>(ap + aoff[t]);
+        for (int t = 0; t < MT; ++t) a[t] = *reinterpret_cast<const f32x4*>(ap + aoff[t]);
 #pragma unroll
         for (int e = 0; e < 4; ++e)
 #pragma unroll
-          for (int t = 0; t < 13; ++t) acc[t] = mfma16f(a[t][e], bf[e], acc[t]);
+          for (int t = 0; t < MT; ++t) acc[t] = mfma16f(a[t][e], bf[e], acc[t]);
       };
       // B fragment of step s+1 requested before the MFMAs of step s; unconditional (the last step re-loads itself)
       f32x4 b0 = load_b(0), b1;
@@ -172,13 +177,13 @@ __global__ __launch_bounds__(256, 2) void conv5x5_igemm_f32(const float* __restr
       f32x4* red = reinterpret_cast<f32x4*>(reinterpret_cast<char*>(tile) + kF32TileBytes);   // [ntile][13][64 lanes]
       if (ksp == 1) {
 #pragma unroll
-        for (int t = 0; t < 13; ++t) red[(ntile * 13 + t) * 64 + lane] = acc[t];
+        for (int t = 0; t < MT; ++t) red[(ntile * MT + t) * 64 + lane] = acc[t];
       }
       __syncthreads();
       // every wave adds (branch-free: a conditional update of the accumulators costs a second register copy of
       // them); only the ksp == 0 wave of a pair stores its result
 #pragma unroll
-      for (int t = 0; t < 13; ++t) acc[t] += red[(ntile * 13 + t) * 64 + lane];
+      for (int t = 0; t < MT; ++t) acc[t] += red[(ntile * MT + t) * 64 + lane];
     }
 
     // ---- epilogue.  C/D map: lane holds rows 4g + r -> window 4t + g, q = r; column l16 ----
@@ -190,8 +195,8 @@ __global__ __launch_bounds__(256, 2) void conv5x5_igemm_f32(const float* __restr
     if (MODE == F32_MODE_FWD) {
       const float bv = bias[n];
 #pragma unroll
-      for (int t = 0; t < 13; ++t) {
-        const int wI = 4 * t + ge;
+      for (int t = 0; t < MT; ++t) {
+        const int wI = 4 * (t0 + t) + ge;
         if (wI < 49) {
           const f32x4 v = acc[t];
           float best = v[0];
@@ -207,8 +212,8 @@ __global__ __launch_bounds__(256, 2) void conv5x5_igemm_f32(const float* __restr
       }
     } else if (ksp == 0) {
 #pragma unroll
-      for (int t = 0; t < 13; ++t) {
-        const int wI = 4 * t + ge;
+      for (int t = 0; t < MT; ++t) {
+        const int wI = 4 * (t0 + t) + ge;
         if (wI < 49) {
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
@@ -248,7 +253,9 @@ __global__ __launch_bounds__(256) void pack_conv2_weights_f32(const float* __res
 }
 
 // ----------------------------------------------------------------------------------------------------
-// wgrad.  grid = (G image ranges, (CIN/32) * (COUT/64) channel tiles)
+// wgrad.  grid = (G image ranges, (CIN/32) * (COUT/64) channel tiles, ceil(13 / NJ) tap ranges)
+//   NJ = taps per wave: 13 (all of the wave's taps) or 7 -- the small-batch launch, where G alone leaves CUs idle:
+//   two workgroups stage the same image range and each runs half of the taps into the same slab.
 //   x [B,14,14,CIN] fp32, gpool [B,7,7,COUT] fp32, arg [B,7,7,COUT] u8
 //   part [G][25*CIN*COUT + COUT] fp32 slabs (HWIO order, then the bias gradient)
 // ----------------------------------------------------------------------------------------------------
@@ -256,7 +263,7 @@ constexpr int kWgfXFloats = kF32TilePos * 32;   // zero-haloed input tile [324][
 constexpr int kWgfDyFloats = 196 * 64;          // max-pool/ReLU-expanded output gradient [196][64 co]
 constexpr int kWgfBytes = (kWgfXFloats + kWgfDyFloats) * 4;   // 91648
 
-template <int CIN, int COUT>
+template <int CIN, int COUT, int NJ>
 __global__ __launch_bounds__(256, 1) void conv5x5_wgrad_f32(const float* __restrict__ x, const float* __restrict__ gpool,
                                                             const uint8_t* __restrict__ arg, float* __restrict__ part,
                                                             int B, int imgs_per_block) {
@@ -269,9 +276,9 @@ __global__ __launch_bounds__(256, 1) void conv5x5_wgrad_f32(const float* __restr
   const int i32 = lane & 31, h = lane >> 5;
   const int b_begin = blockIdx.x * imgs_per_block, b_end = min(B, b_begin + imgs_per_block);
 
-  f32x16 acc[13];
+  f32x16 acc[NJ];
 #pragma unroll
-  for (int t = 0; t < 13; ++t)
+  for (int t = 0; t < NJ; ++t)
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
   f32x4 bsum = {0.f, 0.f, 0.f, 0.f};   // bias gradient of channels 4*(tid & 15) .. +3 over this thread's staging items
@@ -334,24 +341,24 @@ __global__ __launch_bounds__(256, 1) void conv5x5_wgrad_f32(const float* __restr
   // one position pair (two k) per MFMA: lane half h takes position 2*xj + h of row y.  Two fragment sets: the 14
   // LDS reads of pair xj+1 are issued before the 13 MFMAs of pair xj (one wave per SIMD: nothing else hides them).
   auto kloop = [&](auto TP) {
-    constexpr int tp_ = decltype(TP)::value;
-    auto load = [&](const float* pa, const float* pb, int xj, float (&av)[13], float& bv) {
+    constexpr int tp_ = decltype(TP)::value;   // first tap of this wave in this workgroup; the others follow in twos
+    auto load = [&](const float* pa, const float* pb, int xj, float (&av)[NJ], float& bv) {
       bv = pb[2 * xj * 64];
 #pragma unroll
-      for (int j = 0; j < 13; ++j) {
-        const int tap = (tp_ + 2 * j) < 25 ? (tp_ + 2 * j) : 23;   // the 13th tap of the odd group is a discarded repeat
+      for (int j = 0; j < NJ; ++j) {
+        const int tap = (tp_ + 2 * j) < 25 ? (tp_ + 2 * j) : 23;   // taps past the 25th are discarded repeats
         av[j] = pa[(2 * xj + (tap / 5) * kF32TileW + tap % 5) * 32];
       }
     };
-    auto mma = [&](const float (&av)[13], float bv) {
+    auto mma = [&](const float (&av)[NJ], float bv) {
 #pragma unroll
-      for (int j = 0; j < 13; ++j) acc[j] = mfma32f(av[j], bv, acc[j]);
+      for (int j = 0; j < NJ; ++j) acc[j] = mfma32f(av[j], bv, acc[j]);
     };
 #pragma unroll 1
     for (int y = 0; y < 14; ++y) {
       const float* pa = xt + (y * kF32TileW + h) * 32 + i32;
       const float* pb = dyt + (y * 14 + h) * 64 + cohalf * 32 + i32;
-      float a0[13], a1[13], b0, b1;
+      float a0[NJ], a1[NJ], b0, b1;
       load(pa, pb, 0, a0, b0);
 #pragma unroll
       for (int xj = 0; xj < 6; xj += 2) {
@@ -385,7 +392,7 @@ __global__ __launch_bounds__(256, 1) void conv5x5_wgrad_f32(const float* __restr
     }
     // ---- slab: dW rows ci = (r & 3) + 8 * (r >> 2) + 4 * h, column co = i32 of this wave's half ----
 #pragma unroll
-    for (int j = 0; j < 13; ++j) {
+    for (int j = 0; j < NJ; ++j) {
       const int tap = tp_ + 2 * j;
       if (tap < 25) {
 #pragma unroll
@@ -396,14 +403,21 @@ __global__ __launch_bounds__(256, 1) void conv5x5_wgrad_f32(const float* __restr
       }
     }
   };
-  if (tpar == 0) body(std::integral_constant<int, 0>{});
-  else body(std::integral_constant<int, 1>{});
+  // (first tap = tap parity + 2 * NJ * tap range: a compile-time constant per instantiation, so the tap offsets stay
+  // immediates of the LDS reads)
+  if (NJ == 13 || blockIdx.z == 0) {
+    if (tpar == 0) body(std::integral_constant<int, 0>{});
+    else body(std::integral_constant<int, 1>{});
+  } else {
+    if (tpar == 0) body(std::integral_constant<int, 2 * (NJ % 13)>{});
+    else body(std::integral_constant<int, 2 * (NJ % 13) + 1>{});
+  }
   // bias gradient: thread t holds channels 4 * (t & 15) .. +3; fixed-order sum of the 16 threads per chunk
   __syncthreads();
   f32x4* red = reinterpret_cast<f32x4*>(wsm);
   red[tid] = bsum;
   __syncthreads();
-  if (cic == 0 && tid < 64) {
+  if (cic == 0 && blockIdx.z == 0 && tid < 64) {
     float s = 0.f;
 #pragma unroll
     for (int k = 0; k < 16; ++k) s += red[k * 16 + (tid >> 2)][tid & 3];
@@ -426,10 +440,10 @@ static int f32_cu_count() {
   return cus;
 }
 
-template <int KTOT, int NCTOT, int MODE>
-static int launch_igemm_f32(const void* in, const void* in_arg, const void* wk, const void* bias, void* out, void* out_arg,
-                            int B, hipStream_t s) {
-  auto kern = conv5x5_igemm_f32<KTOT, NCTOT, MODE>;
+template <int KTOT, int NCTOT, int MODE, int MT>
+static int launch_igemm_f32_mt(const void* in, const void* in_arg, const void* wk, const void* bias, void* out,
+                               void* out_arg, int B, hipStream_t s) {
+  auto kern = conv5x5_igemm_f32<KTOT, NCTOT, MODE, MT>;
   // 80 KiB per workgroup = exactly two per CU (the dgrad reduction area fits in the slack): the grid is persistent,
   // two workgroups per CU walking the batch, so there is no partial last round of workgroups
   constexpr int lds = 80 * 1024;
@@ -443,23 +457,54 @@ static int launch_igemm_f32(const void* in, const void* in_arg, const void* wk, 
   constexpr int groups = NCTOT / NCW;
   int gx = (2 * f32_cu_count() + groups - 1) / groups;
   if (gx > B) gx = B;
-  hipLaunchKernelGGL(kern, dim3(gx, groups), dim3(256), lds, s, (const float*)in, (const uint8_t*)in_arg,
-                     (const float*)wk, (const float*)bias, (float*)out, (uint8_t*)out_arg, B);
+  hipLaunchKernelGGL(kern, dim3(gx, groups, (13 + MT - 1) / MT), dim3(256), lds, s, (const float*)in,
+                     (const uint8_t*)in_arg, (const float*)wk, (const float*)bias, (float*)out, (uint8_t*)out_arg, B);
   return (int)hipGetLastError();
 }
 
-template <int CIN, int COUT>
-static int launch_wgrad_f32(const void* x, const void* gpool, const void* arg, void* part, int B, int G, hipStream_t s) {
-  auto kern = conv5x5_wgrad_f32<CIN, COUT>;
+// M ranges per image: as many (up to 3) as keep the launch at one workgroup per CU.  More would put two workgroups'
+// waves on the same SIMDs, whose matrix pipe is what bounds this kernel.  DTF_F32_MSPLIT=1|2|3 overrides (tools).
+static int f32_msplit(int wgs) {
+  static int forced = -1;
+  if (forced < 0) {
+    const char* v = getenv("DTF_F32_MSPLIT");
+    forced = v ? atoi(v) : 0;
+  }
+  if (forced >= 1 && forced <= 3) return forced;
+  const int cus = f32_cu_count();
+  return 3 * wgs <= cus ? 3 : (2 * wgs <= cus ? 2 : 1);
+}
+
+template <int KTOT, int NCTOT, int MODE>
+static int launch_igemm_f32(const void* in, const void* in_arg, const void* wk, const void* bias, void* out, void* out_arg,
+                            int B, hipStream_t s) {
+  constexpr int groups = NCTOT / ((MODE == F32_MODE_FWD) ? 64 : 32);
+  switch (f32_msplit(B * groups)) {
+    case 3: return launch_igemm_f32_mt<KTOT, NCTOT, MODE, 5>(in, in_arg, wk, bias, out, out_arg, B, s);
+    case 2: return launch_igemm_f32_mt<KTOT, NCTOT, MODE, 7>(in, in_arg, wk, bias, out, out_arg, B, s);
+    default: return launch_igemm_f32_mt<KTOT, NCTOT, MODE, 13>(in, in_arg, wk, bias, out, out_arg, B, s);
+  }
+}
+
+template <int CIN, int COUT, int NJ>
+static int launch_wgrad_f32_nj(const void* x, const void* gpool, const void* arg, void* part, int B, int G, hipStream_t s) {
+  auto kern = conv5x5_wgrad_f32<CIN, COUT, NJ>;
   static bool attr_set = false;
   if (!attr_set) {
     (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, kWgfBytes);
     attr_set = true;
   }
   const int ipb = (B + G - 1) / G;
-  hipLaunchKernelGGL(kern, dim3(G, (CIN / 32) * (COUT / 64)), dim3(256), kWgfBytes, s, (const float*)x, (const float*)gpool,
-                     (const uint8_t*)arg, (float*)part, B, ipb);
+  hipLaunchKernelGGL(kern, dim3(G, (CIN / 32) * (COUT / 64), (13 + NJ - 1) / NJ), dim3(256), kWgfBytes, s, (const float*)x,
+                     (const float*)gpool, (const uint8_t*)arg, (float*)part, B, ipb);
   return (int)hipGetLastError();
+}
+
+template <int CIN, int COUT>
+static int launch_wgrad_f32(const void* x, const void* gpool, const void* arg, void* part, int B, int G, hipStream_t s) {
+  // two tap ranges when that still leaves one workgroup per CU (see f32_msplit)
+  if (f32_msplit(G * (CIN / 32) * (COUT / 64)) >= 2) return launch_wgrad_f32_nj<CIN, COUT, 7>(x, gpool, arg, part, B, G, s);
+  return launch_wgrad_f32_nj<CIN, COUT, 13>(x, gpool, arg, part, B, G, s);
 }
 
 extern "C" {

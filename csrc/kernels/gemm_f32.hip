@@ -18,6 +18,10 @@
 #include "f32_common.hpp"
 #include <hip/hip_ext.h>
 
+// csrc/kernels/optim.hip: sums part[G][stride] slabs into out (the split-K dgrad below reuses it)
+extern "C" int dtf_reduce_segments(int count, const void** part, void** out, const int* G, const int* n, const long* stride,
+                                   hipStream_t s);
+
 namespace dtf {
 
 enum { F32_KCONTIG = 0, F32_KSLOW = 1 };
@@ -210,6 +214,7 @@ int dtf_gemm_f32_nn_partial(const void* A, const void* B, void* part, int M, int
     S = (256 + tiles - 1) / tiles;
     if (S > 8) S = 8;
   }
+  if (S > 32) S = 32;
   if (S > T) S = T;
   const int tps = (T + S - 1) / S;
   S = (T + tps - 1) / tps;
@@ -221,6 +226,26 @@ int dtf_gemm_f32_nn_partial(const void* A, const void* B, void* part, int M, int
 int dtf_gemm_f32_nt(const void* A, const void* B, void* C, int M, int N, int K, int lda, int ldb, int ldc, hipStream_t s) {
   if ((K & 31) || (lda & 3) || (ldb & 3)) return -3;
   return launch_gemm_f32<F32_KCONTIG, F32_KCONTIG, F32_EPI_STORE>(A, B, C, M, N, K, lda, ldb, ldc, 1, K / 32, nullptr, s);
+}
+
+// The same product for a small batch: M / 128 * N / 128 output tiles do not fill 256 CUs (batch 100: 25 workgroups,
+// each walking all of K -> 66 us measured), so K is cut into S ranges whose partial products go to part[S][M][N] and
+// are summed into C (dense, ldc == N) by the slab-reduction kernel.  S <= 1 or part == NULL: the plain launch.
+int dtf_gemm_f32_nt_splitk(const void* A, const void* B, void* part, void* C, int M, int N, int K, int lda, int ldb,
+                           int ldc, int S, hipStream_t s) {
+  if (S <= 1 || !part) return dtf_gemm_f32_nt(A, B, C, M, N, K, lda, ldb, ldc, s);
+  if ((K & 31) || (lda & 3) || (ldb & 3) || ldc != N || (long)M * N > 0x7fffffffL) return -3;
+  const int T = K / 32;
+  if (S > T) S = T;
+  const int tps = (T + S - 1) / S;
+  S = (T + tps - 1) / tps;
+  int rc = launch_gemm_f32<F32_KCONTIG, F32_KCONTIG, F32_EPI_STORE>(A, B, part, M, N, K, lda, ldb, N, S, tps, nullptr, s);
+  if (rc != 0) return rc;
+  const void* parts[1] = {part};
+  void* outs[1] = {C};
+  int G[1] = {S}, n[1] = {M * N};
+  long st[1] = {(long)M * N};
+  return dtf_reduce_segments(1, parts, outs, G, n, st, s);
 }
 
 // C[M,N] = A[K,M]^T . B[K,N]  (fc1 wgrad: A = flat, B = dh1, K = batch); hyper != NULL: C is the fp32 weight and the

@@ -14,6 +14,8 @@ struct DtfEngineDesc {
   // model / batch
   int B, c1, c2, hidden, flat, classes;
   int head_ks, c2_g, c1_g, optimizer /*0 sgd, 1 adam*/, shuffle, multi_stream;
+  int fc1_splits;    // split-K factor the partial-product buffer fc1_part was sized for (B rows each)
+  int dgrad_splits;  // fp32 fc1 dgrad at a small batch: K ranges summed from dgrad_part (1: plain GEMM)
   unsigned ds_n, ds_hb, sample_seed, fuse_dense_update;  // last: fc1 SGD update inside its wgrad GEMM (1 GPU)
   uint64_t seed;
   float keep_prob;
@@ -24,7 +26,7 @@ struct DtfEngineDesc {
   // device buffers
   void *params, *grads, *shadow, *fc1_part, *wc2T, *adam_m, *adam_v, *state, *hyper;
   void *idx, *p1, *arg1, *p2, *arg2, *h1, *logits, *loss_rows, *correct_rows, *dlogits, *da, *dflat, *dp1;
-  void *head_part, *c2_part, *c1_part;
+  void *head_part, *c2_part, *c1_part, *dgrad_part;
   void* out_wT;  // fp32 [classes][hidden]: transposed output weight for the head kernel
   void *ds_images, *ds_labels;
   // native-owned handles (filled by dtf_engine_init)
@@ -126,16 +128,19 @@ int dtf_engine_forward_conv(const DtfEngineDesc* e, const void* images, const vo
 }
 
 // Split-K factor of the fc1 forward GEMM for n rows.  The partial-product buffer (engine.py fc1_part) holds
-// auto_splits(B) * B rows; a ragged evaluation chunk n < B has fewer tiles and would by itself pick MORE splits than
+// fc1_splits * B rows; a ragged evaluation chunk n < B has fewer tiles and would by itself pick MORE splits than
 // fit there (e.g. hidden 4096, B = 1024: one split; n = 784: two splits of 784 rows), so the choice is capped.
-static int auto_splits(int M, int N) {
+// The fp32 kernels take up to 32 splits (batch 100: 8 output tiles of 128 x 128, 98 K tiles -> 8 x 25 workgroups
+// instead of 8 x 8; the bf16 GEMM keeps the 8 it was tuned with).
+static int auto_splits(const DtfEngineDesc* e, int M, int N) {
   const int tiles = ((M + 127) / 128) * ((N + 127) / 128);
   const int S = (256 + tiles - 1) / tiles;
-  return S > 8 ? 8 : S;
+  const int cap = is_f32(e) ? 32 : 8;
+  return S > cap ? cap : S;
 }
 static int fc1_splits_for(const DtfEngineDesc* e, int n) {
-  const long cap_rows = (long)auto_splits(e->B, e->hidden) * e->B;
-  int S = auto_splits(n, e->hidden);
+  const long cap_rows = (long)e->fc1_splits * e->B;
+  int S = auto_splits(e, n, e->hidden);
   while (S > 1 && (long)S * n > cap_rows) --S;
   return S;
 }
@@ -206,8 +211,8 @@ int dtf_engine_backward_dense(const DtfEngineDesc* e, hipStream_t s) { return ba
 static int fc1_dgrad(const DtfEngineDesc* e, int head_w, hipStream_t s) {
   if (is_f32(e)) {
     if (head_w) DTF_TRY(dtf_head_f32_wgrad(e->h1, e->dlogits, e->da, e->head_part, e->B, e->hidden, e->head_ks, s));
-    return dtf_gemm_f32_nt(e->da, f32at(e->params, e->off_wd1), e->dflat, e->B, e->flat, e->hidden, e->hidden, e->hidden,
-                           e->flat, s);
+    return dtf_gemm_f32_nt_splitk(e->da, f32at(e->params, e->off_wd1), e->dgrad_part, e->dflat, e->B, e->flat, e->hidden,
+                                  e->hidden, e->hidden, e->flat, e->dgrad_splits, s);
   }
   if (head_w)   // + the output-layer weight gradient as extra workgroups of the same launch
     return dtf_gemm_nt_head_wgrad(e->da, bf16at(e->shadow, e->off_wd1), e->dflat, e->B, e->flat, e->hidden, e->hidden,

@@ -154,8 +154,18 @@ class HipEngine:
         self.arg2 = torch.empty((B, 7, 7, C2), **u8)
         self.h1 = torch.empty((B, H), **act)
         tiles = ((B + 127) // 128) * ((H + 127) // 128)
-        self.fc1_splits = max(1, min(8, -(-256 // tiles)))       # mirrors dtf_gemm_nn_fwd's choice
+        # split-K of the fc1 forward GEMM (csrc/runtime/engine.hip auto_splits: ~256 workgroups; the fp32 kernels go to
+        # 32 splits, which is what fills the chip at the reference's batch 100)
+        self.fc1_splits = max(1, min(32 if dtype == "fp32" else 8, -(-256 // tiles)))
         self.fc1_part = torch.empty((self.fc1_splits, B, H), **f32)
+        # fp32 fc1 dgrad at a small batch: ceil(B / 128) * ceil(FLAT / 128) output tiles do not fill 256 CUs (batch
+        # 100: 25) -> split-K partial products, summed by the slab-reduction kernel.  (The bf16 dgrad uses 64-row
+        # tiles and H / 32 = 32 K steps; it is not K-bound the same way.)
+        d_tiles = ((B + 127) // 128) * ((FLAT + 127) // 128)
+        self.dgrad_splits = max(1, min(8, H // 128, 256 // d_tiles)) if dtype == "fp32" else 1
+        if os.environ.get("DTF_DGRAD_SPLITS"):                  # tuning override
+            self.dgrad_splits = max(1, min(int(os.environ["DTF_DGRAD_SPLITS"]), H // 32)) if dtype == "fp32" else 1
+        self.dgrad_part = torch.empty((self.dgrad_splits, B, FLAT) if self.dgrad_splits > 1 else (4,), **f32)
         self.logits = torch.empty((B, spec.classes), **f32)
         self.loss_rows = torch.empty(B, **f32)
         self.correct_rows = torch.empty(B, **f32)
@@ -211,6 +221,7 @@ class HipEngine:
         sp, lay = self.spec, self.layout
         d.B, d.c1, d.c2, d.hidden, d.flat, d.classes = self.B, sp.c1, sp.c2, sp.hidden, sp.flat, sp.classes
         d.head_ks, d.c2_g, d.c1_g = self.head_ks, self.c2_g, self.c1_g
+        d.fc1_splits, d.dgrad_splits = self.fc1_splits, self.dgrad_splits
         d.optimizer = 0 if self.optimizer == "sgd" else 1
         d.shuffle, d.multi_stream = int(self.shuffle), int(self.multi_stream)
         # fc1 SGD update inside its wgrad GEMM (single-GPU train_step only; the wd1 gradient is then never
@@ -224,7 +235,7 @@ class HipEngine:
         d.head_stride, d.c2_stride, d.c1_stride = self.head_stride, self.c2_stride, self.c1_stride
         for name in ("params", "grads", "shadow", "fc1_part", "wc2T", "out_wT", "state", "hyper", "idx", "p1", "arg1", "p2", "arg2",
                      "h1", "logits", "loss_rows", "correct_rows", "dlogits", "da", "dflat", "dp1", "head_part",
-                     "c2_part", "c1_part"):
+                     "c2_part", "c1_part", "dgrad_part"):
             setattr(d, name, getattr(self, name).data_ptr())
         if self.optimizer == "adam":
             d.adam_m, d.adam_v = self.adam_m.data_ptr(), self.adam_v.data_ptr()

@@ -110,6 +110,8 @@ _SIGS = {
     "dtf_conv2_f32_wgrad": [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p],
     "dtf_gemm_f32_nn_partial": [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p],
     "dtf_gemm_f32_nt": [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p],
+    "dtf_gemm_f32_nt_splitk": [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_int,
+                               c_void_p],
     "dtf_gemm_f32_tn": [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p],
     "dtf_head_f32_fwd_bwd": [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                              c_void_p, c_void_p, c_int, c_int, c_float, c_float, c_int, c_void_p],
@@ -125,14 +127,15 @@ class EngineDesc(ctypes.Structure):
 
     _fields_ = (
         [(n, c_int) for n in ("B", "c1", "c2", "hidden", "flat", "classes", "head_ks", "c2_g", "c1_g", "optimizer",
-                              "shuffle", "multi_stream")]
+                              "shuffle", "multi_stream", "fc1_splits", "dgrad_splits")]
         + [(n, c_uint) for n in ("ds_n", "ds_hb", "sample_seed", "fuse_dense_update")]
         + [("seed", c_uint64), ("keep_prob", c_float), ("dtype", c_int), ("n_total", c_long)]
         + [(n, c_long) for n in ("off_out_w", "off_out_b", "off_bd1", "off_wd1", "off_wc2", "off_bc2", "off_wc1",
                                  "off_bc1", "head_stride", "c2_stride", "c1_stride")]
         + [(n, c_void_p) for n in ("params", "grads", "shadow", "fc1_part", "wc2T", "adam_m", "adam_v", "state", "hyper",
                                    "idx", "p1", "arg1", "p2", "arg2", "h1", "logits", "loss_rows", "correct_rows",
-                                   "dlogits", "da", "dflat", "dp1", "head_part", "c2_part", "c1_part", "out_wT", "ds_images",
+                                   "dlogits", "da", "dflat", "dp1", "head_part", "c2_part", "c1_part", "dgrad_part", "out_wT",
+                                   "ds_images",
                                    "ds_labels")]
         + [(n, c_void_p) for n in ("side1", "side2", "ev_head", "ev_fork", "ev_join1", "ev_join2", "ev_dgrad",
                                    "ev_dense_ready", "ev_dense_updated", "ev_tail_ready", "ev_tail_reduced")]

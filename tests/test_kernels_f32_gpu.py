@@ -40,15 +40,15 @@ def dead_code(arg, pooled):
 
 # ----------------------------------------------------------------------- GEMMs
 @pytest.mark.parametrize("M,N,K,S", [(1024, 1024, 3136, 0), (100, 1024, 3136, 0), (257, 384, 192, 3), (64, 128, 64, 1),
-                                     (1, 1024, 3136, 0)])
+                                     (1, 1024, 3136, 0), (100, 1024, 3136, 32), (100, 1024, 3136, 99)])
 def test_gemm_f32_nn_partial(gpu_lib, M, N, K, S):
     g = torch.Generator(device="cpu").manual_seed(15)
     # asymmetric operands so a transposed / garbled fragment map cannot pass
     A = torch.randn(M, K, generator=g).to(DEV)
     Bm = (torch.randn(K, N, generator=g) * 0.05 + torch.arange(N).float()[None, :] * 1e-3).to(DEV)
-    part = torch.full((8, M, N), float("nan"), device=DEV)
+    part = torch.full((32, M, N), float("nan"), device=DEV)         # the wrapper never uses more than 32 splits
     S_used = gpu_lib.dtf_gemm_f32_nn_partial(ptr(A), ptr(Bm), ptr(part), M, N, K, K, N, S, stream())
-    assert S_used > 0
+    assert 0 < S_used <= 32
     got = part[:S_used].sum(0)
     assert bool(torch.isfinite(got).all())
     assert rel_err(got, A.double() @ Bm.double()) < TOL
@@ -63,6 +63,24 @@ def test_gemm_f32_nt(gpu_lib, M, N, K):
     check(gpu_lib.dtf_gemm_f32_nt(ptr(A), ptr(Bm), ptr(C), M, N, K, K, K, N, stream()), "gemm_f32_nt")
     assert bool(torch.isfinite(C).all())
     assert rel_err(C, A.double() @ Bm.double().t()) < TOL
+
+
+@pytest.mark.parametrize("M,N,K,S", [(100, 3136, 1024, 8), (100, 3136, 1024, 3), (37, 260, 96, 8), (128, 128, 64, 2),
+                                     (100, 3136, 1024, 1)])
+def test_gemm_f32_nt_splitk(gpu_lib, M, N, K, S):
+    """Small-batch fc1 dgrad: K ranges into partial slabs + slab reduction == the plain product."""
+    g = torch.Generator(device="cpu").manual_seed(6)
+    A = torch.randn(M, K, generator=g).to(DEV)
+    Bm = (torch.randn(N, K, generator=g) * 0.05 + torch.arange(N).float()[:, None] * 1e-3).to(DEV)
+    C = torch.full((M, N), float("nan"), device=DEV)
+    part = torch.full((S, M, N), float("nan"), device=DEV)
+    check(gpu_lib.dtf_gemm_f32_nt_splitk(ptr(A), ptr(Bm), ptr(part), ptr(C), M, N, K, K, K, N, S, stream()),
+          "gemm_f32_nt_splitk")
+    assert bool(torch.isfinite(C).all())
+    assert rel_err(C, A.double() @ Bm.double().t()) < TOL
+    # a C that is not dense cannot be the target of the slab reduction
+    if S > 1:
+        assert gpu_lib.dtf_gemm_f32_nt_splitk(ptr(A), ptr(Bm), ptr(part), ptr(C), M, N, K, K, K, N + 4, S, stream()) == -3
 
 
 @pytest.mark.parametrize("M,N,K", [(3136, 1024, 100), (3136, 1024, 256), (200, 136, 1000), (128, 128, 64), (36, 260, 7)])
@@ -160,7 +178,9 @@ def _conv2_inputs(B, C1, C2, seed):
     return g, x, w, b
 
 
-@pytest.mark.parametrize("B,C1,C2", [(1, 32, 64), (5, 32, 64), (64, 32, 64), (3, 128, 256)])
+# B * (C2 / 64) workgroups against 256 CUs picks the M ranges per image: 3 (<= 85), 2 (<= 128), 1 (see conv2_f32.hip)
+@pytest.mark.parametrize("B,C1,C2", [(1, 32, 64), (5, 32, 64), (64, 32, 64), (3, 128, 256), (100, 32, 64), (260, 32, 64),
+                                     (30, 128, 256), (70, 128, 256)])
 def test_conv2_f32_fwd(gpu_lib, B, C1, C2):
     g, x, w, b = _conv2_inputs(B, C1, C2, 3)
     packed = torch.empty(2, 25 * C1 * C2, device=DEV)
@@ -178,7 +198,9 @@ def test_conv2_f32_fwd(gpu_lib, B, C1, C2):
     assert bool(((arg == 4) == (pooled <= 0)).all())
 
 
-@pytest.mark.parametrize("B,C1,C2,G", [(1, 32, 64, 1), (5, 32, 64, 3), (32, 32, 64, 8), (3, 128, 256, 2), (9, 32, 64, 16)])
+# likewise for dgrad (M ranges) and wgrad (G * tiles <= 128: two tap ranges)
+@pytest.mark.parametrize("B,C1,C2,G", [(1, 32, 64, 1), (5, 32, 64, 3), (32, 32, 64, 8), (3, 128, 256, 2), (9, 32, 64, 16),
+                                       (100, 32, 64, 100), (260, 32, 64, 200), (30, 128, 256, 16), (70, 128, 256, 4)])
 def test_conv2_f32_backward(gpu_lib, B, C1, C2, G):
     g, x, w, b = _conv2_inputs(B, C1, C2, 4)
     xf = x.double().requires_grad_(True)
