@@ -27,6 +27,8 @@ int dtf_conv2_dgrad_conv1_wgrad(const void* gpool, const void* arg2, const void*
                                 const void* idx, const void* arg1, void* part1, int B, hipStream_t s);
 int dtf_conv2_wgrad(const void* x, const void* gpool, const void* arg, void* part, int B, int cin,
                     int cout, int G, hipStream_t s);
+int dtf_conv2_wgrad_nt(const void* x, const void* gpool, const void* arg, void* part, int B, int cin, int cout, int G,
+                       int nt, hipStream_t s);
 int dtf_gemm_nt(const void* A, const void* B, void* C, const void* bias, int M, int N, int K, int lda, int ldb,
                 int ldc, int epi, float keep_prob, uint64_t seed, const void* state, int tile, hipStream_t s);
 int dtf_gemm_tn_ev(const void* A, const void* B, void* C, int M, int N, int K, int lda, int ldb, int ldc, int tile,

@@ -559,23 +559,37 @@ __global__ __launch_bounds__(256) void pack_conv2_weights(const bf16* __restrict
 // fragment feeds every tap.
 // Element j of lane group g  <->  dy = g>>1, x = 4*(g&1) + (j&3) + 8*(j>>2).
 // ----------------------------------------------------------------------------
+// NT = 16-wide co tiles per wave (output tile 16 ci x 16*NT co).  NT = 2 is the 32/64 model's tile (4 tiles x 64
+// image chunks fill the chip); NT = 4 reads 11 fragments per 28 MFMAs instead of 9 per 14 (-39 % LDS bytes per
+// MFMA, the bound of this kernel) at the price of half as many tiles: the widened model has enough of them.
 constexpr int kWgXTileBytes = kTilePos * 16 * 2;   // 10496
-constexpr int kWgDyTileBytes = 7 * 32 * 32 * 2;    // 14336
-constexpr int kWgRedBytes = 4 * 58 * 64 * 4;       // 59392: end-of-kernel reduction of the two k halves
+constexpr int wg_dy_tile_bytes(int nt) { return 7 * 32 * 16 * nt * 2; }          // NT 2: 14336, NT 4: 28672
+constexpr int wg_red_rows(int nt) { return 7 * nt * 4 + nt; }                    // accumulators + bias sums per lane
+constexpr int wg_red_bytes(int nt) { return 4 * wg_red_rows(nt) * 64 * 4; }      // end-of-kernel sum of the two k halves
+constexpr int wg_lds_bytes(int nt) {
+  return wg_red_bytes(nt) > 2 * (kWgXTileBytes + wg_dy_tile_bytes(nt)) ? wg_red_bytes(nt)
+                                                                       : 2 * (kWgXTileBytes + wg_dy_tile_bytes(nt));
+}
 
 // 8 waves = (tw: tap group, taps tw, tw+4, ..) x (kh: alternate row pairs).  Two waves per SIMD let
 // the transposed LDS reads of one wave run under the MFMAs of the other; the global loads of image
 // b+1 are issued before the k-loop of image b (register prefetch) and expanded/written to LDS after
 // it.  The two kh halves are summed through LDS once, at the end.
-template <int C_IN, int C_OUT>
-__global__ __launch_bounds__(512, 2) void conv5x5_wgrad(
+template <int C_IN, int C_OUT, int NT>
+__global__ __launch_bounds__(512, NT == 2 ? 2 : 1) void conv5x5_wgrad(
     const bf16* __restrict__ x, const bf16* __restrict__ gpool,
     const uint8_t* __restrict__ arg, float* __restrict__ part, int B, int imgs_per_block) {
   constexpr int CI_T = C_IN / 16;
+  constexpr int CO_W = 16 * NT;        // output channels per workgroup
+  constexpr int CO_CH = CO_W / 8;      // 16-byte chunks per gradient row
+  constexpr int RED_ROWS = wg_red_rows(NT);
+  static_assert(NT == 2 || NT == 4, "2 or 4 co tiles per wave");
+  static_assert(C_OUT % CO_W == 0, "C_OUT must be a multiple of the workgroup's co tile");
   typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
   typedef __attribute__((ext_vector_type(8))) short s16x8;
-  __shared__ __attribute__((aligned(16))) char smem[kWgRedBytes];
-  // two image buffers, each: xt [328][16] | dyt [7][32][32] (32-B halves swizzled)
+  extern __shared__ __attribute__((aligned(16))) char smem[];   // wg_lds_bytes(NT)
+  // two image buffers, each: xt [328][16] | dyt [7][32][CO_W] (32-B n-tile chunks swizzled over the 256-B bank row)
+  constexpr int kWgDyTileBytes = wg_dy_tile_bytes(NT);
   constexpr int kBufElems = (kWgXTileBytes + kWgDyTileBytes) / 2;
   bf16* xt = reinterpret_cast<bf16*>(smem);
   bf16* dyt = reinterpret_cast<bf16*>(smem + kWgXTileBytes);
@@ -598,12 +612,14 @@ __global__ __launch_bounds__(512, 2) void conv5x5_wgrad(
   if (tb) tb[0] = t_prev;
 #endif
 
-  f32x4 acc[7][2];
+  f32x4 acc[7][NT];
 #pragma unroll
   for (int t = 0; t < 7; ++t)
 #pragma unroll
-    for (int j = 0; j < 2; ++j) acc[t][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
-  float bsum[2] = {0.f, 0.f};
+    for (int j = 0; j < NT; ++j) acc[t][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  float bsum[NT];
+#pragma unroll
+  for (int j = 0; j < NT; ++j) bsum[j] = 0.f;
 
   // zero once: halo, slack and the x = 14,15 dummy columns stay zero
   for (int i = tid; i < 2 * (kWgXTileBytes + kWgDyTileBytes) / 16; i += 512)
@@ -611,7 +627,10 @@ __global__ __launch_bounds__(512, 2) void conv5x5_wgrad(
 
   const int tr_pos = (g >> 1) * kTileW + 4 * (g & 1) + qr;   // A: row pair 0, tap (0,0), first read
   const int kkrow = (g >> 1) * 16 + 4 * (g & 1) + qr;        // B: k row of the first read
-  const int bsw = (kkrow >> 2) & 1;                          // its half swizzle; the +8 read has the same
+  // 8 / NT gradient rows span the 256-B bank row, and the 8 rows a 32-lane group reads must land in 8 different
+  // 32-byte chunks of it: chunk = n tile XOR (row / (8 / NT)) mod NT.  The +8 read has the same swizzle.
+  auto dy_swz = [](int kk) { return (kk / (8 / NT)) & (NT - 1); };
+  const int bsw = dy_swz(kkrow);
   // element offsets of this wave's taps (tw + 4t; the 7th tap of groups 1..3 does not exist and is
   // clamped to tap 24: computed branch-free and discarded, so the k-loop has no control flow)
   int tap_off[7];
@@ -624,10 +643,10 @@ __global__ __launch_bounds__(512, 2) void conv5x5_wgrad(
 
   // staging roles: threads 0..391 own one 16-byte chunk of the input tile, threads 0..195 one
   // (pooled position, 8-channel chunk) item of the gradient expansion
-  const bool has_x = tid < 196 * 2, has_dy = tid < 49 * 4;
+  const bool has_x = tid < 196 * 2, has_dy = tid < 49 * CO_CH;
   const int x_ch = tid & 1, x_pos = tid >> 1;
   const int x_tp = (x_pos / 14 + 2) * kTileW + (x_pos % 14 + 2);
-  const int d_c8 = tid & 3, d_pp = tid >> 2;
+  const int d_c8 = tid % CO_CH, d_pp = tid / CO_CH;
   u32x4 xr = {0u, 0u, 0u, 0u};
   u32x4 gv_r = {0u, 0u, 0u, 0u};
   u32x2 ar_r = {0u, 0u};
@@ -635,7 +654,7 @@ __global__ __launch_bounds__(512, 2) void conv5x5_wgrad(
     if (has_x && !(DTF_ABLATE & 32))
       xr = *reinterpret_cast<const u32x4*>(x + ((size_t)b * 196 + x_pos) * C_IN + ci_t * 16 + x_ch * 8);
     if (has_dy && !(DTF_ABLATE & 128)) {
-      size_t off = ((size_t)b * 49 + d_pp) * C_OUT + co_t * 32 + d_c8 * 8;
+      size_t off = ((size_t)b * 49 + d_pp) * C_OUT + co_t * CO_W + d_c8 * 8;
       gv_r = *reinterpret_cast<const u32x4*>(gpool + off);
       ar_r = *reinterpret_cast<const u32x2*>(arg + off);
     }
@@ -649,8 +668,8 @@ __global__ __launch_bounds__(512, 2) void conv5x5_wgrad(
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
         int kk = (q >> 1) * 16 + 2 * w + (q & 1);
-        int slot = (((d_c8 >> 1) ^ ((kk >> 2) & 1)) << 1) | (d_c8 & 1);
-        *reinterpret_cast<u32x4*>(dyt + boff + (r * 32 + kk) * 32 + slot * 8) = o[q];
+        int slot = (((d_c8 >> 1) ^ dy_swz(kk)) << 1) | (d_c8 & 1);
+        *reinterpret_cast<u32x4*>(dyt + boff + (r * 32 + kk) * CO_W + slot * 8) = o[q];
       }
     }
   };
@@ -691,13 +710,13 @@ __global__ __launch_bounds__(512, 2) void conv5x5_wgrad(
     // k-loop over this wave's row pairs, software-pipelined: the 18 transposed reads of step r+2
     // are in flight while the 14 MFMAs of step r issue (two fragment sets, loop unrolled by two)
     const bf16* a_img = a_lane + boff;
-    const bf16* b_img = dyt + boff + kkrow * 32 + pc * 4;
-    auto load_frags = [&](int r, bf16x8 (&af)[7], bf16x8 (&bf)[2]) {
+    const bf16* b_img = dyt + boff + kkrow * CO_W + pc * 4;
+    auto load_frags = [&](int r, bf16x8 (&af)[7], bf16x8 (&bf)[NT]) {
 #pragma unroll
-      for (int j = 0; j < 2; ++j) {
-        const bf16* p0 = b_img + r * 32 * 32 + ((j ^ bsw) << 4);
+      for (int j = 0; j < NT; ++j) {
+        const bf16* p0 = b_img + r * 32 * CO_W + ((j ^ bsw) << 4);
         s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)p0);
-        s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(p0 + 8 * 32));
+        s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(p0 + 8 * CO_W));
         s16x8 v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
         bf[j] = __builtin_bit_cast(bf16x8, v);
       }
@@ -710,10 +729,10 @@ __global__ __launch_bounds__(512, 2) void conv5x5_wgrad(
         af[t] = __builtin_bit_cast(bf16x8, av);
       }
     };
-    auto mma_frags = [&](const bf16x8 (&af)[7], const bf16x8 (&bf)[2]) {
+    auto mma_frags = [&](const bf16x8 (&af)[7], const bf16x8 (&bf)[NT]) {
       if (do_bias) {
 #pragma unroll
-        for (int j = 0; j < 2; ++j)
+        for (int j = 0; j < NT; ++j)
 #pragma unroll
           for (int e = 0; e < 8; ++e) bsum[j] += (float)bf[j][e];
       }
@@ -722,14 +741,34 @@ __global__ __launch_bounds__(512, 2) void conv5x5_wgrad(
         if (DTF_ABLATE & 64) {
           asm volatile("" ::"v"(af[t]), "v"(bf[0]), "v"(bf[1]));
         } else {
-          acc[t][0] = mfma16(af[t], bf[0], acc[t][0]);
-          acc[t][1] = mfma16(af[t], bf[1], acc[t][1]);
+#pragma unroll
+          for (int j = 0; j < NT; ++j) acc[t][j] = mfma16(af[t], bf[j], acc[t][j]);
         }
       }
     };
-    if (!(DTF_ABLATE & 256)) {
+    if (NT == 4) {
+      // 112 accumulator registers per lane leave room for ONE fragment set (two spill: 153 registers to scratch):
+      // no software pipeline here; the SIMD's other wave runs its 28 MFMAs (448 cycles) while this one waits for
+      // its 22 transposed reads
+      bf16x8 af0[7], bf0[NT];
+      const int r0 = (kh + b) & 1;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int r = r0 + 2 * i;
+        if (r < 7) {
+          load_frags(r, af0, bf0);
+#if !DTF_C2W_FREE_SCHED
+          __builtin_amdgcn_sched_barrier(0);
+#endif
+          mma_frags(af0, bf0);
+#if !DTF_C2W_FREE_SCHED
+          __builtin_amdgcn_sched_barrier(0);
+#endif
+        }
+      }
+    } else if (!(DTF_ABLATE & 256)) {
       // 4 (r = 0,2,4,6) or 3 (r = 1,3,5) steps, straight-line so every wait count is exact
-      bf16x8 af0[7], bf0[2], af1[7], bf1[2];
+      bf16x8 af0[7], bf0[NT], af1[7], bf1[NT];
       const int r = (kh + b) & 1;
       load_frags(r, af0, bf0);
       load_frags(r + 2, af1, bf1);
@@ -764,16 +803,16 @@ __global__ __launch_bounds__(512, 2) void conv5x5_wgrad(
 
   // ---- sum the two kh halves through LDS; kh = 0 waves write their taps: rows ci, cols co ----
   __syncthreads();
-  float* red = reinterpret_cast<float*>(smem);  // [tw][58][64 lanes]
+  float* red = reinterpret_cast<float*>(smem);  // [tw][RED_ROWS][64 lanes]
   if (kh == 1) {
 #pragma unroll
     for (int t = 0; t < 7; ++t)
 #pragma unroll
-      for (int j = 0; j < 2; ++j)
+      for (int j = 0; j < NT; ++j)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) red[(tw * 58 + (t * 2 + j) * 4 + r) * 64 + lane] = acc[t][j][r];
-    red[(tw * 58 + 56) * 64 + lane] = bsum[0];
-    red[(tw * 58 + 57) * 64 + lane] = bsum[1];
+        for (int r = 0; r < 4; ++r) red[(tw * RED_ROWS + (t * NT + j) * 4 + r) * 64 + lane] = acc[t][j][r];
+#pragma unroll
+    for (int j = 0; j < NT; ++j) red[(tw * RED_ROWS + 28 * NT + j) * 64 + lane] = bsum[j];
   }
   __syncthreads();
 #if DTF_TIMING
@@ -786,12 +825,12 @@ __global__ __launch_bounds__(512, 2) void conv5x5_wgrad(
     const int tap = tw + 4 * t;
     if (tap < 25) {
 #pragma unroll
-      for (int j = 0; j < 2; ++j)
+      for (int j = 0; j < NT; ++j)
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           int ci = ci_t * 16 + 4 * g + r;
-          int co = co_t * 32 + j * 16 + i16;
-          float v = acc[t][j][r] + red[(tw * 58 + (t * 2 + j) * 4 + r) * 64 + lane];
+          int co = co_t * CO_W + j * 16 + i16;
+          float v = acc[t][j][r] + red[(tw * RED_ROWS + (t * NT + j) * 4 + r) * 64 + lane];
           if ((DTF_ABLATE & 512) && v != 12345.f) continue;
           slab[((size_t)tap * C_IN + ci) * C_OUT + co] = v;
         }
@@ -799,11 +838,11 @@ __global__ __launch_bounds__(512, 2) void conv5x5_wgrad(
   }
   if (do_bias) {
 #pragma unroll
-    for (int j = 0; j < 2; ++j) {
-      float s = bsum[j] + red[(tw * 58 + 56 + j) * 64 + lane];
+    for (int j = 0; j < NT; ++j) {
+      float s = bsum[j] + red[(tw * RED_ROWS + 28 * NT + j) * 64 + lane];
       s += __shfl_xor(s, 16, 64);
       s += __shfl_xor(s, 32, 64);
-      if (g == 0) slab[25 * C_IN * C_OUT + co_t * 32 + j * 16 + i16] = s;
+      if (g == 0) slab[25 * C_IN * C_OUT + co_t * CO_W + j * 16 + i16] = s;
     }
   }
 }
@@ -846,6 +885,21 @@ static int launch_igemm(const void* in, const void* in_arg, const void* wk,
   hipLaunchKernelGGL(kern, dim3(grid), dim3(threads), lds, s, (const bf16*)in, (const uint8_t*)in_arg,
                      (const bf16*)wk, (const float*)bias, (bf16*)out,
                      (uint8_t*)out_arg, B, c1f, c1w);
+  return DTF_LAUNCH_CHECK();
+}
+
+template <int C_IN, int C_OUT, int NT>
+static int launch_wgrad(const void* x, const void* gpool, const void* arg, void* part, int B, int G, hipStream_t s) {
+  auto kern = conv5x5_wgrad<C_IN, C_OUT, NT>;
+  constexpr int lds = wg_lds_bytes(NT);
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    attr_set = true;
+  }
+  const int ipb = (B + G - 1) / G;
+  hipLaunchKernelGGL(kern, dim3(G, (C_IN / 16) * (C_OUT / (16 * NT))), dim3(512), lds, s, (const bf16*)x, (const bf16*)gpool,
+                     (const uint8_t*)arg, (float*)part, B, ipb);
   return DTF_LAUNCH_CHECK();
 }
 
@@ -900,22 +954,30 @@ int dtf_conv2_dgrad_conv1_wgrad(const void* gpool, const void* arg2, const void*
   return launch_igemm<64, 32, 32, 2, 1, MODE_DGRAD, 3, true>(gpool, arg2, w, nullptr, nullptr, nullptr, B, s, Conv1Fused{}, c);
 }
 
-// wgrad partial slabs: part [G][25*cin*cout + cout]
+// wgrad partial slabs: part [G][25*cin*cout + cout].  nt = 16-wide co tiles per wave (2 or 4; see conv5x5_wgrad);
+// 0 picks 4 for the widened model (32 output tiles x G) and 2 for the 32/64 model, DTF_C2W_NT overrides (tools).
+int dtf_conv2_wgrad_nt(const void* x, const void* gpool, const void* arg, void* part, int B, int cin, int cout, int G,
+                       int nt, hipStream_t s) {
+  if (G <= 0 || B <= 0) return -2;
+  if (nt == 0) {
+    static int forced = -1;
+    if (forced < 0) {
+      const char* v = getenv("DTF_C2W_NT");
+      forced = v ? atoi(v) : 0;
+    }
+    nt = (forced == 2 || forced == 4) ? forced : (cin >= 128 ? 4 : 2);
+  }
+  if (nt != 2 && nt != 4) return -3;
+  if (cin == 32 && cout == 64)
+    return nt == 4 ? launch_wgrad<32, 64, 4>(x, gpool, arg, part, B, G, s) : launch_wgrad<32, 64, 2>(x, gpool, arg, part, B, G, s);
+  if (cin == 128 && cout == 256)
+    return nt == 4 ? launch_wgrad<128, 256, 4>(x, gpool, arg, part, B, G, s)
+                   : launch_wgrad<128, 256, 2>(x, gpool, arg, part, B, G, s);
+  return -1;
+}
 int dtf_conv2_wgrad(const void* x, const void* gpool, const void* arg, void* part,
                     int B, int cin, int cout, int G, hipStream_t s) {
-  if (G <= 0) return -2;
-  int ipb = (B + G - 1) / G;
-  if (cin == 32 && cout == 64) {
-    hipLaunchKernelGGL((conv5x5_wgrad<32, 64>), dim3(G, 4), dim3(512), 0, s, (const bf16*)x,
-                       (const bf16*)gpool, (const uint8_t*)arg, (float*)part, B, ipb);
-    return DTF_LAUNCH_CHECK();
-  }
-  if (cin == 128 && cout == 256) {
-    hipLaunchKernelGGL((conv5x5_wgrad<128, 256>), dim3(G, 64), dim3(512), 0, s, (const bf16*)x,
-                       (const bf16*)gpool, (const uint8_t*)arg, (float*)part, B, ipb);
-    return DTF_LAUNCH_CHECK();
-  }
-  return -1;
+  return dtf_conv2_wgrad_nt(x, gpool, arg, part, B, cin, cout, G, 0, s);
 }
 
 }  // extern "C"

@@ -242,7 +242,7 @@ def test_fused_conv2_dgrad_conv1_wgrad_matches_the_two_kernels(gpu_lib, B):
     assert float(ref.sum(0).abs().sum()) > 0
 
 
-@pytest.mark.parametrize("B,C1,C2", [(1, 32, 64), (5, 32, 64), (32, 32, 64), (3, 128, 256)])
+@pytest.mark.parametrize("B,C1,C2", [(1, 32, 64), (5, 32, 64), (32, 32, 64), (3, 128, 256), (9, 128, 256)])
 def test_conv2_backward(gpu_lib, B, C1, C2):
     g, x, w, b = _conv2_inputs(B, C1, C2, 4)
     xf = x.float().requires_grad_(True)
@@ -260,15 +260,24 @@ def test_conv2_backward(gpu_lib, B, C1, C2):
     check(gpu_lib.dtf_conv2_dgrad(ptr(gp), ptr(arg), ptr(packed[1]), ptr(dx), B, C1, C2, stream()),
           "conv2_dgrad")
     assert rel_err(dx, xf.grad) < 8e-3
-    # wgrad
+    # wgrad: the default launch, then both wave tiles (16 ci x 32 co and 16 ci x 64 co) explicitly
     G = 3
     stride = 25 * C1 * C2 + C2
-    part = torch.zeros(G, stride, device=DEV)
-    check(gpu_lib.dtf_conv2_wgrad(ptr(x), ptr(gp), ptr(arg), ptr(part), B, C1, C2, G, stream()),
-          "conv2_wgrad")
-    got = part.sum(0)
-    assert rel_err(got[:25 * C1 * C2].reshape(5, 5, C1, C2), wf.grad) < 3e-3
-    assert rel_err(got[25 * C1 * C2:], bfp.grad) < 3e-3
+    results = []
+    for nt in (None, 2, 4):
+        part = torch.full((G, stride), float("nan"), device=DEV)
+        if nt is None:
+            check(gpu_lib.dtf_conv2_wgrad(ptr(x), ptr(gp), ptr(arg), ptr(part), B, C1, C2, G, stream()), "conv2_wgrad")
+        else:
+            check(gpu_lib.dtf_conv2_wgrad_nt(ptr(x), ptr(gp), ptr(arg), ptr(part), B, C1, C2, G, nt, stream()),
+                  f"conv2_wgrad_nt{nt}")
+        got = part[:min(G, B)].sum(0)            # image chunks past the batch write nothing
+        assert bool(torch.isfinite(got).all()), nt
+        assert rel_err(got[:25 * C1 * C2].reshape(5, 5, C1, C2), wf.grad) < 3e-3, nt
+        assert rel_err(got[25 * C1 * C2:], bfp.grad) < 3e-3, nt
+        results.append(got)
+    # same products, same summation order over the images: the two wave tiles agree bit for bit
+    assert torch.equal(results[1], results[2])
 
 
 # ----------------------------------------------------------------------- GEMMs
