@@ -757,13 +757,9 @@ __global__ __launch_bounds__(512, NT == 2 ? 2 : 1) void conv5x5_wgrad(
         const int r = r0 + 2 * i;
         if (r < 7) {
           load_frags(r, af0, bf0);
-#if !DTF_C2W_FREE_SCHED
           __builtin_amdgcn_sched_barrier(0);
-#endif
           mma_frags(af0, bf0);
-#if !DTF_C2W_FREE_SCHED
           __builtin_amdgcn_sched_barrier(0);
-#endif
         }
       }
     } else if (!(DTF_ABLATE & 256)) {
