@@ -15,6 +15,7 @@ struct DtfEngineDesc {
   int B, c1, c2, hidden, flat, classes;
   int head_ks, c2_g, c1_g, optimizer /*0 sgd, 1 adam*/, shuffle, multi_stream;
   int fc1_splits;    // split-K factor the partial-product buffer fc1_part was sized for (B rows each)
+  int c2_nt;         // bf16 conv2 wgrad: 16-wide co tiles per wave (2 | 4), 0 = the kernel's choice by model
   int dgrad_splits;  // fp32 fc1 dgrad at a small batch: K ranges summed from dgrad_part (1: plain GEMM)
   unsigned ds_n, ds_hb, sample_seed, fuse_dense_update;  // last: fc1 SGD update inside its wgrad GEMM (1 GPU)
   uint64_t seed;
@@ -182,6 +183,12 @@ static int dgrad_conv1_wgrad(const DtfEngineDesc* e, const void* images, const v
   return dtf_conv1_wgrad(images, idx, e->dp1, e->arg1, e->c1_part, e->B, e->c1, e->c1_g, s);
 }
 
+// conv2 filter gradient slabs (c2_nt: the bf16 kernel's co tiles per wave, chosen with c2_g in engine.py; 0 = by model)
+static int conv2_wgrad(const DtfEngineDesc* e, hipStream_t s) {
+  if (is_f32(e)) return dtf_conv2_f32_wgrad(e->p1, e->dflat, e->arg2, e->c2_part, e->B, e->c1, e->c2, e->c2_g, s);
+  return dtf_conv2_wgrad_nt(e->p1, e->dflat, e->arg2, e->c2_part, e->B, e->c1, e->c2, e->c2_g, e->c2_nt, s);
+}
+
 // head wgrad + slab reduce + fc1 wgrad: finalises the (head | wd1) prefix of the gradient arena.
 // reduce == 0 leaves the head slabs unreduced (the fused single-GPU SGD tail sums them itself);
 // reduce == -1 does not compute them either: the training step runs the head wgrad inside the fc1
@@ -233,8 +240,7 @@ static int backward_conv_impl(const DtfEngineDesc* e, const void* images, const 
     HIP_TRY(hipStreamWaitEvent(e->side2, e->ev_fork, 0));
     s2 = e->side2;
   }
-  DTF_TRY((is_f32(e) ? dtf_conv2_f32_wgrad : dtf_conv2_wgrad)(e->p1, e->dflat, e->arg2, e->c2_part, e->B, e->c1, e->c2,
-                                                              e->c2_g, s2));
+  DTF_TRY(conv2_wgrad(e, s2));
   if (e->multi_stream) HIP_TRY(hipEventRecord(e->ev_join2, s2));
   DTF_TRY(dgrad_conv1_wgrad(e, images, idx, s));
   if (e->multi_stream) HIP_TRY(hipStreamWaitEvent(s, e->ev_join2, 0));
@@ -328,8 +334,7 @@ static int train_tail_fused_dense(const DtfEngineDesc* e, long step_inc, hipStre
   else
     DTF_TRY(dtf_gemm_tn_sgd(e->p2, e->da, f32at(e->params, e->off_wd1), bf16at(e->shadow, e->off_wd1), e->hyper, e->flat,
                             e->hidden, e->B, e->flat, e->hidden, e->hidden, s1));
-  DTF_TRY((is_f32(e) ? dtf_conv2_f32_wgrad : dtf_conv2_wgrad)(e->p1, e->dflat, e->arg2, e->c2_part, e->B, e->c1, e->c2,
-                                                              e->c2_g, s2));
+  DTF_TRY(conv2_wgrad(e, s2));
   DTF_TRY(dgrad_conv1_wgrad(e, e->ds_images, e->idx, s));
   if (e->multi_stream) {
     HIP_TRY(hipEventRecord(e->ev_join1, s1));

@@ -185,8 +185,15 @@ class HipEngine:
         self.head_part = torch.empty((self.head_ks, self.head_stride), **f32)
         # conv2 wgrad split-K over images: G slabs x (C1/16 * C2/32) output tiles workgroups.  64 slabs fill the
         # chip for the 32/64 model (4 tiles); the widened model has 64 tiles and 3.3 MB slabs -> 8 slabs
-        c2_tiles = (C1 // 16) * (C2 // 32)
-        self.c2_g = max(1, min((B + 1) // 2, int(os.environ.get("DTF_C2_G", "64" if c2_tiles <= 4 else "8"))))
+        # Wave tile of the bf16 kernel: 16 ci x 64 co (4 co tiles per wave: -39 % LDS fragment bytes per MFMA, half as
+        # many output tiles) for the widened model and, with twice the image chunks, for the 32/64 model from 4096
+        # images per GPU (-2 %; a wash at 1024, where the doubled slab traffic eats the gain)
+        self.c2_nt = 4 if (C1 >= 128 or B >= 4096) else 2
+        if os.environ.get("DTF_C2W_NT") in ("2", "4"):          # A/B switch for tools
+            self.c2_nt = int(os.environ["DTF_C2W_NT"])
+        c2_tiles = (C1 // 16) * (C2 // (16 * self.c2_nt))
+        default_g = "8" if C1 >= 128 else ("64" if c2_tiles >= 4 else "128")
+        self.c2_g = max(1, min((B + 1) // 2, int(os.environ.get("DTF_C2_G", default_g))))
         if dtype == "fp32":
             # conv5x5_wgrad_f32: one workgroup per (image range, 32 ci x 64 co tile), one workgroup per CU
             f32_tiles = (C1 // 32) * (C2 // 64)
@@ -221,7 +228,7 @@ class HipEngine:
         sp, lay = self.spec, self.layout
         d.B, d.c1, d.c2, d.hidden, d.flat, d.classes = self.B, sp.c1, sp.c2, sp.hidden, sp.flat, sp.classes
         d.head_ks, d.c2_g, d.c1_g = self.head_ks, self.c2_g, self.c1_g
-        d.fc1_splits, d.dgrad_splits = self.fc1_splits, self.dgrad_splits
+        d.fc1_splits, d.dgrad_splits, d.c2_nt = self.fc1_splits, self.dgrad_splits, self.c2_nt
         d.optimizer = 0 if self.optimizer == "sgd" else 1
         d.shuffle, d.multi_stream = int(self.shuffle), int(self.multi_stream)
         # fc1 SGD update inside its wgrad GEMM (single-GPU train_step only; the wd1 gradient is then never

@@ -128,7 +128,7 @@ class EngineDesc(ctypes.Structure):
 
     _fields_ = (
         [(n, c_int) for n in ("B", "c1", "c2", "hidden", "flat", "classes", "head_ks", "c2_g", "c1_g", "optimizer",
-                              "shuffle", "multi_stream", "fc1_splits", "dgrad_splits")]
+                              "shuffle", "multi_stream", "fc1_splits", "c2_nt", "dgrad_splits")]
         + [(n, c_uint) for n in ("ds_n", "ds_hb", "sample_seed", "fuse_dense_update")]
         + [("seed", c_uint64), ("keep_prob", c_float), ("dtype", c_int), ("n_total", c_long)]
         + [(n, c_long) for n in ("off_out_w", "off_out_b", "off_bd1", "off_wd1", "off_wc2", "off_bc2", "off_wc1",
