@@ -20,7 +20,16 @@ import os
 import sys
 import time
 
-import torch
+# The contract is ONE line on stdout.  Native libraries write there too (RCCL prints a version banner on stdout when
+# its first communicator comes up), so file descriptor 1 is pointed at stderr for the life of the process and the
+# result line goes to a private duplicate of the real stdout.
+_RESULT_FD = 1
+if __name__ == "__main__":
+    _RESULT_FD = os.dup(1)
+    sys.stdout.flush()
+    os.dup2(2, 1)
+
+import torch  # noqa: E402
 
 sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 
@@ -53,6 +62,9 @@ def main():
                          "even at --gpus 1, to exercise the N>1 code path on a one-GPU box")
     ap.add_argument("--no_p2p_tail", action="store_true",
                     help="N>1: keep the small tail all-reduce on RCCL instead of the one-shot peer-to-peer kernel")
+    ap.add_argument("--grad_comm", choices=["fp32", "bf16"], default="fp32",
+                    help="N > 1 / --force_dp, bf16 configuration: bf16 = opt-in 16-bit collective for the fc1 weight gradient "
+                         "(NOT the reference's fp32 gradient sum; recorded in config.grad_comm)")
     ap.add_argument("--no_p2p_dense", action="store_true",
                     help="N>1: keep the dense all-reduce on RCCL even if the two-shot peer-to-peer kernel measures faster")
     ap.add_argument("--rehearse_one_gpu", action="store_true",
@@ -137,12 +149,14 @@ def main():
         # a collective whose cost is what it takes from the kernels it overlaps with (world 1, 64 workgroups: 50 us
         # stand-alone, +30 us on the step).  DTF_BENCH_DENSE_P2P_WORLD1 lets a one-rank --force_dp run try it as well.
         dense_cand = None
-        if not args.no_p2p_dense and (world > 1 or os.environ.get("DTF_BENCH_DENSE_P2P_WORLD1")) and world <= 8:
+        if (not args.no_p2p_dense and args.grad_comm == "fp32" and world <= 8
+                and (world > 1 or os.environ.get("DTF_BENCH_DENSE_P2P_WORLD1"))):
             dense_cand, why = bring_up(n_dense_arena, True)
             if dense_cand is None:
                 dense_how = why
         dp = SyncDataParallel(eng, tail_group=tail_group, tail_p2p=tail_p2p, dense_p2p=dense_p2p,
-                              shard_dense={"auto": None, "allreduce": False, "sharded": True}[args.dense])
+                              shard_dense={"auto": None, "allreduce": False, "sharded": True}[args.dense],
+                              grad_comm=args.grad_comm)
         dense_how = "rccl reduce-scatter + sharded update + all-gather" if dp.shard else "rccl all-reduce"
         dp.broadcast_parameters()
         step = dp.train_step
@@ -329,7 +343,7 @@ def main():
         global_batch = B * world
         value = global_batch * args.steps / dt
         _, fb = spec.flops_per_image()
-        print(json.dumps({
+        line = json.dumps({
             "metric": "train images/sec (whole node)",
             "value": round(value, 1),
             "unit": "images/s",
@@ -348,11 +362,13 @@ def main():
                        "graph": bool(use_graph),
                        # HIP streams of this process: compute (+ comm) + the engine's backward side streams (RCCL's own not counted)
                        "streams": 1 + (1 if dp_path else 0) + eng.streams_in_use(),
-                       **({"tail_allreduce": tail_how, "dense_allreduce": dense_how} if dp_path else {})},
+                       **({"tail_allreduce": tail_how, "dense_allreduce": dense_how, "grad_comm": args.grad_comm}
+                          if dp_path else {})},
             "model_tflops": round(value * fb / 1e12, 2),
             "final_loss": round(loss, 4),
             **({"comm_diag": comm_diag} if comm_diag is not None else {}),
-        }), flush=True)
+        })
+        os.write(_RESULT_FD, (line + "\n").encode())
     # The diagnostics below run collectives after the measurement is complete: if they stall (they never have), every
     # rank gives up after 90 s, rank 0 still prints the headline line, and the processes exit.
     def give_up():

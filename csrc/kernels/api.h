@@ -33,6 +33,8 @@ int dtf_gemm_nt(const void* A, const void* B, void* C, const void* bias, int M, 
                 int ldc, int epi, float keep_prob, uint64_t seed, const void* state, int tile, hipStream_t s);
 int dtf_gemm_tn_ev(const void* A, const void* B, void* C, int M, int N, int K, int lda, int ldb, int ldc, int tile,
                    hipEvent_t done, hipStream_t s);
+int dtf_gemm_tn_g16_ev(const void* A, const void* B, void* C, int M, int N, int K, int lda, int ldb, int ldc,
+                       hipEvent_t done, hipStream_t s);
 int dtf_gemm_tn(const void* A, const void* B, void* C, int M, int N, int K, int lda, int ldb, int ldc, int tile,
                 hipStream_t s);
 int dtf_gemm_tn_sgd(const void* A, const void* B, void* W, void* shadow, const void* hyper, int M, int N, int K,
@@ -62,6 +64,10 @@ int dtf_sgd_update(void* w, const void* g, void* shadow, const void* hyper, long
                    long step_inc, long drop_inc, hipStream_t s);
 int dtf_adam_update(void* w, const void* g, void* m, void* v, void* shadow, const void* hyper, long n, void* tstate,
                     int adam_slot, void* state, long cursor_inc, long step_inc, long drop_inc, hipStream_t s);
+int dtf_sgd_update_g16(void* w, const void* g, void* shadow, const void* hyper, long n, void* state, long cursor_inc,
+                       long step_inc, long drop_inc, hipStream_t s);
+int dtf_adam_update_g16(void* w, const void* g, void* m, void* v, void* shadow, const void* hyper, long n, void* tstate,
+                        int adam_slot, void* state, long cursor_inc, long step_inc, long drop_inc, hipStream_t s);
 int dtf_cast_bf16(const void* w, void* shadow, long n, hipStream_t s);
 int dtf_reduce_segments(int count, const void** part, void** out, const int* G, const int* n, const long* stride,
                         hipStream_t s);

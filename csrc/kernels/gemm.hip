@@ -217,7 +217,9 @@ __global__ __launch_bounds__(NW * 64, DTF_GEMM_MINW) void gemm_nt_bf16(const bf1
 // w -= lr * g in place and writes the bf16 compute copy -- the fc1 weight gradient (98 % of the
 // model's gradient bytes) then never goes through memory.  Single-GPU SGD only: with data
 // parallelism the gradient has to exist for the all-reduce.
-template <int BM, int BN, int NW, bool SGD = false>
+// G16 = true: C is a bf16 matrix (the gradient goes out in bf16: the opt-in 16-bit dense collective of
+// parallel/sync_dp.py, half the bytes on the links).
+template <int BM, int BN, int NW, bool SGD = false, bool G16 = false>
 __global__ __launch_bounds__(NW * 64, DTF_GEMM_MINW) void gemm_tn_bf16(const bf16* A, const bf16* Bm, float* __restrict__ C,
                                                         int M, int N, int K, int lda, int ldb, int ldc,
                                                         bf16* __restrict__ shadow = nullptr,
@@ -362,7 +364,10 @@ __global__ __launch_bounds__(NW * 64, DTF_GEMM_MINW) void gemm_tn_bf16(const bf1
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           const int mrow = m0 + wm * WM + i * 16 + 4 * g + r;
-          if (mrow < M) C[(size_t)mrow * ldc + n] = acc[i][j][r];
+          if (mrow < M) {
+            if (G16) reinterpret_cast<bf16*>(C)[(size_t)mrow * ldc + n] = (bf16)acc[i][j][r];
+            else C[(size_t)mrow * ldc + n] = acc[i][j][r];
+          }
         }
     }
   }
@@ -621,6 +626,15 @@ int dtf_gemm_tn_ev(const void* A, const void* B, void* C, int M, int N, int K, i
                           (const float*)nullptr);
   else
     return -1;
+  return (int)hipGetLastError();
+}
+// The same product stored as bf16 (C: bf16 [M][ldc]); 128 x 128 tiles
+int dtf_gemm_tn_g16_ev(const void* A, const void* B, void* C, int M, int N, int K, int lda, int ldb, int ldc,
+                       hipEvent_t done, hipStream_t s) {
+  if ((lda & 7) || (ldb & 7) || (M & 7) || (N & 7)) return -3;
+  hipExtLaunchKernelGGL((gemm_tn_bf16<128, 128, 8, false, true>), dim3((N + 127) / 128, (M + 127) / 128), dim3(512), 0, s,
+                        nullptr, done, 0, (const bf16*)A, (const bf16*)B, (float*)C, M, N, K, lda, ldb, ldc, (bf16*)nullptr,
+                        (const float*)nullptr);
   return (int)hipGetLastError();
 }
 int dtf_gemm_tn(const void* A, const void* B, void* C, int M, int N, int K, int lda, int ldb, int ldc,

@@ -40,14 +40,22 @@ __device__ __forceinline__ void store_bf16x4(bf16* p, float a, float b, float c,
   *reinterpret_cast<bf16x4*>(p) = v;
 }
 
+// four consecutive gradient values: fp32, or bf16 (the 16-bit dense collective of parallel/sync_dp.py)
+__device__ __forceinline__ f32x4 load_grad4(const float* g, long i) { return reinterpret_cast<const f32x4*>(g)[i]; }
+__device__ __forceinline__ f32x4 load_grad4(const bf16* g, long i) {
+  const bf16x4 v = reinterpret_cast<const bf16x4*>(g)[i];
+  return (f32x4){(float)v[0], (float)v[1], (float)v[2], (float)v[3]};
+}
+
 // n must be a multiple of 4 (arena tensors are padded to 4 floats)
-__global__ __launch_bounds__(256) void sgd_update(float* __restrict__ w, const float* __restrict__ g,
+template <typename GT>
+__global__ __launch_bounds__(256) void sgd_update(float* __restrict__ w, const GT* __restrict__ g,
                                                   bf16* __restrict__ shadow, const float* __restrict__ hyper,
                                                   long n4, StepAdvance adv) {
   const float lr = hyper[0] * hyper[4];
   for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long)gridDim.x * blockDim.x) {
     f32x4 wv = reinterpret_cast<const f32x4*>(w)[i];
-    f32x4 gv = reinterpret_cast<const f32x4*>(g)[i];
+    f32x4 gv = load_grad4(g, i);
     wv[0] = fmaf(-lr, gv[0], wv[0]);
     wv[1] = fmaf(-lr, gv[1], wv[1]);
     wv[2] = fmaf(-lr, gv[2], wv[2]);
@@ -59,7 +67,8 @@ __global__ __launch_bounds__(256) void sgd_update(float* __restrict__ w, const f
 }
 
 // TF AdamOptimizer semantics: lr_t = lr * sqrt(1-b2^t)/(1-b1^t); w -= lr_t * m / (sqrt(v) + eps)
-__global__ __launch_bounds__(256) void adam_update(float* __restrict__ w, const float* __restrict__ g,
+template <typename GT>
+__global__ __launch_bounds__(256) void adam_update(float* __restrict__ w, const GT* __restrict__ g,
                                                    float* __restrict__ m, float* __restrict__ v,
                                                    bf16* __restrict__ shadow, const float* __restrict__ hyper,
                                                    long n4, const int64_t* __restrict__ tptr) {
@@ -68,7 +77,7 @@ __global__ __launch_bounds__(256) void adam_update(float* __restrict__ w, const 
   const float lr_t = lr * sqrtf(1.f - powf(b2, t)) / (1.f - powf(b1, t));
   for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long)gridDim.x * blockDim.x) {
     f32x4 wv = reinterpret_cast<const f32x4*>(w)[i];
-    f32x4 gv = reinterpret_cast<const f32x4*>(g)[i];
+    f32x4 gv = load_grad4(g, i);
     f32x4 mv = reinterpret_cast<const f32x4*>(m)[i];
     f32x4 vv = reinterpret_cast<const f32x4*>(v)[i];
 #pragma unroll
@@ -432,7 +441,16 @@ int dtf_sgd_update(void* w, const void* g, void* shadow, const void* hyper, long
                    long cursor_inc, long step_inc, long drop_inc, hipStream_t s) {
   if (n & 3) return -3;
   StepAdvance adv{(int64_t*)state, cursor_inc, step_inc, drop_inc, -1};
-  hipLaunchKernelGGL(sgd_update, dim3(grid_for(n / 4)), dim3(256), 0, s, (float*)w, (const float*)g,
+  hipLaunchKernelGGL(sgd_update<float>, dim3(grid_for(n / 4)), dim3(256), 0, s, (float*)w, (const float*)g,
+                     (bf16*)shadow, (const float*)hyper, n / 4, adv);
+  return (int)hipGetLastError();
+}
+// g: bf16 gradient (8-byte aligned)
+int dtf_sgd_update_g16(void* w, const void* g, void* shadow, const void* hyper, long n, void* state,
+                       long cursor_inc, long step_inc, long drop_inc, hipStream_t s) {
+  if ((n & 3) || ((uintptr_t)g & 7)) return -3;
+  StepAdvance adv{(int64_t*)state, cursor_inc, step_inc, drop_inc, -1};
+  hipLaunchKernelGGL(sgd_update<bf16>, dim3(grid_for(n / 4)), dim3(256), 0, s, (float*)w, (const bf16*)g,
                      (bf16*)shadow, (const float*)hyper, n / 4, adv);
   return (int)hipGetLastError();
 }
@@ -443,7 +461,18 @@ int dtf_adam_update(void* w, const void* g, void* m, void* v, void* shadow, cons
                     void* tstate, int adam_slot, void* state, long cursor_inc, long step_inc, long drop_inc,
                     hipStream_t s) {
   if ((n & 3) || adam_slot < 3 || adam_slot > 7 || !tstate) return -3;
-  hipLaunchKernelGGL(adam_update, dim3(grid_for(n / 4)), dim3(256), 0, s, (float*)w, (const float*)g,
+  hipLaunchKernelGGL(adam_update<float>, dim3(grid_for(n / 4)), dim3(256), 0, s, (float*)w, (const float*)g,
+                     (float*)m, (float*)v, (bf16*)shadow, (const float*)hyper, n / 4,
+                     (const int64_t*)tstate + adam_slot);
+  StepAdvance adv{(int64_t*)tstate, state ? cursor_inc : 0, state ? step_inc : 0, state ? drop_inc : 0, adam_slot};
+  hipLaunchKernelGGL(advance_state_kernel, dim3(1), dim3(1), 0, s, adv);
+  return (int)hipGetLastError();
+}
+int dtf_adam_update_g16(void* w, const void* g, void* m, void* v, void* shadow, const void* hyper, long n,
+                        void* tstate, int adam_slot, void* state, long cursor_inc, long step_inc, long drop_inc,
+                        hipStream_t s) {
+  if ((n & 3) || adam_slot < 3 || adam_slot > 7 || !tstate || ((uintptr_t)g & 7)) return -3;
+  hipLaunchKernelGGL(adam_update<bf16>, dim3(grid_for(n / 4)), dim3(256), 0, s, (float*)w, (const bf16*)g,
                      (float*)m, (float*)v, (bf16*)shadow, (const float*)hyper, n / 4,
                      (const int64_t*)tstate + adam_slot);
   StepAdvance adv{(int64_t*)tstate, state ? cursor_inc : 0, state ? step_inc : 0, state ? drop_inc : 0, adam_slot};

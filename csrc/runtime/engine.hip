@@ -28,6 +28,7 @@ struct DtfEngineDesc {
   void *params, *grads, *shadow, *fc1_part, *wc2T, *adam_m, *adam_v, *state, *hyper;
   void *idx, *p1, *arg1, *p2, *arg2, *h1, *logits, *loss_rows, *correct_rows, *dlogits, *da, *dflat, *dp1;
   void *head_part, *c2_part, *c1_part, *dgrad_part;
+  void* dense_g16;   // bf16 [flat * hidden] or NULL: the data-parallel step's wd1 gradient in 16 bits (sync_dp.py grad_comm)
   void* out_wT;  // fp32 [classes][hidden]: transposed output weight for the head kernel
   void *ds_images, *ds_labels;
   // native-owned handles (filled by dtf_engine_init)
@@ -194,7 +195,8 @@ static int conv2_wgrad(const DtfEngineDesc* e, hipStream_t s) {
 // reduce == -1 does not compute them either: the training step runs the head wgrad inside the fc1
 // dgrad launch (backward_conv_impl with head_w != 0).
 // done != NULL: that event is complete when the fc1 wgrad GEMM is (bound to the kernel: no marker in the stream).
-static int backward_dense_impl(const DtfEngineDesc* e, int reduce, hipStream_t s, hipEvent_t done = nullptr) {
+// g16 != 0: the fc1 weight gradient is written as bf16 into e->dense_g16 instead of the gradient arena.
+static int backward_dense_impl(const DtfEngineDesc* e, int reduce, hipStream_t s, hipEvent_t done = nullptr, int g16 = 0) {
   if (reduce >= 0)
     DTF_TRY((is_f32(e) ? dtf_head_f32_wgrad : dtf_head_wgrad)(e->h1, e->dlogits, e->da, e->head_part, e->B, e->hidden,
                                                               e->head_ks, s));
@@ -208,6 +210,8 @@ static int backward_dense_impl(const DtfEngineDesc* e, int reduce, hipStream_t s
   if (is_f32(e))
     return dtf_gemm_f32_tn_ev(e->p2, e->da, f32at(e->grads, e->off_wd1), e->flat, e->hidden, e->B, e->flat, e->hidden,
                               e->hidden, nullptr, done, s);
+  if (g16)
+    return dtf_gemm_tn_g16_ev(e->p2, e->da, e->dense_g16, e->flat, e->hidden, e->B, e->flat, e->hidden, e->hidden, done, s);
   return dtf_gemm_tn_ev(e->p2, e->da, f32at(e->grads, e->off_wd1), e->flat, e->hidden, e->B, e->flat, e->hidden,
                         e->hidden, 0, done, s);
 }
@@ -281,19 +285,26 @@ int dtf_engine_backward(const DtfEngineDesc* e, const void* images, const void* 
 }
 
 static int update_range_src(const DtfEngineDesc* e, long lo, long hi, int advance, int advance_cursor, long step_inc,
-                            int adam_slot, const void* gsrc, hipStream_t s);
+                            int adam_slot, const void* gsrc, hipStream_t s, int g16 = 0);
 int dtf_engine_update_range(const DtfEngineDesc* e, long lo, long hi, int advance, int advance_cursor, long step_inc,
                             int adam_slot, hipStream_t s) {
   return update_range_src(e, lo, hi, advance, advance_cursor, step_inc, adam_slot, nullptr, s);
 }
 // gsrc != nullptr: the gradient of [lo, hi) is read there instead of from the gradient arena (the staging buffer of
-// the peer-to-peer all-reduce, which then does not have to copy its result into the arena)
+// the peer-to-peer all-reduce, which then does not have to copy its result into the arena); g16: gsrc holds bf16
 static int update_range_src(const DtfEngineDesc* e, long lo, long hi, int advance, int advance_cursor, long step_inc,
-                            int adam_slot, const void* gsrc, hipStream_t s) {
+                            int adam_slot, const void* gsrc, hipStream_t s, int g16) {
   const long n = hi - lo;
   const void* g = gsrc ? gsrc : (const void*)f32at(e->grads, lo);
   void* st = advance ? e->state : nullptr;
   const long cinc = (advance && advance_cursor) ? e->B : 0;
+  if (g16) {
+    if (!gsrc || is_f32(e)) return -3;
+    if (e->optimizer == 0)
+      return dtf_sgd_update_g16(f32at(e->params, lo), g, bf16at(e->shadow, lo), e->hyper, n, st, cinc, step_inc, 1, s);
+    return dtf_adam_update_g16(f32at(e->params, lo), g, f32at(e->adam_m, lo), f32at(e->adam_v, lo), bf16at(e->shadow, lo),
+                               e->hyper, n, e->state, adam_slot, st, cinc, step_inc, 1, s);
+  }
   if (e->optimizer == 0)
     DTF_TRY(dtf_sgd_update(f32at(e->params, lo), g, is_f32(e) ? nullptr : bf16at(e->shadow, lo), e->hyper, n, st, cinc,
                            step_inc, 1, s));
@@ -409,7 +420,8 @@ int dtf_engine_dp_phase1(const DtfEngineDesc* e, int wait_dense_updated, hipStre
     DTF_TRY(backward_dense_impl(e, -1, s));
     HIP_TRY(hipEventRecord(e->ev_dense_ready, s));
   } else {
-    DTF_TRY(backward_dense_impl(e, -1, s, e->ev_dense_ready));   // fc1 wgrad only; the event rides on the kernel
+    // fc1 wgrad only; the event rides on the kernel
+    DTF_TRY(backward_dense_impl(e, -1, s, e->ev_dense_ready, e->dense_g16 != nullptr && !is_f32(e)));
   }
   return (int)hipStreamWaitEvent(comm, e->ev_dense_ready, 0);
 }
@@ -419,8 +431,12 @@ int dtf_engine_dp_phase2(const DtfEngineDesc* e, long dense_lo, long dense_hi, i
                          hipStream_t tail) {
   DTF_TRY(backward_conv_impl(e, e->ds_images, e->idx, 0, reduce_tail ? 2 : 0, -1, s));
   // (the dense update overwrites the bf16 wd1 that fc1 dgrad reads: that kernel ran before ev_dense_ready)
-  if (!(DTF_EXP_DP & 2))
-    DTF_TRY(update_range_src(e, dense_lo, dense_hi, 0, 0, 0, dense_adam_slot, dense_grad_src, (DTF_EXP_DP & 4) ? s : comm));
+  if (!(DTF_EXP_DP & 2)) {
+    const int g16 = e->dense_g16 != nullptr && !is_f32(e);
+    if (g16 && dense_grad_src) return -3;     // the 16-bit gradient lives in e->dense_g16, not in a peer-to-peer staging area
+    const void* gsrc = g16 ? (const void*)bf16at(e->dense_g16, dense_lo - e->off_wd1) : dense_grad_src;
+    DTF_TRY(update_range_src(e, dense_lo, dense_hi, 0, 0, 0, dense_adam_slot, gsrc, (DTF_EXP_DP & 4) ? s : comm, g16));
+  }
   if (record_updated) HIP_TRY(hipEventRecord(e->ev_dense_updated, comm));
   // tail == s: the tail collective is issued on the compute stream itself (everything after it depends on
   // it anyway), which needs no events at all; a separate tail stream is ordered behind the conv backward

@@ -219,6 +219,7 @@ class HipEngine:
 
         self._graph = None
         self._graph_stream = None
+        self.dense_g16 = None      # see enable_dense_g16()
         self._build_desc()
 
     def _build_desc(self):
@@ -339,6 +340,22 @@ class HipEngine:
     # stream (and forks/joins its own side streams).  No host synchronisation anywhere.
     def _d(self):
         return ctypes.byref(self._desc)
+
+    def enable_dense_g16(self) -> torch.Tensor:
+        """16-bit dense gradient for the data-parallel step (parallel/sync_dp.py ``grad_comm="bf16"``): the fc1 weight
+        gradient is written as bf16 into this buffer by its GEMM, travels in bf16, and the dense update reads it
+        there.  Mixed-precision configuration only.  Returns the buffer (flat, wd1's element count)."""
+        if self.dtype != "bf16":
+            raise ValueError("the 16-bit gradient collective belongs to the bf16 configuration")
+        if self.dense_g16 is None:
+            lo, hi = self.layout.segment("wd1", "wd1")
+            self.dense_g16 = torch.zeros(hi - lo, dtype=torch.bfloat16, device=self.device)
+            self._desc.dense_g16 = self.dense_g16.data_ptr()
+        return self.dense_g16
+
+    def disable_dense_g16(self):
+        self.dense_g16 = None
+        self._desc.dense_g16 = None
 
     def launch_sample(self):
         check(self.lib.dtf_engine_sample(self._d(), self._s()), "sample")

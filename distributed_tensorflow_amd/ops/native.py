@@ -60,6 +60,10 @@ _SIGS = {
     "dtf_sgd_update": [c_void_p, c_void_p, c_void_p, c_void_p, c_long, c_void_p, c_long, c_long, c_long, c_void_p],
     "dtf_adam_update": [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_long, c_void_p, c_int,
                         c_void_p, c_long, c_long, c_long, c_void_p],
+    "dtf_sgd_update_g16": [c_void_p, c_void_p, c_void_p, c_void_p, c_long, c_void_p, c_long, c_long, c_long, c_void_p],
+    "dtf_adam_update_g16": [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_long, c_void_p, c_int,
+                            c_void_p, c_long, c_long, c_long, c_void_p],
+    "dtf_gemm_tn_g16_ev": [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p],
     "dtf_advance_state": [c_void_p, c_long, c_long, c_long, c_void_p],
     "dtf_cast_bf16": [c_void_p, c_void_p, c_long, c_void_p],
     "dtf_reduce_segments": [c_int, ctypes.POINTER(c_void_p), ctypes.POINTER(c_void_p), ctypes.POINTER(c_int),
@@ -135,7 +139,7 @@ class EngineDesc(ctypes.Structure):
                                  "off_bc1", "head_stride", "c2_stride", "c1_stride")]
         + [(n, c_void_p) for n in ("params", "grads", "shadow", "fc1_part", "wc2T", "adam_m", "adam_v", "state", "hyper",
                                    "idx", "p1", "arg1", "p2", "arg2", "h1", "logits", "loss_rows", "correct_rows",
-                                   "dlogits", "da", "dflat", "dp1", "head_part", "c2_part", "c1_part", "dgrad_part", "out_wT",
+                                   "dlogits", "da", "dflat", "dp1", "head_part", "c2_part", "c1_part", "dgrad_part", "dense_g16", "out_wT",
                                    "ds_images",
                                    "ds_labels")]
         + [(n, c_void_p) for n in ("side1", "side2", "ev_head", "ev_fork", "ev_join1", "ev_join2", "ev_dgrad",

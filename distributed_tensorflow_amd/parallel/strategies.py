@@ -112,7 +112,11 @@ class SyncAllReduce:
     coordinated_stop = True
 
     def __init__(self, backend: Backend, task: TaskInfo, worker_group, chief_rank: int, tail_group=None,
-                 p2p: bool = False, log=None, stop_check_steps: int = 20, shard_dense=None):
+                 p2p: bool = False, log=None, stop_check_steps: int = 20, shard_dense=None, grad_comm: str = "fp32"):
+        if grad_comm not in ("fp32", "bf16"):
+            raise ValueError(f"--grad_comm must be fp32 or bf16, not {grad_comm!r}")
+        if grad_comm == "bf16" and (backend.name != "hip" or backend.engine.dtype != "bf16"):
+            raise ValueError("--grad_comm=bf16 needs --backend=hip with --dtype=bf16")
         self.b, self.task, self.group, self.chief_rank = backend, task, worker_group, chief_rank
         self.world = task.num_workers
         self.step_count = backend.get_global_step()
@@ -130,14 +134,18 @@ class SyncAllReduce:
         # The overlapped schedule (parallel/sync_dp.py) needs collectives that run on streams: RCCL, or the
         # peer-to-peer kernels (--p2p_allreduce; these also work between tasks that share one GPU over gloo).
         # (an explicit --dense_update=sharded also selects it over gloo, staged through the host: tests, rehearsals)
-        if backend.name == "hip" and (dist.get_backend(worker_group) != "gloo" or p2p or shard_dense):
+        if backend.name == "hip" and (dist.get_backend(worker_group) != "gloo" or p2p or shard_dense
+                                      or grad_comm == "bf16"):
             from .sync_dp import SyncDataParallel
             tail_p2p = dense_p2p = None
             if p2p:
+                # (the 16-bit dense collective goes through the process group as well)
                 tail_p2p, dense_p2p = self._bring_up_p2p(backend.engine, worker_group, log or (lambda *a: None),
-                                                         dense=not shard_dense)
+                                                         dense=not shard_dense and grad_comm != "bf16")
             self._dp = SyncDataParallel(backend.engine, group=worker_group, tail_group=tail_group, tail_p2p=tail_p2p,
-                                        dense_p2p=dense_p2p, shard_dense=shard_dense)
+                                        dense_p2p=dense_p2p, shard_dense=shard_dense, grad_comm=grad_comm)
+            if grad_comm == "bf16" and log:
+                log(f"worker/{task.task_index}: fc1 weight gradient communicated in bf16 (--grad_comm=bf16)")
             if self._dp.shard and log:
                 log(f"worker/{task.task_index}: dense update sharded over {self.world} workers "
                     f"(reduce-scatter -> update of 1/{self.world} -> all-gather of the compute copy)")

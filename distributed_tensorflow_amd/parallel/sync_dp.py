@@ -30,6 +30,11 @@ Design for xGMI (point-to-point links, ring collectives are per-link bound):
     kernel touches 1/N of the arena.  The fp32 master weights (and Adam moments) of the other ranks' shards go stale in
     between; ``gather_master()`` (a collective: every rank calls it) brings them up to date before anything reads
     them -- checkpoints, parameter dumps, the end of training (parallel/strategies.py arranges the agreement).
+  * ``grad_comm="bf16"`` (opt-in, mixed-precision configuration, RCCL / process-group paths): the fc1 weight gradient
+    is produced, communicated and consumed in bf16 -- half the bytes of the dominant message ((N-1)/N x (6.4 + 6.4) MB
+    per rank when sharded).  The sum over ranks is then a bf16 sum (each hop rounds to 8 bits of mantissa), which is
+    NOT the arithmetic of the reference's fp32 gradients: tests/test_engine_numerics_gpu.py holds the convergence
+    comparison, and benchmark numbers taken with it say so in their ``config``.
 """
 from __future__ import annotations
 
@@ -78,7 +83,14 @@ class SyncDataParallel:
 
     def __init__(self, engine: HipEngine, bucket_mb: float = 64.0, group=None, tail_group=None,
                  defer_dense_update: bool = True, tail_p2p=None, dense_p2p=None, p2p_tail_update: bool = True,
-                 shard_dense=None):
+                 shard_dense=None, grad_comm: str = "fp32"):
+        if grad_comm not in ("fp32", "bf16"):
+            raise ValueError(f"grad_comm must be fp32 or bf16, not {grad_comm!r}")
+        if grad_comm == "bf16" and engine.dtype != "bf16":
+            raise ValueError("grad_comm=bf16 needs the bf16 configuration (the fp32 configuration is exact end to end)")
+        if grad_comm == "bf16" and dense_p2p is not None:
+            raise ValueError("grad_comm=bf16 uses the process-group collectives; the peer-to-peer dense kernel sums fp32")
+        self.grad_comm = grad_comm
         self.eng = engine
         self.group = group
         self.tail_group = tail_group if tail_group is not None else group
@@ -115,6 +127,12 @@ class SyncDataParallel:
         self.rank = dist.get_rank(group)
         # what the all-gather carries: the tensor the fc1 kernels read
         self._dense_weights = (engine.params if engine.dtype == "fp32" else engine.shadow)[0:self.n_dense]
+        # what the dense collective carries: the fp32 gradient arena's wd1 range, or its 16-bit stand-in
+        if grad_comm == "bf16":
+            self._dense_grad = engine.enable_dense_g16()[0:self.n_dense]
+        else:
+            engine.disable_dense_g16()
+            self._dense_grad = engine.grads[0:self.n_dense]
         self.master_stale = False      # True while other ranks' shards of the fp32 master / moments are out of date
         self.shard = False
         self.shard_lo, self.shard_hi = 0, self.n_dense
@@ -147,7 +165,7 @@ class SyncDataParallel:
         _pg.all_reduce_sum(self.eng.grads[lo:hi], group=group)
 
     def _reduce_scatter(self):
-        _pg.reduce_scatter_sum_inplace(self.eng.grads[0:self.n_dense], self.rank, self.world, group=self.group)
+        _pg.reduce_scatter_sum_inplace(self._dense_grad, self.rank, self.world, group=self.group)
 
     def _all_gather(self):
         _pg.all_gather_inplace(self._dense_weights, self.rank, self.world, group=self.group)
@@ -180,7 +198,7 @@ class SyncDataParallel:
         else:
             with torch.cuda.stream(self.comm_stream):
                 for lo, hi in self.dense_buckets:
-                    self._allreduce(lo, hi, self.group)
+                    _pg.all_reduce_sum(self._dense_grad[lo:hi], group=self.group)
         if tr: tr.pop(); tr.push("dp_phase2: conv backward")
         shard = self.shard and self.dense_p2p is None
         lo, hi = (self.shard_lo, self.shard_hi) if shard else (0, self.n_dense)

@@ -74,6 +74,12 @@ def run(F, log=print) -> dict:
         mode = "local"
     if mode == "async" and task.num_ps == 0:
         raise SystemExit("--mode=async needs at least one ps task (--ps_hosts)")
+    grad_comm = getattr(F, "grad_comm", "fp32")
+    if grad_comm not in ("fp32", "bf16"):
+        raise SystemExit(f"--grad_comm must be fp32 or bf16, got {grad_comm!r}")
+    if grad_comm == "bf16" and (kind != "hip" or getattr(F, "dtype", "bf16") != "bf16" or mode != "sync"):
+        # every task checks this before the rendezvous, so a refused job ends everywhere at once
+        raise SystemExit("--grad_comm=bf16 needs --mode=sync with --backend=hip and --dtype=bf16 (more than one task)")
 
     if kind == "hip":
         local_rank = int(os.environ.get("LOCAL_RANK", F.local_rank if F.local_rank >= 0 else task.rank))
@@ -203,7 +209,8 @@ def run(F, log=print) -> dict:
                                  p2p=bool(getattr(F, "p2p_allreduce", False)), log=log,
                                  stop_check_steps=F.health_check_steps,
                                  shard_dense={"auto": None, "sharded": True, "replicated": False}[
-                                     getattr(F, "dense_update", "auto")])
+                                     getattr(F, "dense_update", "auto")],
+                                 grad_comm=getattr(F, "grad_comm", "fp32"))
     elif async_impl == "push":
         strategy = push_obj
     elif async_impl == "p2p":

@@ -70,6 +70,9 @@ flags.DEFINE_integer("lr_warmup_steps", 0, "linear warm-up from --learning_rate 
 flags.DEFINE_string("dense_update", "auto", "sync mode, hip backend over RCCL: auto | sharded (reduce-scatter the fc1 gradient, "
                     "each worker updates 1/N of wd1, all-gather the compute copy) | replicated (all-reduce, every worker "
                     "updates all of it); auto = sharded when there is more than one worker")
+flags.DEFINE_string("grad_comm", "fp32", "sync mode, hip backend, bf16 configuration: fp32 (reference arithmetic) | bf16 (opt-in: the "
+                    "fc1 weight gradient -- 98 % of the bytes -- is produced, summed across workers and consumed in bf16; "
+                    "half the bytes of the dominant collective, not the reference's fp32 gradient sum)")
 flags.DEFINE_boolean("trace", False, "roctx ranges around steps/collectives/checkpoints (rocprofv3 --marker-trace)")
 flags.DEFINE_integer("fault_inject_step", -1, "test hook: crash this worker after N local steps")
 flags.DEFINE_integer("fault_inject_task", -1, "test hook: which worker task crashes (-1 = any)")

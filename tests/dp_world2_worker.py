@@ -15,6 +15,10 @@ from distributed_tensorflow_amd.parallel import comm  # noqa: E402
 from distributed_tensorflow_amd.parallel.sync_dp import SyncDataParallel  # noqa: E402
 
 rank, port, optimizer, tail = int(sys.argv[1]), int(sys.argv[2]), sys.argv[3], sys.argv[4]
+# a "-g16" suffix on the tail mode: the fc1 weight gradient travels in bf16 (SyncDataParallel grad_comm="bf16"); the
+# replay rounds each rank's wd1 gradient to bf16 and sums in bf16 the way the process group does
+G16 = tail.endswith("-g16")
+tail = tail[:-4] if G16 else tail
 WORLD = int(sys.argv[5]) if len(sys.argv) > 5 else 2
 DTYPE = sys.argv[6] if len(sys.argv) > 6 else "bf16"
 B, STEPS, LR = 64, 5, (0.01 if optimizer == "sgd" else 1e-3)
@@ -47,7 +51,8 @@ if tail.startswith("p2p"):     # both messages through the peer-to-peer kernels 
 # "pg": both messages as all-reduces of the process group; "pg-sharded": the dense one as reduce-scatter -> update of
 # this rank's 1/WORLD of wd1 -> all-gather of the compute copy
 dp = SyncDataParallel(eng, tail_group=dist.new_group(), tail_p2p=tail_p2p, dense_p2p=dense_p2p,
-                      p2p_tail_update=(tail != "p2p-plain"), shard_dense=(tail == "pg-sharded"))
+                      p2p_tail_update=(tail != "p2p-plain"), shard_dense=(tail == "pg-sharded"),
+                      grad_comm="bf16" if G16 else "fp32")
 assert dp.shard == (tail == "pg-sharded")
 dp.broadcast_parameters()
 
@@ -68,6 +73,12 @@ for _ in range(STEPS):
     g = refs[0].grads.clone()
     for e in refs[1:]:
         g += e.grads
+    if G16:
+        nd = dp.n_dense
+        g16 = refs[0].grads[0:nd].to(torch.bfloat16)
+        for e in refs[1:]:
+            g16 = (g16.float() + e.grads[0:nd].to(torch.bfloat16).float()).to(torch.bfloat16)
+        g[0:nd] = g16.float()
     for e in refs:
         e.grads.copy_(g)
         e.launch_update()

@@ -40,6 +40,28 @@ def test_sync_1ps_2workers_hip_backend_over_gloo(gpu_lib, tmp_path, p2p):
     assert int(ck["Variable_8"]) == 24 and ck["Variable_2"].shape == (3136, 1024)
 
 
+def test_sync_bf16_gradient_collective_through_the_cli(gpu_lib, tmp_path):
+    """--grad_comm=bf16 (opt-in 16-bit collective for the fc1 weight gradient): trains, the workers stay identical, and
+    the fp32 configuration refuses it."""
+    import numpy as np
+    logdir = str(tmp_path / "logs")
+    dumps = [str(tmp_path / f"w{i}.npy") for i in range(2)]
+    out = launch(1, 2, ["--mode=sync", "--batch_size=128", "--steps=40", "--grad_comm=bf16"] + COMMON, logdir, backend="hip",
+                 per_task_extra={("worker", w): [f"--dump_params={dumps[w]}"] for w in (0, 1)})
+    _ok(out)
+    w0 = out[("worker", 0)][1]
+    assert "fc1 weight gradient communicated in bf16" in w0, w0[-2000:]
+    l0 = [float(m.group(3)) for m in DISPLAY.finditer(w0)]
+    assert l0[-1] < l0[0], l0
+    p0, p1 = (np.load(d) for d in dumps)
+    assert np.array_equal(p0, p1), "workers ended with different master weights"
+    bad = launch(1, 1, ["--mode=sync", "--batch_size=64", "--steps=4", "--grad_comm=bf16", "--dtype=fp32"] + COMMON,
+                 str(tmp_path / "logs2"), backend="hip")
+    for key in (("worker", 0), ("ps", 0)):
+        rc, o = bad[key]
+        assert rc != 0 and "--grad_comm=bf16 needs" in o, (key, o[-2000:])
+
+
 @pytest.mark.parametrize("optimizer", ["sgd", "adam"])
 def test_sync_sharded_dense_update_timed_checkpoints(gpu_lib, tmp_path, optimizer):
     """--dense_update=sharded through the CLI: each worker updates half of wd1, so the chief's TIMED checkpoints need
@@ -190,7 +212,9 @@ def test_async_parameter_server_hip_backend_over_gloo(gpu_lib, tmp_path, impl):
     ("sgd", "p2p-plain", 2, "bf16"),
     # dense message as reduce-scatter -> sharded update -> all-gather of the compute copy (sync_dp.py shard_dense)
     ("sgd", "pg-sharded", 2, "bf16"), ("adam", "pg-sharded", 2, "bf16"), ("sgd", "pg-sharded", 4, "bf16"),
-    ("sgd", "pg-sharded", 2, "fp32"), ("sgd", "p2p", 4, "bf16")])
+    ("sgd", "pg-sharded", 2, "fp32"), ("sgd", "p2p", 4, "bf16"),
+    # the fc1 weight gradient produced, summed and consumed in bf16 (grad_comm="bf16"); the replay rounds the same way
+    ("sgd", "pg-g16", 2, "bf16"), ("adam", "pg-sharded-g16", 2, "bf16")])
 # (Adam is compared at world 2 only, where the sums are exact: with three or more addends the rounding of a near-zero
 #  gradient sum changes m / sqrt(v) by O(1), so a replay comparison says nothing there)
 def test_overlapped_dp_schedule_world2_over_gloo(gpu_lib, optimizer, tail, world, dtype):

@@ -186,6 +186,39 @@ def test_sync_dp_world1_rccl_matches_plain_engine(gpu_lib, dataset):
         dp2.flush()
         torch.cuda.synchronize()
         assert torch.allclose(a2.params, b2.params, rtol=0, atol=1e-6)
+        # grad_comm="bf16" (opt-in): the fc1 weight gradient is produced, communicated and consumed in bf16.  First step:
+        # exactly the fp32 path's gradient rounded once; everything outside wd1 untouched.  Then 150 steps whose loss
+        # curve stays with the fp32-gradient run.
+        e32 = HipEngine(ModelSpec(), 128, dataset, learning_rate=0.01, seed=4, keep_prob=0.75)
+        e16 = HipEngine(ModelSpec(), 128, dataset, learning_rate=0.01, seed=4, keep_prob=0.75)
+        e32.init_params(seed=2)
+        e16.init_params(seed=2)
+        dp32 = SyncDataParallel(e32, tail_group=tail_group)
+        dp16 = SyncDataParallel(e16, tail_group=tail_group, grad_comm="bf16")
+        w0 = e16.params.clone()
+        nd = dp16.n_dense
+        dp32.train_step(); dp32.flush()
+        dp16.train_step(); dp16.flush()
+        torch.cuda.synchronize()
+        g = e32.grads[0:nd]
+        assert float(g.abs().max()) > 0
+        assert torch.equal(e16.dense_g16, g.to(torch.bfloat16))
+        assert torch.allclose(e16.params[0:nd], w0[0:nd] - 0.01 * g.to(torch.bfloat16).float(), rtol=0, atol=5e-8)
+        assert torch.equal(e16.params[nd:], e32.params[nd:])
+        assert torch.equal(e16.shadow[0:nd], e16.params[0:nd].to(torch.bfloat16))
+        l0 = e32.last_metrics()[0]
+        curve = []
+        for i in range(150):
+            dp32.train_step()
+            dp16.train_step()
+            if i % 10 == 9:
+                curve.append((e32.last_metrics()[0], e16.last_metrics()[0]))
+        dp32.flush(); dp16.flush()
+        assert curve[-1][0] < 0.5 * l0, (l0, curve)
+        for l32, l16 in curve:
+            assert abs(l16 - l32) <= 0.1 * max(l32, 0.05 * l0), curve
+        with pytest.raises(ValueError):
+            SyncDataParallel(HipEngine(ModelSpec(), 32, None, dtype="fp32"), tail_group=tail_group, grad_comm="bf16")
     finally:
         dist.destroy_process_group()
 

@@ -373,6 +373,46 @@ def test_gemm_tn(gpu_lib, M, N, K, tile):
     assert rel_err(C, ref) < 1e-4
 
 
+@pytest.mark.parametrize("M,N,K", [(3136, 1024, 128), (200, 136, 1000)])
+def test_gemm_tn_bf16_gradient_store(gpu_lib, M, N, K):
+    """The 16-bit gradient epilogue (grad_comm="bf16"): exactly the fp32 product of the plain kernel, rounded once."""
+    g = torch.Generator(device="cpu").manual_seed(9)
+    A = bf(torch.randn(K, M, generator=g) + torch.arange(M).float()[None, :] * 1e-3).to(DEV)
+    Bm = bf(torch.randn(K, N, generator=g)).to(DEV)
+    C = torch.empty(M, N, device=DEV)
+    check(gpu_lib.dtf_gemm_tn(ptr(A), ptr(Bm), ptr(C), M, N, K, M, N, N, 128, stream()), "gemm_tn")
+    C16 = torch.full((M, N), float("nan"), dtype=torch.bfloat16, device=DEV)
+    check(gpu_lib.dtf_gemm_tn_g16_ev(ptr(A), ptr(Bm), ptr(C16), M, N, K, M, N, N, None, stream()), "gemm_tn_g16")
+    assert torch.equal(C16, C.to(torch.bfloat16))
+
+
+def test_sgd_and_adam_with_bf16_gradient(gpu_lib):
+    """The optimizer kernels reading a bf16 gradient == the same kernels on that gradient widened to fp32, bit for bit."""
+    n = 4 * 1000 + 4
+    w0 = torch.randn(n, device=DEV)
+    g16 = torch.randn(n, device=DEV).to(torch.bfloat16)
+    g32 = g16.float()
+    hyper = torch.tensor([0.01, 0.9, 0.999, 1e-8, 0.5, 0, 0, 0], device=DEV)
+    outs = []
+    for wide in (True, False):
+        state = torch.zeros(8, dtype=torch.int64, device=DEV)
+        w, sh = w0.clone(), torch.empty(n, dtype=torch.bfloat16, device=DEV)
+        if wide:
+            check(gpu_lib.dtf_sgd_update(ptr(w), ptr(g32), ptr(sh), ptr(hyper), n, ptr(state), 128, 1, 1, stream()), "sgd")
+        else:
+            check(gpu_lib.dtf_sgd_update_g16(ptr(w), ptr(g16), ptr(sh), ptr(hyper), n, ptr(state), 128, 1, 1, stream()), "sgd16")
+        assert state[:4].tolist() == [128, 1, 1, 0]
+        m, v = torch.zeros(n, device=DEV), torch.zeros(n, device=DEV)
+        for _ in range(3):
+            f = gpu_lib.dtf_adam_update if wide else gpu_lib.dtf_adam_update_g16
+            check(f(ptr(w), ptr(g32 if wide else g16), ptr(m), ptr(v), ptr(sh), ptr(hyper), n, ptr(state), 3, ptr(state),
+                    0, 1, 1, stream()), "adam")
+        assert int(state[3]) == 3
+        outs.append((w, sh, m, v))
+    for a_, b_ in zip(*outs):
+        assert torch.equal(a_, b_)
+
+
 def test_transpose(gpu_lib):
     x = bf(torch.randn(3, 100, 72)).to(DEV)
     out = torch.empty(3, 72, 100, dtype=torch.bfloat16, device=DEV)
