@@ -162,7 +162,8 @@ class SyncDataParallel:
     def _allreduce(self, lo: int, hi: int, group):
         # RCCL reduces in place on the current stream; over gloo (ranks sharing one GPU in tests and rehearsals)
         # parallel/comm.py stages the range through the host -- correct, nothing overlaps
-        _pg.all_reduce_sum(self.eng.grads[lo:hi], group=group)
+        # (a dense bucket lives in the 16-bit gradient buffer when grad_comm == "bf16")
+        _pg.all_reduce_sum(self._dense_grad[lo:hi] if hi <= self.n_dense else self.eng.grads[lo:hi], group=group)
 
     def _reduce_scatter(self):
         _pg.reduce_scatter_sum_inplace(self._dense_grad, self.rank, self.world, group=self.group)
@@ -198,7 +199,7 @@ class SyncDataParallel:
         else:
             with torch.cuda.stream(self.comm_stream):
                 for lo, hi in self.dense_buckets:
-                    _pg.all_reduce_sum(self._dense_grad[lo:hi], group=self.group)
+                    self._allreduce(lo, hi, self.group)
         if tr: tr.pop(); tr.push("dp_phase2: conv backward")
         shard = self.shard and self.dense_p2p is None
         lo, hi = (self.shard_lo, self.shard_hi) if shard else (0, self.n_dense)
