@@ -28,9 +28,14 @@ struct StepAdvance {
 
 __device__ __forceinline__ void advance_state(const StepAdvance& a) {
   if (a.state && blockIdx.x == 0 && threadIdx.x == 0) {
-    a.state[0] += a.cursor_inc;
-    a.state[1] += a.step_inc;
-    a.state[2] += a.drop_inc;
+    // Only the counters this launch actually advances are touched: "+= 0" is still a read-modify-write, and the
+    // data-parallel Adam step runs two of these on different streams at once (the dense range's counter bump on the
+    // comm stream, the tail kernel's cursor / step advance on the compute stream) -- an untouched "+= 0" there wrote
+    // the OLD cursor / global step / dropout offset back over the other stream's increment (seen as a step that
+    // trained on the previous batch again, 2 runs in 8 of the two-rank Adam replay test).
+    if (a.cursor_inc) a.state[0] += a.cursor_inc;
+    if (a.step_inc) a.state[1] += a.step_inc;
+    if (a.drop_inc) a.state[2] += a.drop_inc;
     if (a.adam_slot >= 3) a.state[a.adam_slot] += 1;
   }
 }

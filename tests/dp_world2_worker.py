@@ -83,6 +83,18 @@ for _ in range(STEPS):
         e.grads.copy_(g)
         e.launch_update()
     losses.append((eng.last_metrics()[0], refs[rank].last_metrics()[0]))
+    if os.environ.get("DPW2_DIAG"):      # where does a step first differ from the replay?  (needs every update applied)
+        dp.flush()
+        torch.cuda.synchronize()
+        nd = dp.n_dense
+        r = refs[rank]
+        msg = [f"step {_ + 1}: dense {(eng.params[:nd] - r.params[:nd]).abs().max().item():.3g}",
+               f"tail {(eng.params[nd:] - r.params[nd:]).abs().max().item():.3g}",
+               f"state {eng.state.tolist()} vs {r.state.tolist()}"]
+        if optimizer == "adam":
+            msg.append(f"m dense {(eng.adam_m[:nd] - r.adam_m[:nd]).abs().max().item():.3g} "
+                       f"tail {(eng.adam_m[nd:] - r.adam_m[nd:]).abs().max().item():.3g}")
+        print(f"DIAG rank {rank} " + " | ".join(msg), flush=True)
 dp.flush()
 if dp.shard and DTYPE == "bf16":
     # the other ranks' shards of the fp32 master are stale until the (collective) gather; the compute copy is not

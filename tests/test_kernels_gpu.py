@@ -413,6 +413,32 @@ def test_sgd_and_adam_with_bf16_gradient(gpu_lib):
         assert torch.equal(a_, b_)
 
 
+def test_step_state_counters_advance_independently_on_two_streams(gpu_lib):
+    """The data-parallel Adam step bumps the dense range's step counter on the comm stream while the tail kernel advances
+    cursor / global step / dropout offset on the compute stream.  A counter advanced by 0 must not be touched at all:
+    "+= 0" wrote a stale value back over the other stream's increment (lost batches in the two-rank Adam runs)."""
+    n, iters = 256, 1500
+    w, g = torch.zeros(n, device=DEV), torch.zeros(n, device=DEV)
+    m, v = torch.zeros(n, device=DEV), torch.zeros(n, device=DEV)
+    hyper = torch.tensor([0.01, 0.9, 0.999, 1e-8, 1.0, 0, 0, 0], device=DEV)
+    state = torch.zeros(8, dtype=torch.int64, device=DEV)
+    sa, sb = torch.cuda.Stream(), torch.cuda.Stream()
+    torch.cuda.synchronize()
+    # both streams first spin for ~50 ms, so that all launches below are queued before any of them runs: the two
+    # streams then drain back to back and their one-thread kernels really overlap (launched eagerly they alternate)
+    for st in (sa, sb):
+        with torch.cuda.stream(st):
+            torch.cuda._sleep(100_000_000)
+    for _ in range(iters):
+        # stream A: Adam on a small range, bumps state[3] only (state == NULL: no cursor / step advance)
+        check(gpu_lib.dtf_adam_update(ptr(w), ptr(g), ptr(m), ptr(v), None, ptr(hyper), n, ptr(state), 3, None, 0, 0, 0,
+                                      sa.cuda_stream), "adam")
+        # stream B: the step advance
+        check(gpu_lib.dtf_advance_state(ptr(state), 64, 1, 2, sb.cuda_stream), "advance")
+    torch.cuda.synchronize()
+    assert state[:4].tolist() == [64 * iters, iters, 2 * iters, iters], state.tolist()
+
+
 def test_transpose(gpu_lib):
     x = bf(torch.randn(3, 100, 72)).to(DEV)
     out = torch.empty(3, 72, 100, dtype=torch.bfloat16, device=DEV)
