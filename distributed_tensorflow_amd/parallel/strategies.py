@@ -232,6 +232,15 @@ class SyncAllReduce:
         self.step_count += 1
         return self.step_count
 
+    def set_learning_rate(self, lr: float):
+        """Change the learning rate between two steps.  The previous step's dense update may still be pending on the
+        comm stream and reads the rate from device memory: the compute stream (where the new value is written) first
+        waits for it, otherwise that update takes the old or the new rate depending on timing -- on each replica
+        separately (GPU-side wait, no host synchronisation; only the steps of a warm-up pay it)."""
+        if self._dp is not None:
+            self._dp.flush()
+        self.b.set_learning_rate(lr)
+
     def finish(self):
         """Every worker calls this after the same last step."""
         if self._dp is not None:

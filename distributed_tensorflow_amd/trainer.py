@@ -328,7 +328,8 @@ def _train_loop(F, task, mode, backend, strategy, sv, live, timer, metrics, resu
             if lr_sched is not None:
                 lr = lr_sched(step)            # a function of the global step: the same on every synchronous worker
                 if lr != cur_lr:
-                    backend.set_learning_rate(lr)
+                    # (a strategy with updates in flight on other streams orders them first)
+                    getattr(strategy, "set_learning_rate", backend.set_learning_rate)(lr)
                     cur_lr = lr
             if tracing: trace.push(f"step {prev}")
             step = strategy.step()
