@@ -40,6 +40,22 @@ def test_sync_1ps_2workers_hip_backend_over_gloo(gpu_lib, tmp_path, p2p):
     assert int(ck["Variable_8"]) == 24 and ck["Variable_2"].shape == (3136, 1024)
 
 
+def test_sync_lr_warmup_keeps_the_replicas_identical(gpu_lib, tmp_path):
+    """A learning rate that changes every step (linear warm-up) with the overlapped schedule: the rate lives in device
+    memory and the previous step's dense update may still be pending on the comm stream when the next value is
+    written -- the strategy orders the two (SyncAllReduce.set_learning_rate); the replicas must end bit-identical."""
+    import numpy as np
+    logdir = str(tmp_path / "logs")
+    dumps = [str(tmp_path / f"w{i}.npy") for i in range(2)]
+    out = launch(1, 2, ["--mode=sync", "--batch_size=64", "--steps=40", "--p2p_allreduce", "--lr_scaling=linear",
+                        "--lr_base_batch=16", "--lr_warmup_steps=36"] + COMMON, logdir, backend="hip",
+                 per_task_extra={("worker", w): [f"--dump_params={dumps[w]}"] for w in (0, 1)})
+    _ok(out)
+    assert "dense all-reduce: peer-to-peer kernel" in out[("worker", 0)][1]
+    p0, p1 = (np.load(d) for d in dumps)
+    assert np.array_equal(p0, p1), "workers ended with different master weights"
+
+
 def test_sync_bf16_gradient_collective_through_the_cli(gpu_lib, tmp_path):
     """--grad_comm=bf16 (opt-in 16-bit collective for the fc1 weight gradient): trains, the workers stay identical, and
     the fp32 configuration refuses it."""
