@@ -26,6 +26,10 @@ namespace dtf {
 
 enum { EPI_STORE = 0, EPI_BIAS_RELU_DROPOUT = 1, EPI_NOSTORE_DIAG = 2 };
 
+#ifndef DTF_GEMM_DMA_DEFAULT
+#define DTF_GEMM_DMA_DEFAULT 5
+#endif
+
 // ---------------------------------------------------------------------------------------------
 // Shared software pipeline.  One K tile (BK = 64) per phase, double-buffered LDS, two register
 // sets: the global loads of tile t+2 are issued at the head of phase t and written to LDS at the
@@ -79,13 +83,104 @@ __device__ __forceinline__ void gemm_pipeline(int T, GL&& gload, SW&& swrite, CP
   }
 }
 
+// ---------------------------------------------------------------------------------------------
+// LDS-DMA pipeline of the 128 x 128 x 8-wave kernels (round 2): `buffer_load_dwordx4 ... lds` writes the operand
+// tiles straight into LDS -- no VGPR round trip and no ds_write_b128 on the LDS store path (13 cycles per
+// wave-instruction, which together with the fragment reads made the register-staged loop LDS-bound at 2.3 x its MFMA
+// time).  FOUR LDS buffers, tile t in buffer t % 4:
+//   phase t:  issue the DMA of tile t+3 | read the fragments of tile t+1 | MFMAs on the fragments of tile t (read in
+//             phase t-1) | s_waitcnt vmcnt(4) | s_barrier
+// A DMA writes wave-uniform base + lane * 16 bytes, so the LDS images are linear per wave-instruction and every
+// swizzle is applied to the SOURCE chunk a lane fetches.  Ordering (guide: read a staged buffer one phase AFTER the
+// wait that retires it): vmcnt(4) at the end of phase t leaves only tile t+3's four DMAs of this wave in flight, so
+// its parts of tile t+2 have landed; after the barrier every wave's have, and phase t+1 reads them.  Buffer (t+3) % 4
+// held tile t-1, whose fragments were read in phase t-2 and consumed by the MFMAs of phase t-1: free at phase t.
+// DMAs past the last tile read zeros (beyond the descriptor) or in-range data into buffers that are never multiplied.
+// Every kernel using it stages exactly 2 + 2 sixteen-byte chunks per thread and tile (the 4 in vmcnt(4)).
+// Measured (tools/scratch/gemm_tile_ab.py, fc1 dgrad shape): 13.8 -> 11.1 us; 45.0 -> 39.5 us at 4096 rows.
+// ---------------------------------------------------------------------------------------------
+// one 16-byte LDS-DMA per lane: LDS destination = lds (wave-uniform) + lane * 16, source = buffer offset voff + soff
+__device__ __forceinline__ void dma16(__amdgpu_buffer_rsrc_t r, const void* lds, uint32_t voff, uint32_t soff) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  typedef __attribute__((address_space(3))) void lds_void;
+  __builtin_amdgcn_raw_ptr_buffer_load_lds(r, (lds_void*)lds, 16, voff, soff, 0, 0);
+#else
+  (void)r; (void)lds; (void)voff; (void)soff;
+#endif
+}
+
+// Transposed LDS read for the DMA-staged kernels.  Through the compiler's builtin, every ds_read_b64_tr_b16 that follows an
+// LDS-DMA gets an `s_waitcnt vmcnt(0)` in front of it (the builtin is modelled as reading any memory, so it "may alias"
+// the pending DMA writes): the prefetch depth collapses to zero and the kernel runs 10-15 % SLOWER than the register-
+// staged one (measured).  As inline asm the read is invisible to that pass; gemm_pipeline_dma4 retires these reads
+// itself with `s_waitcnt lgkmcnt(0)` at the end of the phase that issued them (they are consumed one phase later).
+typedef __attribute__((ext_vector_type(4))) short dma_s16x4;
+__device__ __forceinline__ dma_s16x4 lds_tr_read_b64(const bf16* p) {
+  dma_s16x4 v;
+  const uint32_t a = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) const void*)p;
+  asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(v) : "v"(a));
+  return v;
+}
+
+// The same for a plain 16-byte fragment read where the compiler orders it against the pending DMAs of its own array
+// (split-K NN kernel: `s_waitcnt vmcnt(2)` in front of the A-fragment reads of every phase).
+__device__ __forceinline__ bf16x8 lds_read_b128(const bf16* p) {
+  u32x4 v;
+  const uint32_t a = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) const void*)p;
+  asm volatile("ds_read_b128 %0, %1" : "=v"(v) : "v"(a));
+  return __builtin_bit_cast(bf16x8, v);
+}
+
+template <class FR, class DM, class LF, class MM>
+__device__ __forceinline__ void gemm_pipeline_dma4(int T, DM&& dma, LF&& load_frags, MM&& mma) {
+  FR f0, f1;
+  DTF_GSTAMP(0);
+  // No tile past the last one is fetched: a workgroup of the split-K forward walks 13 tiles, and three useless ones
+  // were +23 % of its operand traffic (and a drain of their latency at the end).  Where nothing new is issued the
+  // wait is vmcnt(0): whatever is still in flight is exactly the tile the next phase reads.
+  dma(0, 0);
+  if (T > 1) dma(1, 1);
+  if (T > 2) {
+    dma(2, 2);
+    asm volatile("s_waitcnt vmcnt(4)" ::: "memory");   // tiles 0 and 1 landed (this wave's parts)
+  } else {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  }
+  __builtin_amdgcn_s_barrier();
+  DTF_GSTAMP(1);
+  load_frags(f0, 0);
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // (fragment reads issued as inline asm: see lds_tr_read_b64)
+#pragma unroll 1
+  for (int t = 0; t < T; t += 4) {
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      if (t + u < T) {
+        const bool more = t + u + 3 < T;
+        if (more) dma(t + u + 3, (u + 3) % 4);
+        if (t + u + 1 < T) load_frags((u & 1) ? f0 : f1, (u + 1) % 4);
+        mma((u & 1) ? f1 : f0);
+        if (more) asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+      }
+    }
+  }
+  // (nothing is in flight here; the last barrier above also orders the LDS for an epilogue that reuses it)
+}
+
+template <int MT, int NTL>
+struct GemmFrags {
+  bf16x8 a[2][MT], b[2][NTL];
+};
+
 // HEADW: the launch is a 1-D grid of the GEMM's tiles FOLLOWED by hw.nbx * KS workgroups that compute the
 // output-layer weight gradient (head_wgrad_core.hpp) -- independent work that fills the CUs this GEMM
 // leaves idle (fc1 dgrad: 200 tiles on 256 CUs) instead of paying for a launch of its own.
 // WAVES_M x (NW / WAVES_M) waves.  The 256 x 128 tile runs 4 x 2 waves of 64 x 64: 8 fragment reads per 16 MFMAs
 // instead of the 128 x 128 tile's 6 per 8, and 1.5 instead of 2 staged bytes per MAC -- the 128 x 128 loop is bound
 // by the LDS (ds_write_b128 store path + fragment reads), not by the MFMA pipe.
-template <int BM, int BN, int NW, int EPI, bool HEADW = false, int WAVES_M = 2>
+// DMA: LDS-DMA staging through gemm_pipeline_dma4 (128 x 128 x 8 waves only) instead of the register-staged pipeline.
+template <int BM, int BN, int NW, int EPI, bool HEADW = false, int WAVES_M = 2, bool DMA = false>
 __global__ __launch_bounds__(NW * 64, DTF_GEMM_MINW) void gemm_nt_bf16(const bf16* A, const bf16* Bm, bf16* __restrict__ C,
                                                         const float* __restrict__ bias, int M, int N, int K,
                                                         int lda, int ldb, int ldc, DropoutArgs drop,
@@ -95,9 +190,11 @@ __global__ __launch_bounds__(NW * 64, DTF_GEMM_MINW) void gemm_nt_bf16(const bf1
   constexpr int WM = BM / WAVES_M, WN = BN / WAVES_N;
   constexpr int MT = WM / 16, NTL = WN / 16;
   constexpr int A_CH = BM * 8 / NT, B_CH = BN * 8 / NT;  // 16-byte chunks per thread
+  constexpr int NBUF = DMA ? 4 : 2;
+  static_assert(!DMA || (A_CH == 2 && B_CH == 2), "gemm_pipeline_dma4 counts 2 + 2 DMAs per thread and tile");
   __shared__ __attribute__((aligned(16))) struct {   // one object: the head wgrad workgroups use it as one scratch area
-    bf16 a[2][BM * BK];
-    bf16 b[2][BN * BK];
+    bf16 a[NBUF][BM * BK];
+    bf16 b[NBUF][BN * BK];
   } sm;
   auto& sA = sm.a;
   auto& sB = sm.b;
@@ -182,7 +279,56 @@ __global__ __launch_bounds__(NW * 64, DTF_GEMM_MINW) void gemm_nt_bf16(const bf1
         for (int j = 0; j < NTL; ++j) acc[i][j] = mfma16(af[kk][i], bfv[kk][j], acc[i][j]);
   };
 
-  gemm_pipeline<A_CH, B_CH>(K / BK, gload, swrite, compute);
+  if constexpr (DMA) {
+    // LDS chunk position (row, p) of a lane <- global chunk p ^ (row & 7) of that row: the same swizzled image
+    uint32_t da[A_CH], db[B_CH];
+#pragma unroll
+    for (int i = 0; i < A_CH; ++i) {
+      const int c = tid + i * NT, row = c >> 3, p = c & 7;
+      da[i] = (uint32_t)(m0 + row) * (uint32_t)(lda * 2) + ((p ^ (row & 7)) << 4);
+    }
+#pragma unroll
+    for (int i = 0; i < B_CH; ++i) {
+      const int c = tid + i * NT, row = c >> 3, p = c & 7;
+      db[i] = (uint32_t)(n0 + row) * (uint32_t)(ldb * 2) + ((p ^ (row & 7)) << 4);
+    }
+    auto dma = [&](int t, int buf) {
+      const uint32_t so = (uint32_t)t * (BK * 2);
+#pragma unroll
+      for (int i = 0; i < A_CH; ++i)
+        dma16(rA, sA[buf] + (wave * 64 + i * NT) * 8, da[i], so);
+#pragma unroll
+      for (int i = 0; i < B_CH; ++i)
+        dma16(rB, sB[buf] + (wave * 64 + i * NT) * 8, db[i], so);
+    };
+    typedef GemmFrags<MT, NTL> FR;
+    auto load_frags = [&](FR& f, int buf) {
+#pragma unroll
+      for (int kk = 0; kk < 2; ++kk) {
+#pragma unroll
+        for (int i = 0; i < MT; ++i) {
+          int row = wm * WM + i * 16 + i16;
+          f.a[kk][i] = *reinterpret_cast<const bf16x8*>(sA[buf] + row * BK + (((kk * 4 + g) ^ (row & 7)) << 3));
+        }
+#pragma unroll
+        for (int j = 0; j < NTL; ++j) {
+          int row = wn * WN + j * 16 + i16;
+          f.b[kk][j] = *reinterpret_cast<const bf16x8*>(sB[buf] + row * BK + (((kk * 4 + g) ^ (row & 7)) << 3));
+        }
+      }
+    };
+    auto mma = [&](const FR& f) {
+#pragma unroll
+      for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+        for (int i = 0; i < MT; ++i)
+#pragma unroll
+          for (int j = 0; j < NTL; ++j) acc[i][j] = mfma16(f.a[kk][i], f.b[kk][j], acc[i][j]);
+    };
+    gemm_pipeline_dma4<FR>(K / BK, dma, load_frags, mma);
+  } else {
+    gemm_pipeline<A_CH, B_CH>(K / BK, gload, swrite, compute);
+  }
   DTF_GSTAMP(2);
 
   uint64_t drop_off = 0;
@@ -219,19 +365,24 @@ __global__ __launch_bounds__(NW * 64, DTF_GEMM_MINW) void gemm_nt_bf16(const bf1
 // parallelism the gradient has to exist for the all-reduce.
 // G16 = true: C is a bf16 matrix (the gradient goes out in bf16: the opt-in 16-bit dense collective of
 // parallel/sync_dp.py, half the bytes on the links).
-template <int BM, int BN, int NW, bool SGD = false, bool G16 = false>
+// DMA (128 x 128 x 8 waves): LDS-DMA staging through gemm_pipeline_dma4; the K-slow images are then unpadded 256-byte
+// rows with their 32-byte windows XORed by (row & 7) (the eight rows of a transposed read's lane group land in eight
+// different windows, which is what the +32-byte pitch does for the register-staged image).
+template <int BM, int BN, int NW, bool SGD = false, bool G16 = false, bool DMA = false>
 __global__ __launch_bounds__(NW * 64, DTF_GEMM_MINW) void gemm_tn_bf16(const bf16* A, const bf16* Bm, float* __restrict__ C,
                                                         int M, int N, int K, int lda, int ldb, int ldc,
                                                         bf16* __restrict__ shadow = nullptr,
                                                         const float* __restrict__ hyper = nullptr) {
   constexpr int BK = 64, NT = NW * 64;
-  constexpr int PA = BM + 16, PB = BN + 16;  // row pitch in elements (+32 B)
+  constexpr int PA = DMA ? BM : BM + 16, PB = DMA ? BN : BN + 16;  // row pitch in elements (+32 B when register-staged)
+  constexpr int NBUF = DMA ? 4 : 2;
   constexpr int WAVES_N = NW / 2;
   constexpr int WM = BM / 2, WN = BN / WAVES_N;
   constexpr int MT = WM / 16, NTL = WN / 16;
   constexpr int A_CH = BK * (BM / 8) / NT, B_CH = BK * (BN / 8) / NT;
-  __shared__ __attribute__((aligned(16))) bf16 sA[2][BK * PA];
-  __shared__ __attribute__((aligned(16))) bf16 sB[2][BK * PB];
+  static_assert(!DMA || (A_CH == 2 && B_CH == 2 && BM == 128 && BN == 128), "gemm_pipeline_dma4: 2 + 2 DMAs per thread and tile");
+  __shared__ __attribute__((aligned(16))) bf16 sA[NBUF][BK * PA];
+  __shared__ __attribute__((aligned(16))) bf16 sB[NBUF][BK * PB];
 
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wave / WAVES_N, wn = wave % WAVES_N;
@@ -307,7 +458,55 @@ __global__ __launch_bounds__(NW * 64, DTF_GEMM_MINW) void gemm_tn_bf16(const bf1
         for (int j = 0; j < NTL; ++j) acc[i][j] = mfma16(af[kk][i], bfv[kk][j], acc[i][j]);
   };
 
-  gemm_pipeline<A_CH, B_CH>((K + BK - 1) / BK, gload, swrite, compute);
+  if constexpr (DMA) {
+    uint32_t da[A_CH], db[B_CH];
+#pragma unroll
+    for (int i = 0; i < A_CH; ++i) {
+      // LDS chunk (row, p) of 16 per row <- global chunk p ^ ((row & 7) << 1)
+      const int c = tid + i * NT, row = c >> 4, p = c & 15;
+      da[i] = (uint32_t)row * (uint32_t)(lda * 2) + (uint32_t)m0 * 2 + ((p ^ ((row & 7) << 1)) << 4);
+    }
+#pragma unroll
+    for (int i = 0; i < B_CH; ++i) {
+      const int c = tid + i * NT, row = c >> 4, p = c & 15;
+      db[i] = (uint32_t)row * (uint32_t)(ldb * 2) + (uint32_t)n0 * 2 + ((p ^ ((row & 7) << 1)) << 4);
+    }
+    auto dma = [&](int t, int buf) {
+#pragma unroll
+      for (int i = 0; i < A_CH; ++i) dma16(rA, sA[buf] + (wave * 64 + i * NT) * 8, da[i], (uint32_t)t * stepA);
+#pragma unroll
+      for (int i = 0; i < B_CH; ++i) dma16(rB, sB[buf] + (wave * 64 + i * NT) * 8, db[i], (uint32_t)t * stepB);
+    };
+    // rows kk*32 + 4g + qr (+16): key = (4g + qr) & 7 for both; column window col0 / 16
+    const int key = (4 * g + qr) & 7;
+    auto tr_frag_sw = [&](const bf16* base, int kk, int col0) -> bf16x8 {
+      const bf16* p0 = base + (kk * 32 + 4 * g + qr) * BM + (((col0 >> 4) ^ key) << 4) + 4 * pc;
+      const dma_s16x4 lo = lds_tr_read_b64(p0), hi = lds_tr_read_b64(p0 + 16 * BM);
+      s16x8 v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+      return __builtin_bit_cast(bf16x8, v);
+    };
+    typedef GemmFrags<MT, NTL> FR;
+    auto load_frags = [&](FR& f, int buf) {
+#pragma unroll
+      for (int kk = 0; kk < 2; ++kk) {
+#pragma unroll
+        for (int i = 0; i < MT; ++i) f.a[kk][i] = tr_frag_sw(sA[buf], kk, wm * WM + i * 16);
+#pragma unroll
+        for (int j = 0; j < NTL; ++j) f.b[kk][j] = tr_frag_sw(sB[buf], kk, wn * WN + j * 16);
+      }
+    };
+    auto mma = [&](const FR& f) {
+#pragma unroll
+      for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+        for (int i = 0; i < MT; ++i)
+#pragma unroll
+          for (int j = 0; j < NTL; ++j) acc[i][j] = mfma16(f.a[kk][i], f.b[kk][j], acc[i][j]);
+    };
+    gemm_pipeline_dma4<FR>((K + BK - 1) / BK, dma, load_frags, mma);
+  } else {
+    gemm_pipeline<A_CH, B_CH>((K + BK - 1) / BK, gload, swrite, compute);
+  }
   DTF_GSTAMP(2);
 
   if constexpr (SGD) {
@@ -317,7 +516,7 @@ __global__ __launch_bounds__(NW * 64, DTF_GEMM_MINW) void gemm_tn_bf16(const bf1
     // four row groups of a store land on different banks) and every thread then updates float4s.
     static_assert(BM == 128 && BN == 128 && NW == 8, "SGD epilogue is written for the 128x128x8-wave tile");
     constexpr int GP = BN + 4;
-    static_assert(64 * GP * 4 <= BK * PA * 2 * 2, "gradient half-tile must fit an operand's LDS buffers");
+    static_assert(64 * GP * 4 <= BK * PA * 2 * NBUF, "gradient half-tile must fit an operand's LDS buffers");
     // All eight master-weight float4s of this thread are requested up front, before the gradient tile is
     // even staged: C is loaded AND stored below, so the compiler keeps "load k+1" behind "store k" and the
     // update was a chain of eight dependent memory round trips (clamped addresses: the loads are unconditional).
@@ -381,19 +580,26 @@ __global__ __launch_bounds__(NW * 64, DTF_GEMM_MINW) void gemm_tn_bf16(const bf1
 // gemm_nt.  B fragments: ds_read_b64_tr_b16 with rows 8g+q / 8g+4+q so that element j of lane
 // group g is k = 8g + j on BOTH operands; the two 128-byte halves of every row with bit 3 set are
 // swapped, which makes these transposed reads bank-conflict free (rows r and r+8 would collide).
-template <int BM, int BN, int NW>
+// DMA (128 x 128 x 8 waves): LDS-DMA staging through gemm_pipeline_dma4.  The B image is then UNPADDED 256-byte rows
+// whose 32-byte windows are XORed with key(r) = (r & 3) | ((r >> 3) & 1) << 2: the eight rows a 32-lane group of a
+// transposed read touches ({0..3} and {8..11} of a 16-row block, same column window) land in eight different windows
+// (what the +32-byte row padding and the half swap achieve in the register-staged image; a DMA cannot write a padded
+// image, one wave-instruction covers four whole rows).
+template <int BM, int BN, int NW, bool DMA = false>
 __global__ __launch_bounds__(NW * 64, DTF_GEMM_MINW) void gemm_nn_splitk_bf16(const bf16* A, const bf16* Bm,
                                                                float* __restrict__ Cp, int M, int N, int K,
                                                                int lda, int ldb, int tiles_per_split) {
   static_assert(BN == 128, "the half-swap swizzle below assumes 256-byte B rows");
   constexpr int BK = 64, NT = NW * 64;
-  constexpr int PB = BN + 16;
+  constexpr int PB = DMA ? BN : BN + 16;
+  constexpr int NBUF = DMA ? 4 : 2;
   constexpr int WAVES_N = NW / 2;
   constexpr int WM = BM / 2, WN = BN / WAVES_N;
   constexpr int MT = WM / 16, NTL = WN / 16;
   constexpr int A_CH = BM * 8 / NT, B_CH = BK * (BN / 8) / NT;
-  __shared__ __attribute__((aligned(16))) bf16 sA[2][BM * BK];
-  __shared__ __attribute__((aligned(16))) bf16 sB[2][BK * PB];
+  static_assert(!DMA || (A_CH == 2 && B_CH == 2), "gemm_pipeline_dma4 counts 2 + 2 DMAs per thread and tile");
+  __shared__ __attribute__((aligned(16))) bf16 sA[NBUF][BM * BK];
+  __shared__ __attribute__((aligned(16))) bf16 sB[NBUF][BK * PB];
 
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wave / WAVES_N, wn = wave % WAVES_N;
@@ -476,7 +682,59 @@ __global__ __launch_bounds__(NW * 64, DTF_GEMM_MINW) void gemm_nn_splitk_bf16(co
         for (int j = 0; j < NTL; ++j) acc[i][j] = mfma16(af[kk][i], bfv[kk][j], acc[i][j]);
   };
 
-  if (T > 0) gemm_pipeline<A_CH, B_CH>(T, gload, swrite, compute);
+  if constexpr (DMA) {
+    uint32_t da[A_CH], db[B_CH];
+#pragma unroll
+    for (int i = 0; i < A_CH; ++i) {
+      const int c = tid + i * NT, row = c >> 3, p = c & 7;
+      da[i] = (uint32_t)(m0 + row) * (uint32_t)(lda * 2) + ((p ^ (row & 7)) << 4) + (uint32_t)t_begin * (BK * 2);
+    }
+#pragma unroll
+    for (int i = 0; i < B_CH; ++i) {
+      // LDS chunk (row, p) of 16 per row <- global chunk p ^ (key(row) << 1)
+      const int c = tid + i * NT, row = c >> 4, p = c & 15;
+      const int key = (row & 3) | (((row >> 3) & 1) << 2);
+      db[i] = (uint32_t)(t_begin * BK + row) * (uint32_t)(ldb * 2) + (uint32_t)n0 * 2 + ((p ^ (key << 1)) << 4);
+    }
+    auto dma = [&](int t, int buf) {
+#pragma unroll
+      for (int i = 0; i < A_CH; ++i) dma16(rA, sA[buf] + (wave * 64 + i * NT) * 8, da[i], (uint32_t)t * (BK * 2));
+#pragma unroll
+      for (int i = 0; i < B_CH; ++i) dma16(rB, sB[buf] + (wave * 64 + i * NT) * 8, db[i], (uint32_t)t * stepB);
+    };
+    typedef GemmFrags<MT, NTL> FR;
+    auto load_frags = [&](FR& f, int buf) {
+#pragma unroll
+      for (int kk = 0; kk < 2; ++kk) {
+#pragma unroll
+        for (int i = 0; i < MT; ++i) {
+          int row = wm * WM + i * 16 + i16;
+          f.a[kk][i] = lds_read_b128(sA[buf] + row * BK + (((kk * 4 + g) ^ (row & 7)) << 3));
+        }
+#pragma unroll
+        for (int j = 0; j < NTL; ++j) {
+          // rows kk*32 + 8g + qr and +4: key = qr | (g & 1) << 2 for both; column window (wn * WN + j * 16) / 16
+          const int r0 = kk * 32 + 8 * g + qr;
+          const int win = ((wn * WN) / 16 + j) ^ (qr | ((g & 1) << 2));
+          const bf16* p0 = sB[buf] + r0 * PB + win * 16 + 4 * pc;
+          const dma_s16x4 lo = lds_tr_read_b64(p0), hi = lds_tr_read_b64(p0 + 4 * PB);
+          s16x8 v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+          f.b[kk][j] = __builtin_bit_cast(bf16x8, v);
+        }
+      }
+    };
+    auto mma = [&](const FR& f) {
+#pragma unroll
+      for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+        for (int i = 0; i < MT; ++i)
+#pragma unroll
+          for (int j = 0; j < NTL; ++j) acc[i][j] = mfma16(f.a[kk][i], f.b[kk][j], acc[i][j]);
+    };
+    if (T > 0) gemm_pipeline_dma4<FR>(T, dma, load_frags, mma);
+  } else {
+    if (T > 0) gemm_pipeline<A_CH, B_CH>(T, gload, swrite, compute);
+  }
   DTF_GSTAMP(2);
 
   float* C = Cp + (size_t)blockIdx.z * M * N;
@@ -549,6 +807,28 @@ extern "C" int dtf_gemm_set_timing_buf(void* p) {
 }
 #endif
 
+// Which 128 x 128 kernels stage through LDS-DMA (gemm_pipeline_dma4): bit 0 NT (fc1 dgrad), bit 1 NN (split-K forward),
+// bit 2 TN (fc1 wgrad).  Stand-alone every one of them is 15-28 % faster than its register-staged twin; what counts is
+// the STEP, and there the chip's clock management couples the kernels (a denser GEMM lowers the clock the conv kernels
+// run at: rocprof shows them 7 % slower next to the DMA GEMMs).  Measured per mask on two devices, interleaved runs
+// (tools/scratch/gemm_dma_mask_ab.sh): at 1024 images NT + TN = -3.1 / -3.4 % step time, with the forward as well +1 %;
+// at 2048 images and up (backward fork/join on side streams: the GEMMs overlap other kernels, and a 128 KiB workgroup
+// cannot share a CU with them) TN is +3.6 % and NT neutral.  Default: NT and TN, only while the batch dimension is at
+// most 1024.  DTF_GEMM_DMA=<mask> forces a mask for every shape (A/B runs).
+static int gemm_dma_forced() {
+  static int mask = -2;
+  if (mask == -2) {
+    const char* v = getenv("DTF_GEMM_DMA");
+    mask = v ? (atoi(v) & 7) : -1;
+  }
+  return mask;
+}
+static bool gemm_dma_use(int bit, int batch_dim) {
+  const int forced = gemm_dma_forced();
+  if (forced >= 0) return (forced & bit) != 0;
+  return (DTF_GEMM_DMA_DEFAULT & bit) != 0 && batch_dim <= 1024;
+}
+
 extern "C" {
 
 // C[M,N] bf16 = A[M,K] . B[N,K]^T ; epi 0 = store, 1 = bias+relu+dropout
@@ -561,11 +841,22 @@ int dtf_gemm_nt(const void* A, const void* B, void* C, const void* bias, int M, 
   // 256 x 128 tiles once they fill the machine 1.5 times over (measured on MI355X: M 4096, N 3136, K 1024: 42.2 vs 49.1 us;
   // M 1024, N 12544, K 4096: 134 vs 149 us; at M 1024, N 3136 their 100 tiles leave 60 % of the CUs idle: 21.9 vs 14.0 us)
   if (tile == 128 && epi == 0 && (long)((M + 255) / 256) * ((N + 127) / 128) >= 384) tile = 256;
+  // 128 x 128 tiles stage through LDS-DMA (gemm_pipeline_dma4); 64 x 64 and 256 x 128 through registers
 #define NT_CASE(BMN, E)                                                                               \
+  if (BMN == 128 && gemm_dma_use(1, M))                                                               \
+    hipLaunchKernelGGL((gemm_nt_bf16<BMN, BMN, BMN / 16, E, false, 2, BMN == 128>),                   \
+                       dim3((N + BMN - 1) / BMN, (M + BMN - 1) / BMN), dim3(BMN * 4), 0, s, (const bf16*)A, \
+                       (const bf16*)B, (bf16*)C, (const float*)bias, M, N, K, lda, ldb, ldc, d, HeadWgradArgs{}); \
+  else NT_CASE_REG(BMN, E)
+#define NT_CASE_REG(BMN, E)                                                                           \
   hipLaunchKernelGGL((gemm_nt_bf16<BMN, BMN, BMN / 16, E>),                                           \
                      dim3((N + BMN - 1) / BMN, (M + BMN - 1) / BMN), dim3(BMN * 4), 0, s, (const bf16*)A, \
                      (const bf16*)B, (bf16*)C, (const float*)bias, M, N, K, lda, ldb, ldc, d, HeadWgradArgs{})
   if (tile == 128 && epi == 0) NT_CASE(128, EPI_STORE);
+  else if (tile == 129 && epi == 0) NT_CASE_REG(128, EPI_STORE);   // register-staged pipeline regardless of the default
+  else if (tile == 130 && epi == 0)                                // LDS-DMA pipeline regardless of the default
+    hipLaunchKernelGGL((gemm_nt_bf16<128, 128, 8, EPI_STORE, false, 2, true>), dim3((N + 127) / 128, (M + 127) / 128), dim3(512), 0,
+                       s, (const bf16*)A, (const bf16*)B, (bf16*)C, (const float*)bias, M, N, K, lda, ldb, ldc, d, HeadWgradArgs{});
   else if (tile == 128 && epi == 1) NT_CASE(128, EPI_BIAS_RELU_DROPOUT);
   else if (tile == 64 && epi == 0) NT_CASE(64, EPI_STORE);
   else if (tile == 64 && epi == 1) NT_CASE(64, EPI_BIAS_RELU_DROPOUT);
@@ -576,6 +867,7 @@ int dtf_gemm_nt(const void* A, const void* B, void* C, const void* bias, int M, 
   else if (tile == 64 && epi == 2) NT_CASE(64, EPI_NOSTORE_DIAG);
   else return -1;
 #undef NT_CASE
+#undef NT_CASE_REG
   return (int)hipGetLastError();
 }
 
@@ -602,9 +894,13 @@ int dtf_gemm_nt_head_wgrad(const void* A, const void* Bw, void* C, int M, int N,
   HeadWgradArgs hw{(const bf16*)h1, (const float*)dlogits, (const bf16*)da, (float*)part, Bsz, H, (Bsz + KS - 1) / KS,
                    (H + kHeadCols - 1) / kHeadCols};
   DropoutArgs d{1.0f, 0, nullptr};
-  hipLaunchKernelGGL((gemm_nt_bf16<128, 128, 8, EPI_STORE, true>), dim3((unsigned)(tiles + (long)hw.nbx * KS)), dim3(512),
-                     0, s, (const bf16*)A, (const bf16*)Bw, (bf16*)C, (const float*)nullptr, M, N, K, lda, ldb, ldc, d,
-                     hw);
+  if (gemm_dma_use(1, M))
+    hipLaunchKernelGGL((gemm_nt_bf16<128, 128, 8, EPI_STORE, true, 2, true>), dim3((unsigned)(tiles + (long)hw.nbx * KS)),
+                       dim3(512), 0, s, (const bf16*)A, (const bf16*)Bw, (bf16*)C, (const float*)nullptr, M, N, K, lda, ldb,
+                       ldc, d, hw);
+  else
+    hipLaunchKernelGGL((gemm_nt_bf16<128, 128, 8, EPI_STORE, true>), dim3((unsigned)(tiles + (long)hw.nbx * KS)), dim3(512),
+                       0, s, (const bf16*)A, (const bf16*)Bw, (bf16*)C, (const float*)nullptr, M, N, K, lda, ldb, ldc, d, hw);
   return (int)hipGetLastError();
 }
 
@@ -616,8 +912,11 @@ int dtf_gemm_tn_ev(const void* A, const void* B, void* C, int M, int N, int K, i
                    int tile, hipEvent_t done, hipStream_t s) {
   if ((lda & 7) || (ldb & 7) || (M & 7) || (N & 7)) return -3;
   if (tile == 0) tile = ((long)((M + 127) / 128) * ((N + 127) / 128) >= 192) ? 128 : 64;
-  if (tile == 128)
-    hipExtLaunchKernelGGL((gemm_tn_bf16<128, 128, 8>), dim3((N + 127) / 128, (M + 127) / 128), dim3(512), 0, s, nullptr,
+  // tile codes 129 / 130: the 128 x 128 tile with register staging / LDS-DMA staging regardless of the default (tests, A/B)
+  if (tile == 128 || tile == 129 || tile == 130)
+    hipExtLaunchKernelGGL(((tile == 130 || (tile == 128 && gemm_dma_use(4, K))) ? gemm_tn_bf16<128, 128, 8, false, false, true>
+                                                                                : gemm_tn_bf16<128, 128, 8>),
+                          dim3((N + 127) / 128, (M + 127) / 128), dim3(512), 0, s, nullptr,
                           done, 0, (const bf16*)A, (const bf16*)B, (float*)C, M, N, K, lda, ldb, ldc, (bf16*)nullptr,
                           (const float*)nullptr);
   else if (tile == 64)
@@ -632,7 +931,8 @@ int dtf_gemm_tn_ev(const void* A, const void* B, void* C, int M, int N, int K, i
 int dtf_gemm_tn_g16_ev(const void* A, const void* B, void* C, int M, int N, int K, int lda, int ldb, int ldc,
                        hipEvent_t done, hipStream_t s) {
   if ((lda & 7) || (ldb & 7) || (M & 7) || (N & 7)) return -3;
-  hipExtLaunchKernelGGL((gemm_tn_bf16<128, 128, 8, false, true>), dim3((N + 127) / 128, (M + 127) / 128), dim3(512), 0, s,
+  hipExtLaunchKernelGGL((gemm_dma_use(4, K) ? gemm_tn_bf16<128, 128, 8, false, true, true> : gemm_tn_bf16<128, 128, 8, false, true>),
+                        dim3((N + 127) / 128, (M + 127) / 128), dim3(512), 0, s,
                         nullptr, done, 0, (const bf16*)A, (const bf16*)B, (float*)C, M, N, K, lda, ldb, ldc, (bf16*)nullptr,
                         (const float*)nullptr);
   return (int)hipGetLastError();
@@ -646,7 +946,8 @@ int dtf_gemm_tn(const void* A, const void* B, void* C, int M, int N, int K, int 
 int dtf_gemm_tn_sgd(const void* A, const void* B, void* W, void* shadow, const void* hyper, int M, int N, int K,
                     int lda, int ldb, int ldw, hipStream_t s) {
   if ((lda & 7) || (ldb & 7) || (M & 7) || (N & 7) || (ldw & 3) || !shadow || !hyper) return -3;
-  hipLaunchKernelGGL((gemm_tn_bf16<128, 128, 8, true>), dim3((N + 127) / 128, (M + 127) / 128), dim3(512), 0, s,
+  hipLaunchKernelGGL((gemm_dma_use(4, K) ? gemm_tn_bf16<128, 128, 8, true, false, true> : gemm_tn_bf16<128, 128, 8, true>),
+                     dim3((N + 127) / 128, (M + 127) / 128), dim3(512), 0, s,
                      (const bf16*)A, (const bf16*)B, (float*)W, M, N, K, lda, ldb, ldw, (bf16*)shadow,
                      (const float*)hyper);
   return (int)hipGetLastError();
@@ -666,7 +967,8 @@ int dtf_gemm_nn_fwd(const void* A, const void* B, void* part, void* out, const v
   if (S > T) S = T;
   const int tps = (T + S - 1) / S;
   S = (T + tps - 1) / tps;
-  hipLaunchKernelGGL((gemm_nn_splitk_bf16<128, 128, 8>), dim3((N + 127) / 128, (M + 127) / 128, S), dim3(512), 0, s,
+  hipLaunchKernelGGL((gemm_dma_use(2, M) ? gemm_nn_splitk_bf16<128, 128, 8, true> : gemm_nn_splitk_bf16<128, 128, 8>),
+                     dim3((N + 127) / 128, (M + 127) / 128, S), dim3(512), 0, s,
                      (const bf16*)A, (const bf16*)B, (float*)part, M, N, K, lda, ldb, tps);
   DropoutArgs d{keep_prob, seed, (const int64_t*)state};
   const long MN = (long)M * N;
@@ -692,7 +994,8 @@ int dtf_gemm_nn_partial(const void* A, const void* B, void* part, int M, int N, 
   if (S > T) S = T;
   const int tps = (T + S - 1) / S;
   S = (T + tps - 1) / tps;
-  hipLaunchKernelGGL((gemm_nn_splitk_bf16<128, 128, 8>), dim3((N + 127) / 128, (M + 127) / 128, S), dim3(512), 0, s,
+  hipLaunchKernelGGL((gemm_dma_use(2, M) ? gemm_nn_splitk_bf16<128, 128, 8, true> : gemm_nn_splitk_bf16<128, 128, 8>),
+                     dim3((N + 127) / 128, (M + 127) / 128, S), dim3(512), 0, s,
                      (const bf16*)A, (const bf16*)B, (float*)part, M, N, K, lda, ldb, tps);
   return hipGetLastError() == hipSuccess ? S : -1;
 }

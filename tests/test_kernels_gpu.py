@@ -315,7 +315,8 @@ def test_gemm_nt_256x128_tile(gpu_lib, M, N, K):
 
 
 
-@pytest.mark.parametrize("M,N,K,S", [(1024, 1024, 3136, 0), (100, 1024, 3136, 0), (257, 384, 192, 3), (64, 128, 64, 1)])
+@pytest.mark.parametrize("M,N,K,S", [(1024, 1024, 3136, 0), (100, 1024, 3136, 0), (257, 384, 192, 3), (64, 128, 64, 1),
+                                     (130, 256, 200, 2), (130, 136, 72, 1)])     # K tails: rows past K must stage as zeros
 def test_gemm_nn_splitk_forward(gpu_lib, M, N, K, S):
     g = torch.Generator(device="cpu").manual_seed(15)
     A = bf(torch.randn(M, K, generator=g)).to(DEV)
@@ -437,6 +438,41 @@ def test_step_state_counters_advance_independently_on_two_streams(gpu_lib):
         check(gpu_lib.dtf_advance_state(ptr(state), 64, 1, 2, sb.cuda_stream), "advance")
     torch.cuda.synchronize()
     assert state[:4].tolist() == [64 * iters, iters, 2 * iters, iters], state.tolist()
+
+
+@pytest.mark.parametrize("M,N,K", [(1024, 3136, 1024), (1000, 3136, 1024), (257, 384, 192), (128, 128, 64)])
+def test_gemm_lds_dma_staging_is_bitwise_the_register_staged_kernel(gpu_lib, M, N, K):
+    """The LDS-DMA pipeline (buffer_load ... lds, four LDS buffers, fragments read a phase ahead, counted vmcnt + raw
+    barriers) multiplies the same fragments in the same order as the register-staged one: bit-identical outputs, for
+    the NT (fc1 dgrad) and TN (fc1 wgrad) kernels, over many launches while another stream keeps the memory system
+    busy (a mis-ordered read of a staged buffer shows up as rare wrong tiles, not as a steady error)."""
+    g = torch.Generator(device="cpu").manual_seed(12)
+    A = bf(torch.randn(M, K, generator=g)).to(DEV)
+    Bm = bf(torch.randn(N, K, generator=g) * 0.05 + torch.arange(N).float()[:, None] * 1e-3).to(DEV)
+    At, Bt = A.t().contiguous(), Bm.t().contiguous()          # TN operands: [K][M], [K][N]
+    Mp, Np = (M + 7) // 8 * 8, (N + 7) // 8 * 8               # the TN kernel wants M, N multiples of 8
+    At = torch.nn.functional.pad(At, (0, Mp - M)).contiguous()
+    Bt = torch.nn.functional.pad(Bt, (0, Np - N)).contiguous()
+    ref_nt = torch.empty(M, N, dtype=torch.bfloat16, device=DEV)
+    ref_tn = torch.empty(Mp, Np, device=DEV)
+    check(gpu_lib.dtf_gemm_nt(ptr(A), ptr(Bm), ptr(ref_nt), None, M, N, K, K, K, N, 0, 1.0, 0, None, 129, stream()), "nt reg")
+    check(gpu_lib.dtf_gemm_tn(ptr(At), ptr(Bt), ptr(ref_tn), Mp, Np, K, Mp, Np, Np, 129, stream()), "tn reg")
+    torch.cuda.synchronize()
+    assert rel_err(ref_nt, A.float() @ Bm.float().t()) < 4e-3
+    noise = torch.cuda.Stream()
+    junk = torch.empty(64 << 20, dtype=torch.uint8, device=DEV)
+    out_nt = torch.empty_like(ref_nt)
+    out_tn = torch.empty_like(ref_tn)
+    for it in range(60):
+        with torch.cuda.stream(noise):
+            junk.copy_(junk.flip(0)) if it % 3 == 0 else junk.add_(1)
+        out_nt.fill_(float("nan"))
+        out_tn.fill_(float("nan"))
+        check(gpu_lib.dtf_gemm_nt(ptr(A), ptr(Bm), ptr(out_nt), None, M, N, K, K, K, N, 0, 1.0, 0, None, 130, stream()), "nt dma")
+        check(gpu_lib.dtf_gemm_tn(ptr(At), ptr(Bt), ptr(out_tn), Mp, Np, K, Mp, Np, Np, 130, stream()), "tn dma")
+        assert torch.equal(out_nt, ref_nt), f"NT, launch {it}"
+        assert torch.equal(out_tn, ref_tn), f"TN, launch {it}"
+    torch.cuda.synchronize()
 
 
 def test_transpose(gpu_lib):

@@ -15,7 +15,7 @@ torch.manual_seed(0)
 for (M, N, K) in [(1024, 3136, 1024), (4096, 3136, 1024), (1024, 12544, 4096)]:
     A = torch.randn(M, K, device="cuda").bfloat16(); B = torch.randn(N, K, device="cuda").bfloat16()
     ref = (A.float() @ B.float().t())
-    for tile in (128, 256):
+    for tile in (128, 129, 256):
         C = torch.zeros(M, N, device="cuda", dtype=torch.bfloat16)
         rc = lib.dtf_gemm_nt(ptr(A), ptr(B), ptr(C), None, M, N, K, K, K, N, 0, 1.0, 0, None, tile, s)
         torch.cuda.synchronize()
