@@ -131,6 +131,24 @@ __device__ __forceinline__ bf16x8 lds_read_b128(const bf16* p) {
   return __builtin_bit_cast(bf16x8, v);
 }
 
+template <int MT, int NTL>
+struct GemmFrags {
+  bf16x8 a[2][MT], b[2][NTL];
+};
+
+// `s_waitcnt lgkmcnt(0)` that the CONSUMERS of a fragment set depend on.  The fragment reads of the DMA kernels are
+// inline asm (lds_tr_read_b64 / lds_read_b128), so the compiler does not know that their results arrive
+// asynchronously; a bare `asm volatile("s_waitcnt ...")` orders only memory operations, and MFMAs -- pure register
+// instructions -- may be scheduled above it (seen: the three-buffer forward variant returned garbage).  Passing every
+// fragment register through the asm as "+v" makes each MFMA on them data-dependent on the wait.
+__device__ __forceinline__ void frags_ready(GemmFrags<4, 2>& f) {
+  asm volatile("s_waitcnt lgkmcnt(0)"
+               : "+v"(f.a[0][0]), "+v"(f.a[0][1]), "+v"(f.a[0][2]), "+v"(f.a[0][3]), "+v"(f.a[1][0]), "+v"(f.a[1][1]),
+                 "+v"(f.a[1][2]), "+v"(f.a[1][3]), "+v"(f.b[0][0]), "+v"(f.b[0][1]), "+v"(f.b[1][0]), "+v"(f.b[1][1])
+               :
+               : "memory");
+}
+
 template <class FR, class DM, class LF, class MM>
 __device__ __forceinline__ void gemm_pipeline_dma4(int T, DM&& dma, LF&& load_frags, MM&& mma) {
   FR f0, f1;
@@ -149,7 +167,7 @@ __device__ __forceinline__ void gemm_pipeline_dma4(int T, DM&& dma, LF&& load_fr
   __builtin_amdgcn_s_barrier();
   DTF_GSTAMP(1);
   load_frags(f0, 0);
-  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // (fragment reads issued as inline asm: see lds_tr_read_b64)
+  frags_ready(f0);   // (fragment reads issued as inline asm: see lds_tr_read_b64)
 #pragma unroll 1
   for (int t = 0; t < T; t += 4) {
 #pragma unroll
@@ -159,19 +177,15 @@ __device__ __forceinline__ void gemm_pipeline_dma4(int T, DM&& dma, LF&& load_fr
         if (more) dma(t + u + 3, (u + 3) % 4);
         if (t + u + 1 < T) load_frags((u & 1) ? f0 : f1, (u + 1) % 4);
         mma((u & 1) ? f1 : f0);
-        if (more) asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)" ::: "memory");
-        else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        frags_ready((u & 1) ? f0 : f1);   // the set just read is complete before anything of the next phase uses it
+        if (more) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
       }
     }
   }
   // (nothing is in flight here; the last barrier above also orders the LDS for an epilogue that reuses it)
 }
-
-template <int MT, int NTL>
-struct GemmFrags {
-  bf16x8 a[2][MT], b[2][NTL];
-};
 
 // HEADW: the launch is a 1-D grid of the GEMM's tiles FOLLOWED by hw.nbx * KS workgroups that compute the
 // output-layer weight gradient (head_wgrad_core.hpp) -- independent work that fills the CUs this GEMM

@@ -17,7 +17,7 @@ import pytest
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 HIPCC = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
-OWN_WAITS = {"vmcnt(4)", "vmcnt(4) lgkmcnt(0)", "vmcnt(0) lgkmcnt(0)", "vmcnt(0)"}
+OWN_WAITS = {"vmcnt(4)", "vmcnt(0)"}
 
 
 @pytest.mark.skipif(not os.path.exists(HIPCC), reason="hipcc not available")
