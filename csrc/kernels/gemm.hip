@@ -833,7 +833,7 @@ static int gemm_dma_forced() {
   static int mask = -2;
   if (mask == -2) {
     const char* v = getenv("DTF_GEMM_DMA");
-    mask = v ? (atoi(v) & 7) : -1;
+    mask = (v && *v) ? (atoi(v) & 7) : -1;
   }
   return mask;
 }
@@ -854,7 +854,9 @@ int dtf_gemm_nt(const void* A, const void* B, void* C, const void* bias, int M, 
   if (tile == 0) tile = ((long)((M + 127) / 128) * ((N + 127) / 128) >= 192) ? 128 : 64;
   // 256 x 128 tiles once they fill the machine 1.5 times over (measured on MI355X: M 4096, N 3136, K 1024: 42.2 vs 49.1 us;
   // M 1024, N 12544, K 4096: 134 vs 149 us; at M 1024, N 3136 their 100 tiles leave 60 % of the CUs idle: 21.9 vs 14.0 us)
-  if (tile == 128 && epi == 0 && (long)((M + 255) / 256) * ((N + 127) / 128) >= 384) tile = 256;
+  // (the LDS-DMA 128 x 128 kernel beats both register-staged tiles at these shapes -- M 1024, N 12544, K 4096: 121 vs
+  //  134 / 138 us -- so the 256 x 128 tile is for the shapes that DMA staging is not used for)
+  if (tile == 128 && epi == 0 && (long)((M + 255) / 256) * ((N + 127) / 128) >= 384 && !gemm_dma_use(1, M)) tile = 256;
   // 128 x 128 tiles stage through LDS-DMA (gemm_pipeline_dma4); 64 x 64 and 256 x 128 through registers
 #define NT_CASE(BMN, E)                                                                               \
   if (BMN == 128 && gemm_dma_use(1, M))                                                               \
