@@ -45,6 +45,7 @@ int dtf_transpose_bf16(const void* in, void* out, int batch, int R, int C, hipSt
 int dtf_head_fwd_bwd(const void* h1, const void* wT, const void* bias, const void* labels, const void* idx,
                      void* logits_out, void* loss_rows, void* correct_rows, void* dlogits, void* da, int B, int H,
                      float grad_scale, float inv_keep, int backward, hipStream_t s);
+int dtf_head_set_onepass(int on);   // 0: the general head kernel also at H == 1024 (tests, A/B)
 int dtf_head_fused_fwd_bwd(const void* part, int S, const void* bias1, float keep_prob, uint64_t seed,
                            const void* state, void* h1, const void* wT, const void* bias, const void* labels,
                            const void* idx, void* logits_out, void* loss_rows, void* correct_rows, void* dlogits,

@@ -44,6 +44,29 @@ struct Fc1Epilogue {
   DropoutArgs drop;
 };
 
+// Sum of S split-K slabs in slab order, ((p0 + p1) + p2) + ..., with four loads in flight per wait: the plain
+// "load, add, next" loop compiles to a chain of S dependent memory round trips (ISA: one `s_waitcnt vmcnt(0)` per
+// slab), which was most of a row's latency.
+__device__ __forceinline__ f32x4 sum_slabs4(const float* p, size_t stride, int S) {
+  auto ld = [&](int i) { return *reinterpret_cast<const f32x4*>(p + (size_t)i * stride); };
+  f32x4 acc;
+  int i;
+  if (S >= 4) {
+    const f32x4 a = ld(0), b = ld(1), c = ld(2), d = ld(3);
+    acc = ((a + b) + c) + d;
+    i = 4;
+  } else {
+    acc = ld(0);
+    i = 1;
+  }
+  for (; i + 4 <= S; i += 4) {
+    const f32x4 a = ld(i), b = ld(i + 1), c = ld(i + 2), d = ld(i + 3);
+    acc += a; acc += b; acc += c; acc += d;
+  }
+  for (; i < S; ++i) acc += ld(i);
+  return acc;
+}
+
 // labels: int32 dataset labels; idx: optional gather (label = labels[idx[b]]).
 // wT: the output weight TRANSPOSED, fp32 [10][H].  A lane owns 4 consecutive hidden units per
 // 256-wide iteration, so every load below is one contiguous 1 KiB (fp32) or 512 B (bf16) wave
@@ -52,7 +75,10 @@ struct Fc1Epilogue {
 // One 256-thread workgroup per batch row (grid-stride), thread t owns hidden units 4t..4t+3 of every
 // 1024-wide slice: 4 waves per row instead of one, so a CU holds 16+ independent load streams
 // (one wave per row left each SIMD with a single latency-bound wave).
-template <typename AT>
+// ONEPASS (H == 1024: a thread sees exactly one 4-wide slice): the slice of h1 and the ten slices of wT stay in
+// registers for the backward half instead of being loaded again behind the row's own stores (44 VGPRs for eleven
+// loads off the row's latency chain; same values, same arithmetic).
+template <typename AT, bool ONEPASS>
 __global__ __launch_bounds__(256) void head_fwd_bwd(
     AT* __restrict__ h1, Fc1Epilogue epi, const float* __restrict__ wT, const float* __restrict__ bias,
     const int* __restrict__ labels, const int* __restrict__ idx, float* __restrict__ logits_out,
@@ -63,22 +89,26 @@ __global__ __launch_bounds__(256) void head_fwd_bwd(
   const bool do_drop = epi.part && epi.drop.keep_prob < 1.0f;
   const uint64_t drop_off = (do_drop && epi.drop.state) ? (uint64_t)epi.drop.state[2] : 0;
   const size_t BH = (size_t)B * H;
+  const __amdgpu_buffer_rsrc_t lab_rs = make_rsrc(labels, 0x7ffffffcull);
+  const __amdgpu_buffer_rsrc_t idx_rs = make_rsrc(idx ? idx : labels, 0x7ffffffcull);
 
   for (int b = blockIdx.x; b < B; b += gridDim.x) {
     DTF_HSTAMP(0);
-    // two dependent loads (gather index, then label): requested first, needed only after the reductions
-    const int label = labels[idx ? idx[b] : b];
+    // two dependent loads (gather index, then label), needed only after the reductions.  As plain (scalar) loads the
+    // compiler sinks the second one to its use -- a memory round trip between the two barriers of the reduction --
+    // so both are raw buffer loads (never sunk), the first issued here with the row's other loads, the second once
+    // those have arrived.  (Always a valid address: a guarded load is a branch with a full wait.)
+    const int li_raw = __builtin_amdgcn_raw_buffer_load_b32(idx_rs, 0, idx ? b * 4 : 0, 0);
     AT* hrow = h1 + (size_t)b * H;
     float z[kCls];
 #pragma unroll
     for (int c = 0; c < kCls; ++c) z[c] = 0.f;
-    for (int j0 = tid * 4; j0 < H; j0 += 1024) {
+    f32x4 hkeep = {0.f, 0.f, 0.f, 0.f}, wkeep[kCls];
+    for (int j0 = tid * 4, once = 1; ONEPASS ? once : (j0 < H); j0 += 1024, once = 0) {
       f32x4 hf;
       if (epi.part) {
-        const float* p = epi.part + (size_t)b * H + j0;
-        hf = *reinterpret_cast<const f32x4*>(p);
-        for (int sI = 1; sI < epi.S; ++sI) hf += *reinterpret_cast<const f32x4*>(p + (size_t)sI * BH);
         const f32x4 bv = *reinterpret_cast<const f32x4*>(epi.bias1 + j0);
+        hf = sum_slabs4(epi.part + (size_t)b * H + j0, BH, epi.S);
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
           float v = fmaxf(hf[e] + bv[e], 0.f);
@@ -94,8 +124,11 @@ __global__ __launch_bounds__(256) void head_fwd_bwd(
         const f32x4 wv = *reinterpret_cast<const f32x4*>(wT + (size_t)c * H + j0);
 #pragma unroll
         for (int e = 0; e < 4; ++e) z[c] = fmaf(hf[e], wv[e], z[c]);
+        if (ONEPASS) wkeep[c] = wv;
       }
+      if (ONEPASS) hkeep = hf;
     }
+    const int label = __builtin_amdgcn_raw_buffer_load_b32(lab_rs, (idx ? li_raw : b) * 4, 0, 0);
     DTF_HSTAMP(1);   // h1 row produced + partial logits
     // fixed-order reduction: lanes (butterfly), then the four waves in index order
 #pragma unroll
@@ -148,12 +181,12 @@ __global__ __launch_bounds__(256) void head_fwd_bwd(
       dlogits[(size_t)b * kCls + tid] = v;
     }
     AT* drow = da + (size_t)b * H;
-    for (int j0 = tid * 4; j0 < H; j0 += 1024) {
-      const f32x4 hv = load_act4(hrow + j0);   // own earlier store when fused
+    for (int j0 = tid * 4, once = 1; ONEPASS ? once : (j0 < H); j0 += 1024, once = 0) {
+      const f32x4 hv = ONEPASS ? hkeep : load_act4(hrow + j0);   // own earlier store when fused
       f32x4 sacc = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
       for (int c = 0; c < kCls; ++c) {
-        const f32x4 wv = *reinterpret_cast<const f32x4*>(wT + (size_t)c * H + j0);
+        const f32x4 wv = ONEPASS ? wkeep[c] : *reinterpret_cast<const f32x4*>(wT + (size_t)c * H + j0);
 #pragma unroll
         for (int e = 0; e < 4; ++e) sacc[e] = fmaf(dl[c], wv[e], sacc[e]);
       }
@@ -228,13 +261,29 @@ extern "C" int dtf_head_set_timing_buf(void* p) {
 }
 #endif
 
+// DTF_HEAD_ONEPASS=0 / dtf_head_set_onepass(0): the general (reloading) kernel also at H == 1024 (A/B measurements,
+// the bitwise test of the two)
+static int g_head_onepass = -1;
+static bool head_onepass_off() {
+  if (g_head_onepass < 0) {
+    const char* e = getenv("DTF_HEAD_ONEPASS");
+    g_head_onepass = !(e && e[0] == '0');
+  }
+  return g_head_onepass == 0;
+}
+extern "C" int dtf_head_set_onepass(int on) {
+  g_head_onepass = on ? 1 : 0;
+  return 0;
+}
+
 template <typename AT>
 static int head_launch(void* h1, Fc1Epilogue epi, const void* wT, const void* bias, const void* labels,
                        const void* idx, void* logits_out, void* loss_rows, void* correct_rows, void* dlogits, void* da,
                        int B, int H, float grad_scale, float inv_keep, int backward, hipStream_t s) {
   if (H % 4) return -3;
   int blocks = B < 4096 ? B : 4096;
-  hipLaunchKernelGGL(head_fwd_bwd<AT>, dim3(blocks), dim3(256), 0, s, (AT*)h1, epi, (const float*)wT,
+  auto kern = (H == 1024 && !head_onepass_off()) ? head_fwd_bwd<AT, true> : head_fwd_bwd<AT, false>;
+  hipLaunchKernelGGL(kern, dim3(blocks), dim3(256), 0, s, (AT*)h1, epi, (const float*)wT,
                      (const float*)bias, (const int*)labels, (const int*)idx, (float*)logits_out,
                      (float*)loss_rows, (float*)correct_rows, (float*)dlogits, (AT*)da, B, H, grad_scale,
                      inv_keep, backward);

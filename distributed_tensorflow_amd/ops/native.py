@@ -51,6 +51,7 @@ _SIGS = {
                                c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int,
                                c_float, c_float, c_int, c_void_p],
     "dtf_transpose_head_w": [c_void_p, c_void_p, c_int, c_void_p],
+    "dtf_head_set_onepass": [c_int],
     "dtf_dropout_mask": [ctypes.c_uint64, ctypes.c_uint64, ctypes.c_float, c_void_p, c_long, c_void_p],
     "dtf_metrics_reduce": [c_void_p, c_void_p, c_int, c_void_p, c_int, c_void_p],
     "dtf_gemm_nn_partial": [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p],

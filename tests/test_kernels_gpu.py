@@ -594,6 +594,48 @@ def test_head_fused_fc1_epilogue_matches_two_kernel_path(gpu_lib, keep):
     assert float(outs[0][0].float().abs().sum()) > 0
 
 
+@pytest.mark.parametrize("S", [1, 2, 3, 4, 6, 8, 9])
+@pytest.mark.parametrize("gather", [False, True])
+def test_head_one_pass_kernel_is_bitwise_the_general_one_and_sums_slabs_in_order(gpu_lib, S, gather):
+    """H == 1024 runs a variant that keeps the row's activations and output-weight slices in registers and has four
+    slab loads in flight (head.hip ONEPASS, sum_slabs4): every output equals the general kernel's bit for bit, and h1
+    is exactly relu(((p0 + p1) + p2) + ... + bias) rounded to bf16 -- the slab order of the stand-alone epilogue."""
+    M, N = 333, 1024
+    g = torch.Generator(device="cpu").manual_seed(100 + S)
+    part = torch.randn(S, M, N, generator=g).to(DEV)
+    bias1 = torch.randn(N, generator=g).to(DEV)
+    wT = (torch.randn(10, N, generator=g) * 0.1).to(DEV)
+    b = (torch.randn(10, generator=g) * 0.1).to(DEV)
+    labels = torch.randint(0, 10, (4 * M,), generator=g, dtype=torch.int32).to(DEV)
+    idx = torch.randperm(4 * M, generator=g)[:M].to(torch.int32).to(DEV) if gather else None
+    state = torch.zeros(8, dtype=torch.int64, device=DEV)
+    outs = []
+    try:
+        for onepass in (0, 1):
+            gpu_lib.dtf_head_set_onepass(onepass)
+            h1 = torch.zeros(M, N, dtype=torch.bfloat16, device=DEV)
+            logits, lrows, crows = torch.empty(M, 10, device=DEV), torch.empty(M, device=DEV), torch.empty(M, device=DEV)
+            dlog, da = torch.empty(M, 10, device=DEV), torch.empty(M, N, dtype=torch.bfloat16, device=DEV)
+            check(gpu_lib.dtf_head_fused_fwd_bwd(ptr(part), S, ptr(bias1), 1.0, 9, ptr(state), ptr(h1), ptr(wT), ptr(b),
+                                                 ptr(labels), ptr(idx) if gather else None, ptr(logits), ptr(lrows),
+                                                 ptr(crows), ptr(dlog), ptr(da), M, N, 1.0 / M, 1.0, 1, stream()), "fused")
+            torch.cuda.synchronize()
+            outs.append((h1, logits, lrows, crows, dlog, da))
+    finally:
+        gpu_lib.dtf_head_set_onepass(1)
+    for x, y in zip(*outs):
+        assert torch.equal(x, y)
+    acc = part[0].clone()
+    for s_ in range(1, S):
+        acc += part[s_]
+    assert torch.equal(outs[1][0], F.relu(acc + bias1).to(torch.bfloat16))
+    lab = labels[idx.long()] if gather else labels[:M]
+    z = outs[1][0].float() @ wT.t() + b
+    assert rel_err(outs[1][1], z) < 1e-5
+    assert torch.equal(outs[1][3], (outs[1][1].argmax(-1) == lab.long()).float())
+    assert rel_err(outs[1][2], R.softmax_cross_entropy_with_logits(z, lab)) < 1e-5
+
+
 # ------------------------------------------------------------------- optimizer
 def test_reduce_segments(gpu_lib):
     a = torch.randn(5, 1000, device=DEV)
