@@ -141,14 +141,36 @@ __device__ __forceinline__ void expand_pool_grad(const u32x4& g, const u32x2& a,
 // reductions of the head kernel were 2.4 us of a 7 us row (tools/conv_timeline.py run 1024 head).
 #define DTF_DPP_ADD(v, ctrl, row_mask) \
   ((v) + __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, (v)), (ctrl), (row_mask), 0xf, false)))
-__device__ __forceinline__ float wave_sum(float v) {
+// the total is valid in lane 63 only (for a caller whose lane 63 consumes it itself: no scalar round trip)
+__device__ __forceinline__ float wave_sum_lane63(float v) {
   v = DTF_DPP_ADD(v, 0xB1, 0xf);    // quad_perm [1,0,3,2]
   v = DTF_DPP_ADD(v, 0x4E, 0xf);    // quad_perm [2,3,0,1]
   v = DTF_DPP_ADD(v, 0x141, 0xf);   // row_half_mirror: sums of 8
   v = DTF_DPP_ADD(v, 0x140, 0xf);   // row_mirror: every lane holds its row's sum of 16
   v = DTF_DPP_ADD(v, 0x142, 0xa);   // row_bcast15 into rows 1 and 3
   v = DTF_DPP_ADD(v, 0x143, 0xc);   // row_bcast31 into rows 2 and 3: lane 63 holds the total
-  return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63));
+  return v;
+}
+__device__ __forceinline__ float wave_sum(float v) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, wave_sum_lane63(v)), 63));
+}
+
+// Sum / maximum over the 16 lanes of a DPP row, result in every lane of the row (four VALU steps)
+__device__ __forceinline__ float row16_sum(float v) {
+  v = DTF_DPP_ADD(v, 0xB1, 0xf);
+  v = DTF_DPP_ADD(v, 0x4E, 0xf);
+  v = DTF_DPP_ADD(v, 0x141, 0xf);
+  v = DTF_DPP_ADD(v, 0x140, 0xf);
+  return v;
+}
+#define DTF_DPP_MAX(v, ctrl) \
+  fmaxf((v), __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, (v)), (ctrl), 0xf, 0xf, false)))
+__device__ __forceinline__ float row16_max(float v) {
+  v = DTF_DPP_MAX(v, 0xB1);
+  v = DTF_DPP_MAX(v, 0x4E);
+  v = DTF_DPP_MAX(v, 0x141);
+  v = DTF_DPP_MAX(v, 0x140);
+  return v;
 }
 
 __device__ __forceinline__ float wave_max(float v) {

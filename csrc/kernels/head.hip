@@ -44,27 +44,41 @@ struct Fc1Epilogue {
   DropoutArgs drop;
 };
 
-// Sum of S split-K slabs in slab order, ((p0 + p1) + p2) + ..., with four loads in flight per wait: the plain
-// "load, add, next" loop compiles to a chain of S dependent memory round trips (ISA: one `s_waitcnt vmcnt(0)` per
-// slab), which was most of a row's latency.
-__device__ __forceinline__ f32x4 sum_slabs4(const float* p, size_t stride, int S) {
-  auto ld = [&](int i) { return *reinterpret_cast<const f32x4*>(p + (size_t)i * stride); };
-  f32x4 acc;
+// Sum of S split-K slabs in slab order, ((p0 + p1) + p2) + ..., for the VQ float4s a thread owns, with four slabs
+// in flight per wait: the plain "load, add, next" loop compiles to a chain of S dependent memory round trips (ISA: one
+// `s_waitcnt vmcnt(0)` per slab).
+template <int VQ>
+__device__ __forceinline__ void sum_slabs4(const float* p, size_t stride, int S, f32x4 (&acc)[VQ]) {
+  auto ld = [&](int i, int q) { return *reinterpret_cast<const f32x4*>(p + (size_t)i * stride + 4 * q); };
   int i;
   if (S >= 4) {
-    const f32x4 a = ld(0), b = ld(1), c = ld(2), d = ld(3);
-    acc = ((a + b) + c) + d;
+    f32x4 v[4][VQ];
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+#pragma unroll
+      for (int q = 0; q < VQ; ++q) v[k][q] = ld(k, q);
+#pragma unroll
+    for (int q = 0; q < VQ; ++q) acc[q] = ((v[0][q] + v[1][q]) + v[2][q]) + v[3][q];
     i = 4;
   } else {
-    acc = ld(0);
+#pragma unroll
+    for (int q = 0; q < VQ; ++q) acc[q] = ld(0, q);
     i = 1;
   }
   for (; i + 4 <= S; i += 4) {
-    const f32x4 a = ld(i), b = ld(i + 1), c = ld(i + 2), d = ld(i + 3);
-    acc += a; acc += b; acc += c; acc += d;
+    f32x4 v[4][VQ];
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+#pragma unroll
+      for (int q = 0; q < VQ; ++q) v[k][q] = ld(i + k, q);
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+#pragma unroll
+      for (int q = 0; q < VQ; ++q) acc[q] += v[k][q];
   }
-  for (; i < S; ++i) acc += ld(i);
-  return acc;
+  for (; i < S; ++i)
+#pragma unroll
+    for (int q = 0; q < VQ; ++q) acc[q] += ld(i, q);
 }
 
 // labels: int32 dataset labels; idx: optional gather (label = labels[idx[b]]).
@@ -72,20 +86,27 @@ __device__ __forceinline__ f32x4 sum_slabs4(const float* p, size_t stride, int S
 // 256-wide iteration, so every load below is one contiguous 1 KiB (fp32) or 512 B (bf16) wave
 // access.  With the native [H][10] layout each lane walked 80 consecutive floats and a single wave
 // load touched 64 cache lines; the texture path made that 9 us for 2 MB of activations.
-// One 256-thread workgroup per batch row (grid-stride), thread t owns hidden units 4t..4t+3 of every
-// 1024-wide slice: 4 waves per row instead of one, so a CU holds 16+ independent load streams
-// (one wave per row left each SIMD with a single latency-bound wave).
-// ONEPASS (H == 1024: a thread sees exactly one 4-wide slice): the slice of h1 and the ten slices of wT stay in
-// registers for the backward half instead of being loaded again behind the row's own stores (44 VGPRs for eleven
-// loads off the row's latency chain; same values, same arithmetic).
-template <typename AT, bool ONEPASS>
-__global__ __launch_bounds__(256) void head_fwd_bwd(
+// One workgroup of NW waves per batch row (grid-stride); a thread owns V = 4 VQ consecutive hidden units of every
+// 1024-wide slice.  Two instantiations:
+//  * <4 waves, V = 4>: any H.  4 waves per row instead of one, so a CU holds 16+ independent load streams (one wave
+//    per row left each SIMD with a single latency-bound wave).
+//  * <2 waves, V = 8, ONEPASS>: H == 1024, a thread sees exactly one slice.  The slice of h1 and the ten slices of wT
+//    stay in registers for the backward half instead of being loaded again behind the row's own stores, and the
+//    per-wave fixed work (ten 64-lane reductions, softmax, the cross-wave exchange) is paid by two waves per row, not
+//    four: at 1024 rows the kernel is bound by VALU issue and by the rate at which 4096 waves can be launched
+//    (in-kernel stamps, tools/conv_timeline.py run 1024 head: workgroup starts spread over 2.7 us of a 5.4 us kernel).
+//    ONE wave per row (16 units per lane, no LDS, no barriers, four rows to a workgroup) was measured too: its row
+//    takes 4.4 us against 2.8 us, step 0.1429 vs 0.1416 ms -- the latency chain of a lone wave per SIMD again.
+template <typename AT, int NW, int V, bool ONEPASS>
+__global__ __launch_bounds__(NW * 64) void head_fwd_bwd(
     AT* __restrict__ h1, Fc1Epilogue epi, const float* __restrict__ wT, const float* __restrict__ bias,
     const int* __restrict__ labels, const int* __restrict__ idx, float* __restrict__ logits_out,
     float* __restrict__ loss_rows, float* __restrict__ correct_rows, float* __restrict__ dlogits,
     AT* __restrict__ da, int B, int H, float grad_scale, float inv_keep, int backward) {
+  static_assert(NW * 64 * V == 1024 && (NW == 2 || NW == 4) && V % 4 == 0, "NW waves cover a 1024-wide slice per pass");
+  constexpr int VQ = V / 4;
   __shared__ __attribute__((aligned(16))) float zred[kCls][4];   // [class][wave]: one 16-byte read per class
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const bool do_drop = epi.part && epi.drop.keep_prob < 1.0f;
   const uint64_t drop_off = (do_drop && epi.drop.state) ? (uint64_t)epi.drop.state[2] : 0;
   const size_t BH = (size_t)B * H;
@@ -103,97 +124,103 @@ __global__ __launch_bounds__(256) void head_fwd_bwd(
     float z[kCls];
 #pragma unroll
     for (int c = 0; c < kCls; ++c) z[c] = 0.f;
-    f32x4 hkeep = {0.f, 0.f, 0.f, 0.f}, wkeep[kCls];
-    for (int j0 = tid * 4, once = 1; ONEPASS ? once : (j0 < H); j0 += 1024, once = 0) {
-      f32x4 hf;
+    f32x4 hkeep[VQ], wkeep[kCls][VQ];
+    for (int j0 = tid * V, once = 1; ONEPASS ? once : (j0 < H); j0 += 1024, once = 0) {
+      f32x4 hf[VQ];
       if (epi.part) {
-        const f32x4 bv = *reinterpret_cast<const f32x4*>(epi.bias1 + j0);
-        hf = sum_slabs4(epi.part + (size_t)b * H + j0, BH, epi.S);
+        f32x4 bv[VQ];
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          float v = fmaxf(hf[e] + bv[e], 0.f);
-          if (do_drop) v *= dropout_scale(epi.drop, drop_off, (uint64_t)b * (uint64_t)H + j0 + e);
-          hf[e] = (float)(AT)v;   // downstream math sees exactly the stored value (bf16-rounded on the mixed path)
+        for (int q = 0; q < VQ; ++q) bv[q] = *reinterpret_cast<const f32x4*>(epi.bias1 + j0 + 4 * q);
+        sum_slabs4<VQ>(epi.part + (size_t)b * H + j0, BH, epi.S, hf);
+#pragma unroll
+        for (int q = 0; q < VQ; ++q) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            float v = fmaxf(hf[q][e] + bv[q][e], 0.f);
+            if (do_drop) v *= dropout_scale(epi.drop, drop_off, (uint64_t)b * (uint64_t)H + j0 + 4 * q + e);
+            hf[q][e] = (float)(AT)v;   // downstream math sees exactly the stored value (bf16-rounded on the mixed path)
+          }
+          store_act4(hrow + j0 + 4 * q, hf[q]);
         }
-        store_act4(hrow + j0, hf);
       } else {
-        hf = load_act4(hrow + j0);
+#pragma unroll
+        for (int q = 0; q < VQ; ++q) hf[q] = load_act4(hrow + j0 + 4 * q);
       }
 #pragma unroll
       for (int c = 0; c < kCls; ++c) {
-        const f32x4 wv = *reinterpret_cast<const f32x4*>(wT + (size_t)c * H + j0);
 #pragma unroll
-        for (int e = 0; e < 4; ++e) z[c] = fmaf(hf[e], wv[e], z[c]);
-        if (ONEPASS) wkeep[c] = wv;
+        for (int q = 0; q < VQ; ++q) {
+          const f32x4 wv = *reinterpret_cast<const f32x4*>(wT + (size_t)c * H + j0 + 4 * q);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) z[c] = fmaf(hf[q][e], wv[e], z[c]);
+          if (ONEPASS) wkeep[c][q] = wv;
+        }
       }
-      if (ONEPASS) hkeep = hf;
+      if (ONEPASS) {
+#pragma unroll
+        for (int q = 0; q < VQ; ++q) hkeep[q] = hf[q];
+      }
     }
     const int label = __builtin_amdgcn_raw_buffer_load_b32(lab_rs, (idx ? li_raw : b) * 4, 0, 0);
     DTF_HSTAMP(1);   // h1 row produced + partial logits
-    // fixed-order reduction: lanes (butterfly), then the four waves in index order
+    // fixed-order reduction: lanes (DPP tree), then the waves in index order
 #pragma unroll
-    for (int c = 0; c < kCls; ++c) z[c] = wave_sum(z[c]);
+    for (int c = 0; c < kCls; ++c) z[c] = wave_sum_lane63(z[c]);
     __syncthreads();   // zred free (previous row consumed)
-    if (lane == 0) {
+    if (lane == 63) {
 #pragma unroll
       for (int c = 0; c < kCls; ++c) zred[c][wave] = z[c];
     }
     __syncthreads();
-#pragma unroll
-    for (int c = 0; c < kCls; ++c) {
-      const f32x4 zw = *reinterpret_cast<const f32x4*>(&zred[c][0]);
-      z[c] = ((zw[0] + zw[1]) + (zw[2] + zw[3])) + bias[c];
-    }
+    // Lane-parallel softmax: lane 16 r + c of every wave owns class c (c >= 10: padding), so the row costs one LDS
+    // read, one exp and two 16-lane DPP reductions per lane instead of ten of each (the replicated softmax was a
+    // third of this kernel's instructions).
+    const int cls = lane & 15;
+    const bool live = cls < kCls;
+    const int cidx = live ? cls : 0;
+    const f32x4 zw = *reinterpret_cast<const f32x4*>(&zred[cidx][0]);
+    const float zc = (NW == 4 ? (zw[0] + zw[1]) + (zw[2] + zw[3]) : zw[0] + zw[1]) + bias[cidx];
 
     DTF_HSTAMP(2);   // logits reduced
-    float zmax = z[0];
-    int amax = 0;
-#pragma unroll
-    for (int c = 1; c < kCls; ++c)
-      if (z[c] > zmax) { zmax = z[c]; amax = c; }
-    float p[kCls], se = 0.f;
-#pragma unroll
-    for (int c = 0; c < kCls; ++c) { p[c] = __expf(z[c] - zmax); se += p[c]; }
+    const float zmax = row16_max(live ? zc : -INFINITY);
+    const float pc = live ? __expf(zc - zmax) : 0.f;
+    const float se = row16_sum(pc);                       // fixed tree order; identical in all four rows
     const float inv = 1.f / se;
-    float zl = 0.f;
-#pragma unroll
-    for (int c = 0; c < kCls; ++c) zl = (c == label) ? z[c] : zl;
+    const int label_u = __builtin_amdgcn_readfirstlane(label);
+    // first class that attains the maximum (the tie-break of a sequential scan); rows replicate, row 0 has the low bits
+    const unsigned eq = (unsigned)__ballot(live && zc == zmax) & 0x3ffu;
+    const int amax = eq ? __builtin_ctz(eq) : 0;
+    const float zl = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, zc), label_u & 15));
+    const float dlc = (pc * inv - (cls == label_u ? 1.f : 0.f)) * grad_scale;
     float dl[kCls];
 #pragma unroll
-    for (int c = 0; c < kCls; ++c) dl[c] = (p[c] * inv - (c == label ? 1.f : 0.f)) * grad_scale;
+    for (int c = 0; c < kCls; ++c) dl[c] = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, dlc), c));
 
     if (tid == 0) {
       loss_rows[b] = __logf(se) + zmax - zl;
-      correct_rows[b] = (amax == label) ? 1.f : 0.f;
+      correct_rows[b] = (amax == label_u) ? 1.f : 0.f;
     }
-    if (logits_out && tid < kCls) {
-      float v = 0.f;
-#pragma unroll
-      for (int c = 0; c < kCls; ++c) v = (c == tid) ? z[c] : v;
-      logits_out[(size_t)b * kCls + tid] = v;
-    }
+    if (logits_out && tid < kCls) logits_out[(size_t)b * kCls + tid] = zc;
     DTF_HSTAMP(3);   // softmax / loss
     if (!backward) continue;
-    if (tid < kCls) {
-      float v = 0.f;
-#pragma unroll
-      for (int c = 0; c < kCls; ++c) v = (c == tid) ? dl[c] : v;
-      dlogits[(size_t)b * kCls + tid] = v;
-    }
+    if (tid < kCls) dlogits[(size_t)b * kCls + tid] = dlc;
     AT* drow = da + (size_t)b * H;
-    for (int j0 = tid * 4, once = 1; ONEPASS ? once : (j0 < H); j0 += 1024, once = 0) {
-      const f32x4 hv = ONEPASS ? hkeep : load_act4(hrow + j0);   // own earlier store when fused
-      f32x4 sacc = {0.f, 0.f, 0.f, 0.f};
+    for (int j0 = tid * V, once = 1; ONEPASS ? once : (j0 < H); j0 += 1024, once = 0) {
 #pragma unroll
-      for (int c = 0; c < kCls; ++c) {
-        const f32x4 wv = ONEPASS ? wkeep[c] : *reinterpret_cast<const f32x4*>(wT + (size_t)c * H + j0);
+      for (int q = 0; q < VQ; ++q) {
+        const f32x4 hv = ONEPASS ? hkeep[q] : load_act4(hrow + j0 + 4 * q);   // own earlier store when fused
+        f32x4 sacc = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-        for (int e = 0; e < 4; ++e) sacc[e] = fmaf(dl[c], wv[e], sacc[e]);
+        for (int c = 0; c < kCls; ++c) {
+          const f32x4 wv = ONEPASS ? wkeep[c][q] : *reinterpret_cast<const f32x4*>(wT + (size_t)c * H + j0 + 4 * q);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) sacc[e] = fmaf(dl[c], wv[e], sacc[e]);
+        }
+        f32x4 o;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) o[e] = (hv[e] > 0.f) ? sacc[e] * inv_keep : 0.f;
+        store_act4(drow + j0 + 4 * q, o);
       }
-      f32x4 o;
-#pragma unroll
-      for (int e = 0; e < 4; ++e) o[e] = (hv[e] > 0.f) ? sacc[e] * inv_keep : 0.f;
-      store_act4(drow + j0, o);
     }
     DTF_HSTAMP(4);   // da row stored
   }
@@ -264,15 +291,15 @@ extern "C" int dtf_head_set_timing_buf(void* p) {
 // DTF_HEAD_ONEPASS=0 / dtf_head_set_onepass(0): the general (reloading) kernel also at H == 1024 (A/B measurements,
 // the bitwise test of the two)
 static int g_head_onepass = -1;
-static bool head_onepass_off() {
+static bool head_onepass() {
   if (g_head_onepass < 0) {
     const char* e = getenv("DTF_HEAD_ONEPASS");
     g_head_onepass = !(e && e[0] == '0');
   }
-  return g_head_onepass == 0;
+  return g_head_onepass != 0;
 }
-extern "C" int dtf_head_set_onepass(int on) {
-  g_head_onepass = on ? 1 : 0;
+extern "C" int dtf_head_set_onepass(int on) {   // < 0: back to the default
+  g_head_onepass = on < 0 ? -1 : (on ? 1 : 0);
   return 0;
 }
 
@@ -282,8 +309,9 @@ static int head_launch(void* h1, Fc1Epilogue epi, const void* wT, const void* bi
                        int B, int H, float grad_scale, float inv_keep, int backward, hipStream_t s) {
   if (H % 4) return -3;
   int blocks = B < 4096 ? B : 4096;
-  auto kern = (H == 1024 && !head_onepass_off()) ? head_fwd_bwd<AT, true> : head_fwd_bwd<AT, false>;
-  hipLaunchKernelGGL(kern, dim3(blocks), dim3(256), 0, s, (AT*)h1, epi, (const float*)wT,
+  const bool onepass = H == 1024 && head_onepass();
+  auto kern = onepass ? head_fwd_bwd<AT, 2, 8, true> : head_fwd_bwd<AT, 4, 4, false>;
+  hipLaunchKernelGGL(kern, dim3(blocks), dim3(onepass ? 128 : 256), 0, s, (AT*)h1, epi, (const float*)wT,
                      (const float*)bias, (const int*)labels, (const int*)idx, (float*)logits_out,
                      (float*)loss_rows, (float*)correct_rows, (float*)dlogits, (AT*)da, B, H, grad_scale,
                      inv_keep, backward);

@@ -596,10 +596,11 @@ def test_head_fused_fc1_epilogue_matches_two_kernel_path(gpu_lib, keep):
 
 @pytest.mark.parametrize("S", [1, 2, 3, 4, 6, 8, 9])
 @pytest.mark.parametrize("gather", [False, True])
-def test_head_one_pass_kernel_is_bitwise_the_general_one_and_sums_slabs_in_order(gpu_lib, S, gather):
-    """H == 1024 runs a variant that keeps the row's activations and output-weight slices in registers and has four
-    slab loads in flight (head.hip ONEPASS, sum_slabs4): every output equals the general kernel's bit for bit, and h1
-    is exactly relu(((p0 + p1) + p2) + ... + bias) rounded to bf16 -- the slab order of the stand-alone epilogue."""
+def test_head_one_pass_kernel_matches_the_general_one_and_sums_slabs_in_order(gpu_lib, S, gather):
+    """H == 1024 runs a variant with two waves per row, eight hidden units per thread, the row's activations and
+    output-weight slices kept in registers for the backward half (head.hip ONEPASS).  h1 is bit for bit the general
+    kernel's and exactly relu(((p0 + p1) + p2) + ... + bias) rounded to bf16 -- the slab order of the stand-alone
+    epilogue; the logits are summed in a different (fixed) order, so everything behind them agrees to rounding."""
     M, N = 333, 1024
     g = torch.Generator(device="cpu").manual_seed(100 + S)
     part = torch.randn(S, M, N, generator=g).to(DEV)
@@ -622,9 +623,11 @@ def test_head_one_pass_kernel_is_bitwise_the_general_one_and_sums_slabs_in_order
             torch.cuda.synchronize()
             outs.append((h1, logits, lrows, crows, dlog, da))
     finally:
-        gpu_lib.dtf_head_set_onepass(1)
-    for x, y in zip(*outs):
-        assert torch.equal(x, y)
+        gpu_lib.dtf_head_set_onepass(-1)     # back to the default variant
+    assert torch.equal(outs[0][0], outs[1][0])
+    for k, tol in ((1, 1e-5), (2, 1e-5), (4, 1e-5), (5, 4e-3)):
+        assert rel_err(outs[1][k], outs[0][k]) < tol
+    assert float((outs[0][3] != outs[1][3]).float().mean()) < 0.01     # a tie in the logits may flip a row
     acc = part[0].clone()
     for s_ in range(1, S):
         acc += part[s_]

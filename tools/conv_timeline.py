@@ -78,7 +78,7 @@ elif len(sys.argv) > 3 and sys.argv[3] == "gemm":
               f"epilogue {d[:, 2].median() / 1e3:5.2f} (max {d[:, 2].max() / 1e3:5.2f}) | end median {ns[:, 3].median() / 1e3:5.2f} max {ns[:, 3].max() / 1e3:5.2f} us")
 elif len(sys.argv) > 3 and sys.argv[3] == "head":
     import torch
-    B = int(sys.argv[2]); H, S = 1024, 3
+    B = int(sys.argv[2]); H, S = 1024, (int(sys.argv[4]) if len(sys.argv) > 4 else 4)
     lib = ctypes.CDLL(f"{OUT}/head_timing.so")
     P, I, F = ctypes.c_void_p, ctypes.c_int, ctypes.c_float
     part = torch.randn(S, B, H, device="cuda") * 0.3
