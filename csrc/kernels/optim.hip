@@ -248,33 +248,38 @@ __device__ __forceinline__ void tail_update4(const FusedSgdArgs& a, long e0, f32
   }
   *reinterpret_cast<f32x4*>(a.w + e0) = wv;
   if (a.shadow) store_bf16x4(a.shadow + e0, wv[0], wv[1], wv[2], wv[3]);
-  const long ro = e0 - a.out_w_off;
-  if (a.out_wT && ro >= 0 && ro < 10L * a.H) {
+  // (32-bit index arithmetic: with `long` operands the divisions below are 64-bit software divisions, a few hundred
+  // instructions on the one wave of the workgroup that runs the update)
+  const long ro64 = e0 - a.out_w_off;
+  if (a.out_wT && ro64 >= 0 && ro64 < 10L * a.H) {
+    const unsigned ro = (unsigned)ro64;
 #pragma unroll
-    for (int e = 0; e < 4; ++e) a.out_wT[(size_t)((ro + e) % 10) * a.H + (ro + e) / 10] = wv[e];
+    for (int e = 0; e < 4; ++e) a.out_wT[(size_t)((ro + e) % 10u) * a.H + (ro + e) / 10u] = wv[e];
   }
-  const long r = e0 - a.wc2_off;
+  const long r64 = e0 - a.wc2_off;
   const long nw = 25L * a.c1 * a.c2;
-  if (a.wc2T && r >= 0 && r < nw && !a.shadow) {
+  if (a.wc2T && r64 >= 0 && r64 < nw && !a.shadow) {
     // fp32 configuration (no bf16 shadow): wc2T holds the fp32 fragment packs of conv2_f32.hip
     // (pack_conv2_weights_f32): [fwd pack | dgrad pack], one lane slot = four consecutive k
     float* pk = reinterpret_cast<float*>(a.wc2T);
-    const int tap = (int)(r / (a.c1 * a.c2)), rem = (int)(r % (a.c1 * a.c2));
-    const int ci = rem / a.c2, co = rem % a.c2;
-    const long f0 = (((long)tap * (a.c1 / 16) + ci / 16) * (a.c2 / 16) + co / 16) * 256 + (((ci % 16) / 4) * 16 + co % 16) * 4 + ci % 4;
+    const unsigned r = (unsigned)r64, cc = (unsigned)(a.c1 * a.c2), c1 = (unsigned)a.c1, c2 = (unsigned)a.c2;
+    const unsigned tap = r / cc, rem = r - tap * cc;
+    const unsigned ci = rem / c2, co = rem - ci * c2;
+    const long f0 = (((long)tap * (c1 / 16) + ci / 16) * (c2 / 16) + co / 16) * 256 + (((ci % 16) / 4) * 16 + co % 16) * 4 + ci % 4;
 #pragma unroll
     for (int e = 0; e < 4; ++e) pk[f0 + 4 * e] = wv[e];   // co+e -> next lane slot (co % 16 + e <= 15)
-    const long d0 = (((long)tap * (a.c2 / 16) + co / 16) * (a.c1 / 16) + ci / 16) * 256 + (((co % 16) / 4) * 16 + ci % 16) * 4;
+    const long d0 = (((long)tap * (c2 / 16) + co / 16) * (c1 / 16) + ci / 16) * 256 + (((co % 16) / 4) * 16 + ci % 16) * 4;
     *reinterpret_cast<f32x4*>(pk + nw + d0) = wv;          // co .. co+3 = the four k of one lane slot
-  } else if (a.wc2T && r >= 0 && r < nw) {
+  } else if (a.wc2T && r64 >= 0 && r64 < nw) {
     // HWIO element (tap, ci, co..co+3) -> the two fragment-ordered packs of conv2.hip
     // (pack_conv2_weights): [fwd pack | dgrad pack]
-    const int tap = (int)(r / (a.c1 * a.c2)), rem = (int)(r % (a.c1 * a.c2));
-    const int ci = rem / a.c2, co = rem % a.c2;
-    const long f0 = (((long)tap * (a.c1 / 32) + ci / 32) * (a.c2 / 16) + co / 16) * 512 + (((ci % 32) / 8) * 16 + co % 16) * 8 + ci % 8;
+    const unsigned r = (unsigned)r64, cc = (unsigned)(a.c1 * a.c2), c1 = (unsigned)a.c1, c2 = (unsigned)a.c2;
+    const unsigned tap = r / cc, rem = r - tap * cc;
+    const unsigned ci = rem / c2, co = rem - ci * c2;
+    const long f0 = (((long)tap * (c1 / 32) + ci / 32) * (c2 / 16) + co / 16) * 512 + (((ci % 32) / 8) * 16 + co % 16) * 8 + ci % 8;
 #pragma unroll
     for (int e = 0; e < 4; ++e) a.wc2T[f0 + 8 * e] = (bf16)wv[e];   // co+e -> next lane slot (co % 16 + e <= 15)
-    const long d0 = (((long)tap * (a.c2 / 32) + co / 32) * (a.c1 / 16) + ci / 16) * 512 + (((co % 32) / 8) * 16 + ci % 16) * 8 + co % 8;
+    const long d0 = (((long)tap * (c2 / 32) + co / 32) * (c1 / 16) + ci / 16) * 512 + (((co % 32) / 8) * 16 + ci % 16) * 8 + co % 8;
     store_bf16x4(a.wc2T + nw + d0, wv[0], wv[1], wv[2], wv[3]);       // 4 consecutive k of one lane slot
   }
 }
