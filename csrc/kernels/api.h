@@ -23,6 +23,9 @@ int dtf_conv12_fwd(const void* images, const void* idx, void* idx_out, const voi
                    const void* bias2, void* p2, void* arg2, int B, hipStream_t s);
 int dtf_conv2_dgrad(const void* gpool, const void* arg, const void* w, void* dx, int B, int cin,
                     int cout, hipStream_t s);
+int dtf_conv2_dgrad_conv1_wgrad_g(const void* gpool, const void* arg2, const void* w, const void* images,
+                                  const void* idx, const void* arg1, void* part1, int B, int G, hipStream_t s);
+int dtf_conv2_small_batch(void);
 int dtf_conv2_dgrad_conv1_wgrad(const void* gpool, const void* arg2, const void* w, const void* images,
                                 const void* idx, const void* arg1, void* part1, int B, hipStream_t s);
 int dtf_conv2_wgrad(const void* x, const void* gpool, const void* arg, void* part, int B, int cin,

@@ -112,8 +112,8 @@ __global__ __launch_bounds__(IMGS * 2 * NW * 64, MINW) void conv5x5_igemm(
     const bf16* __restrict__ in, const uint8_t* __restrict__ in_arg, const bf16* __restrict__ wk,
     const float* __restrict__ bias, bf16* __restrict__ out, uint8_t* __restrict__ out_arg,
     int B, Conv1Fused c1f, Conv1WgradFused c1w) {
-  static_assert(!FUSE1 || MODE != MODE_FWD || (KTOT == 32 && KC == 32 && NW == 2),
-                "the fused conv1 stage feeds the 32-channel forward tile, 4 waves per image");
+  static_assert(!FUSE1 || MODE != MODE_FWD || (KTOT == 32 && KC == 32 && (NW == 2 || NW == 4)),
+                "the fused conv1 stage feeds the 32-channel forward tile, 4 or 8 waves per image");
   static_assert(!FUSE1 || MODE != MODE_DGRAD || (NC == 32 && IMGS * 2 * NW == 4),
                 "the fused conv1 wgrad stage takes 32-channel dx and runs on 4 waves");
   constexpr int NTHREADS = IMGS * 2 * NW * 64;
@@ -152,17 +152,19 @@ __global__ __launch_bounds__(IMGS * 2 * NW * 64, MINW) void conv5x5_igemm(
   // Fused conv1 stage: the dependent chain cursor -> dataset row -> image pixels (two memory round trips)
   // and the filter fragments are requested BEFORE the LDS zero fill, which then runs under their latency
   // (tools/conv_timeline.py: 3.8 us from workgroup start to "images in LDS" with the loads after the fill).
-  unsigned c1_px[2] = {0u, 0u};
+  constexpr int TPI = 2 * NW * 64;              // threads per image
+  constexpr int PX_ROUNDS = (392 + TPI - 1) / TPI;   // 392 pixel pairs per image
+  unsigned c1_px[PX_ROUNDS] = {};
   Conv1Frags c1_frags;
   if constexpr (FUSE1 && MODE == MODE_FWD) {
-    const int b = img0 + w_img, tid_img = tid & 255;
+    const int b = img0 + w_img, tid_img = tid % TPI;
     const SampleCursor cur = sample_cursor(c1f.smp);
     c1_frags = conv1_load_frags(c1f.w1, c1f.b1, 32, 0, lane);
     if (b < B) {
       const size_t row = sample_row(c1f.smp, cur, c1f.idx, b, tid_img == 0);
       const unsigned* src = reinterpret_cast<const unsigned*>(c1f.images + row * 784);
-      c1_px[0] = src[tid_img];                      // 2 pixels (one dword) per load
-      c1_px[1] = src[min(tid_img + 256, 391)];
+#pragma unroll
+      for (int r = 0; r < PX_ROUNDS; ++r) c1_px[r] = src[min(tid_img + r * TPI, 391)];   // 2 pixels (one dword) per load
     }
   }
   // ---- zero the whole tile (halo + slack), then fill the interior ----
@@ -223,17 +225,17 @@ __global__ __launch_bounds__(IMGS * 2 * NW * 64, MINW) void conv5x5_igemm(
     constexpr int TILE_BYTES = IMGS * TPOS * KP * 2;
     bf16* img_all = reinterpret_cast<bf16*>(smem + TILE_BYTES);                                   // [IMGS][32 x 96]
     bf16* orow_all = reinterpret_cast<bf16*>(smem + TILE_BYTES + IMGS * kC1ImgElems * 2);         // [waves][16 x 32]
-    uint8_t* arow_all = reinterpret_cast<uint8_t*>(orow_all + IMGS * 4 * 512);                     // [waves][16 x 32]
+    uint8_t* arow_all = reinterpret_cast<uint8_t*>(orow_all + IMGS * 2 * NW * 512);                // [waves][16 x 32]
     bf16* img_w = img_all + w_img * kC1ImgElems;
     bf16* orow = orow_all + wave * 512;
     uint8_t* arow = arow_all + wave * 512;
     const int b = img0 + w_img;
-    const int tid_img = tid & 255, wi = wave & 3;
+    const int tid_img = tid % TPI, wi = wave % (2 * NW);
     const Conv1Frags& frags = c1_frags;
     if (b < B) {
 #pragma unroll
-      for (int r = 0; r < 2; ++r) {
-        const int i = tid_img + r * 256;
+      for (int r = 0; r < PX_ROUNDS; ++r) {
+        const int i = tid_img + r * TPI;
         if (i < 392) reinterpret_cast<unsigned*>(img_w)[((i / 14 + 2) * kC1Pitch + 2) / 2 + i % 14] = c1_px[r];
       }
     }
@@ -242,7 +244,7 @@ __global__ __launch_bounds__(IMGS * 2 * NW * 64, MINW) void conv5x5_igemm(
 #if DTF_TIMING
     long long tr_mma = 0, tr_copy = 0, tr_prev = wall_clock64();
 #endif
-    for (int rp = wi; rp < 14; rp += 4) {
+    for (int rp = wi; rp < 14; rp += 2 * NW) {
       conv1_pooled_row(img_w, rp, frags, orow, arow, lane);
 #if DTF_TIMING
       { long long t = wall_clock64(); tr_mma += t - tr_prev; tr_prev = t; }
@@ -867,7 +869,7 @@ static int launch_igemm(const void* in, const void* in_arg, const void* wk,
   constexpr int KP = (KC % 64 == 0) ? KC + 8 : KC;
   // fused conv1: + zero-haloed input images + per-wave pooled-row staging (bf16 row + argmax row)
   constexpr size_t tile_lds = (size_t)IMGS * igemm_tile_pos(KC) * KP * 2;
-  constexpr size_t fwd_extra = (size_t)IMGS * kC1ImgElems * 2 + (size_t)IMGS * 4 * (1024 + 512);
+  constexpr size_t fwd_extra = (size_t)IMGS * kC1ImgElems * 2 + (size_t)IMGS * 2 * NW * (1024 + 512);
   // fused conv1 wgrad: dx + shifted image copies + half a gradient tile, aliased over the (dead) conv2 tile
   constexpr size_t c1w_lds = (size_t)IMGS * 196 * NC * 2 + kCpBytes + (size_t)kFusedC1wDyRows * kDy1RowBytes;
   constexpr size_t lds = !FUSE1 ? tile_lds : (MODE == MODE_FWD ? tile_lds + fwd_extra : (tile_lds > c1w_lds ? tile_lds : c1w_lds));
@@ -899,6 +901,15 @@ static int launch_wgrad(const void* x, const void* gpool, const void* arg, void*
   return DTF_LAUNCH_CHECK();
 }
 
+static int conv2_small_batch() {
+  static int v = -1;
+  if (v < 0) {
+    const char* e = getenv("DTF_IMGS1_MAX_B");
+    v = (e && *e) ? atoi(e) : 640;
+    if (v < 0) v = 0;
+  }
+  return v;
+}
 extern "C" {
 
 // packed (2 * 25*cin*cout bf16) = [fwd pack | dgrad pack] of the bf16 HWIO weights w
@@ -928,6 +939,12 @@ int dtf_conv12_fwd(const void* images, const void* idx, void* idx_out, const voi
   if (state && (!idx_out || n == 0 || (1ull << (2 * hb)) < n)) return -3;
   Conv1Fused c{(const bf16*)images, (const int*)idx, SampleArgs{(const int64_t*)state, (int*)idx_out, n, hb, seed, shuffle},
                (const float*)w1, (const float*)b1, (bf16*)p1, (uint8_t*)arg1};
+  // up to conv2_small_batch() images: ONE image per 8-wave workgroup (4-way n split), twice the workgroups and half
+  // the serial work of each -- at batch 100 the two-image kernel is 50 workgroups on 256 CUs, 17 us of latency chain.
+  // Measured with the matching dgrad launch (step, one device): batch 32..256 -11..-13 %, 512 -4 %, 640 -1.4 %,
+  // 768 +-0, 1024 +5 % (two images per workgroup share the B fragments of a step)
+  if (B <= conv2_small_batch())
+    return launch_igemm<32, 32, 64, 1, 4, MODE_FWD, 4, true>(nullptr, nullptr, wT, bias2, p2, arg2, B, s, c);
   return launch_igemm<32, 32, 64, 2, 2, MODE_FWD, 4, true>(nullptr, nullptr, wT, bias2, p2, arg2, B, s, c);
 }
 
@@ -942,13 +959,24 @@ int dtf_conv2_dgrad(const void* gpool, const void* arg, const void* w, void* dx,
 }
 
 // Fused conv2 dgrad -> conv1 filter/bias gradient of the 1 -> 32 -> 64 model (see Conv1WgradFused): dx is
-// never written.  part1 must hold ((B + 1) / 2) slabs of 26 * 32 floats (one per workgroup).
-int dtf_conv2_dgrad_conv1_wgrad(const void* gpool, const void* arg2, const void* w, const void* images,
-                                const void* idx, const void* arg1, void* part1, int B, hipStream_t s) {
+// never written.  part1 holds G slabs of 26 * 32 floats, one per workgroup: G = (B + 1) / 2 selects two images per
+// workgroup, G = B one image per workgroup (4 waves, 2-way n split: the small-batch launch, see dtf_conv12_fwd).
+int dtf_conv2_dgrad_conv1_wgrad_g(const void* gpool, const void* arg2, const void* w, const void* images,
+                                  const void* idx, const void* arg1, void* part1, int B, int G, hipStream_t s) {
   if (!idx) return -3;
   Conv1WgradFused c{(const bf16*)images, (const int*)idx, (const uint8_t*)arg1, (float*)part1};
+  if (G == B && B > 1)
+    return launch_igemm<64, 32, 32, 1, 2, MODE_DGRAD, 3, true>(gpool, arg2, w, nullptr, nullptr, nullptr, B, s, Conv1Fused{}, c);
+  if (G != (B + 1) / 2) return -3;
   return launch_igemm<64, 32, 32, 2, 1, MODE_DGRAD, 3, true>(gpool, arg2, w, nullptr, nullptr, nullptr, B, s, Conv1Fused{}, c);
 }
+int dtf_conv2_dgrad_conv1_wgrad(const void* gpool, const void* arg2, const void* w, const void* images,
+                                const void* idx, const void* arg1, void* part1, int B, hipStream_t s) {
+  return dtf_conv2_dgrad_conv1_wgrad_g(gpool, arg2, w, images, idx, arg1, part1, B, (B + 1) / 2, s);
+}
+// batch size up to which the fused kernels of the 32/64 model take one image per workgroup (DTF_IMGS1_MAX_B overrides;
+// engine.py reads the same variable to size the conv1 slabs)
+int dtf_conv2_small_batch(void) { return conv2_small_batch(); }
 
 // wgrad partial slabs: part [G][25*cin*cout + cout].  nt = 16-wide co tiles per wave (2 or 4; see conv5x5_wgrad);
 // 0 picks 4 for the widened model (32 output tiles x G) and 2 for the 32/64 model, DTF_C2W_NT overrides (tools).

@@ -17,6 +17,8 @@ struct DtfEngineDesc {
   int fc1_splits;    // split-K factor the partial-product buffer fc1_part was sized for (B rows each)
   int c2_nt;         // bf16 conv2 wgrad: 16-wide co tiles per wave (2 | 4), 0 = the kernel's choice by model
   int dgrad_splits;  // fp32 fc1 dgrad at a small batch: K ranges summed from dgrad_part (1: plain GEMM)
+  int c1w_imgs;      // fused conv2 dgrad -> conv1 wgrad kernel: images per workgroup (2, or 1 = the small-batch launch
+                     // with c1_g == B slabs); 0: two kernels
   unsigned ds_n, ds_hb, sample_seed, fuse_dense_update;  // last: fc1 SGD update inside its wgrad GEMM (1 GPU)
   uint64_t seed;
   float keep_prob;
@@ -170,16 +172,16 @@ int dtf_engine_forward_dense(const DtfEngineDesc* e, const void* labels, const v
 }
 
 // conv2 dgrad followed by the conv1 filter gradient.  The 1 -> 32 -> 64 model runs both as ONE kernel
-// (dx stays in LDS; csrc/kernels/conv2.hip Conv1WgradFused) which writes exactly (B + 1) / 2 slabs --
-// engine.py sizes c1_g accordingly.
+// (dx stays in LDS; csrc/kernels/conv2.hip Conv1WgradFused) which writes one slab per workgroup -- (B + 1) / 2 with
+// two images per workgroup, B with one (c1w_imgs; engine.py sizes c1_g accordingly).
 static int dgrad_conv1_wgrad(const DtfEngineDesc* e, const void* images, const void* idx, hipStream_t s) {
   if (is_f32(e)) {
     DTF_TRY(dtf_conv2_f32_dgrad(e->dflat, e->arg2, f32at(e->wc2T, 25L * e->c1 * e->c2), e->dp1, e->B, e->c1, e->c2, s));
     return dtf_conv1_f32_wgrad(images, idx, e->dp1, e->arg1, e->c1_part, e->B, e->c1, e->c1_g, s);
   }
-  if (e->c1 == 32 && e->c2 == 64 && idx && e->c1_g == (e->B + 1) / 2)
-    return dtf_conv2_dgrad_conv1_wgrad(e->dflat, e->arg2, bf16at(e->wc2T, 25L * e->c1 * e->c2), images, idx, e->arg1,
-                                       e->c1_part, e->B, s);
+  if (e->c1 == 32 && e->c2 == 64 && idx && e->c1w_imgs > 0 && e->c1_g == (e->B + e->c1w_imgs - 1) / e->c1w_imgs)
+    return dtf_conv2_dgrad_conv1_wgrad_g(e->dflat, e->arg2, bf16at(e->wc2T, 25L * e->c1 * e->c2), images, idx, e->arg1,
+                                         e->c1_part, e->B, e->c1_g, s);
   DTF_TRY(dtf_conv2_dgrad(e->dflat, e->arg2, bf16at(e->wc2T, 25L * e->c1 * e->c2), e->dp1, e->B, e->c1, e->c2, s));
   return dtf_conv1_wgrad(images, idx, e->dp1, e->arg1, e->c1_part, e->B, e->c1, e->c1_g, s);
 }

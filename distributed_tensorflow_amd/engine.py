@@ -205,7 +205,10 @@ class HipEngine:
         # Measured (bench.py A/B): +2.7 % at batch 256, neutral at 1024, -10 % at 4096+ (lower occupancy of the
         # dgrad phase, one slab per two images) -> fused up to 1024 images per GPU.  Env var: A/B switch for tools.
         fused_c1w = (C1, C2) == (32, 64) and B <= 1024 and dtype == "bf16" and os.environ.get("DTF_FUSED_C1W", "1") == "1"
-        self.c1_g = (B + 1) // 2 if fused_c1w else max(1, min(B, 512))
+        # up to dtf_conv2_small_batch() images the fused kernels take ONE image per workgroup (twice the workgroups,
+        # half the serial work of each: at batch 100 two images per workgroup are 50 workgroups on 256 CUs)
+        self.c1w_imgs = 0 if not fused_c1w else (1 if 1 < B <= int(self.lib.dtf_conv2_small_batch()) else 2)
+        self.c1_g = (B + self.c1w_imgs - 1) // self.c1w_imgs if fused_c1w else max(1, min(B, 512))
         self.c1_stride = 26 * C1
         self.c1_part = torch.empty((self.c1_g, self.c1_stride), **f32)
 
@@ -229,7 +232,7 @@ class HipEngine:
         sp, lay = self.spec, self.layout
         d.B, d.c1, d.c2, d.hidden, d.flat, d.classes = self.B, sp.c1, sp.c2, sp.hidden, sp.flat, sp.classes
         d.head_ks, d.c2_g, d.c1_g = self.head_ks, self.c2_g, self.c1_g
-        d.fc1_splits, d.dgrad_splits, d.c2_nt = self.fc1_splits, self.dgrad_splits, self.c2_nt
+        d.fc1_splits, d.dgrad_splits, d.c2_nt, d.c1w_imgs = self.fc1_splits, self.dgrad_splits, self.c2_nt, self.c1w_imgs
         d.optimizer = 0 if self.optimizer == "sgd" else 1
         d.shuffle, d.multi_stream = int(self.shuffle), int(self.multi_stream)
         # fc1 SGD update inside its wgrad GEMM (single-GPU train_step only; the wd1 gradient is then never

@@ -36,6 +36,9 @@ _SIGS = {
                        c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p],
     "dtf_conv2_dgrad": [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p],
     "dtf_conv2_dgrad_conv1_wgrad": [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p],
+    "dtf_conv2_dgrad_conv1_wgrad_g": [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int,
+                                      c_void_p],
+    "dtf_conv2_small_batch": [],
     "dtf_conv2_wgrad": [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p],
     "dtf_conv2_wgrad_nt": [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p],
     "dtf_gemm_nt": [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_int,
@@ -133,7 +136,7 @@ class EngineDesc(ctypes.Structure):
 
     _fields_ = (
         [(n, c_int) for n in ("B", "c1", "c2", "hidden", "flat", "classes", "head_ks", "c2_g", "c1_g", "optimizer",
-                              "shuffle", "multi_stream", "fc1_splits", "c2_nt", "dgrad_splits")]
+                              "shuffle", "multi_stream", "fc1_splits", "c2_nt", "dgrad_splits", "c1w_imgs")]
         + [(n, c_uint) for n in ("ds_n", "ds_hb", "sample_seed", "fuse_dense_update")]
         + [("seed", c_uint64), ("keep_prob", c_float), ("dtype", c_int), ("n_total", c_long)]
         + [(n, c_long) for n in ("off_out_w", "off_out_b", "off_bd1", "off_wd1", "off_wc2", "off_bc2", "off_wc1",

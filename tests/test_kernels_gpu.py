@@ -174,10 +174,12 @@ def test_conv2_fwd(gpu_lib, B, C1, C2):
     assert bool(((arg == 4) == (pooled.float() <= 0)).all())
 
 
-@pytest.mark.parametrize("B", [1, 2, 37, 256])
+@pytest.mark.parametrize("B", [1, 2, 37, 256, 640, 641, 801])
 def test_fused_conv1_conv2_forward_is_bitwise_the_two_kernels(gpu_lib, B):
     """conv1 computed inside conv2's staging phase (one launch) == conv1_fwd then conv2_fwd, with an
-    explicit gather and with the on-device batch sampler."""
+    explicit gather and with the on-device batch sampler.  Up to dtf_conv2_small_batch() (640) images the fused
+    kernel takes one image per 8-wave workgroup, above that two."""
+    assert gpu_lib.dtf_conv2_small_batch() == 640
     from distributed_tensorflow_amd.data import half_bits
     g = torch.Generator(device="cpu").manual_seed(31)
     N, seed = 300, 11
@@ -215,9 +217,11 @@ def test_fused_conv1_conv2_forward_is_bitwise_the_two_kernels(gpu_lib, B):
 
 
 @pytest.mark.parametrize("B", [1, 2, 33, 128])
-def test_fused_conv2_dgrad_conv1_wgrad_matches_the_two_kernels(gpu_lib, B):
+@pytest.mark.parametrize("imgs", [1, 2])
+def test_fused_conv2_dgrad_conv1_wgrad_matches_the_two_kernels(gpu_lib, B, imgs):
     """dx kept in LDS and consumed by the conv1 filter gradient in the same launch == conv2_dgrad then
-    conv1_wgrad (same arithmetic per image; only the image -> slab assignment differs)."""
+    conv1_wgrad (same arithmetic per image; only the image -> slab assignment differs), with two images per
+    workgroup and with one (the small-batch launch: B slabs)."""
     g = torch.Generator(device="cpu").manual_seed(41)
     N = 200
     images = bf(torch.rand(N, 784, generator=g)).to(DEV)
@@ -230,12 +234,18 @@ def test_fused_conv2_dgrad_conv1_wgrad_matches_the_two_kernels(gpu_lib, B):
     arg1 = torch.randint(0, 5, (B, 14, 14, 32), generator=g, dtype=torch.uint8).to(DEV)
     dx = torch.empty(B, 14, 14, 32, dtype=torch.bfloat16, device=DEV)
     check(gpu_lib.dtf_conv2_dgrad(ptr(gp), ptr(arg2), ptr(packed[1]), ptr(dx), B, 32, 64, stream()), "dgrad")
-    G = (B + 1) // 2
+    G = (B + imgs - 1) // imgs
     ref = torch.zeros(G, 26 * 32, device=DEV)
     check(gpu_lib.dtf_conv1_wgrad(ptr(images), ptr(idx), ptr(dx), ptr(arg1), ptr(ref), B, 32, G, stream()), "conv1_wgrad")
     got = torch.full((G, 26 * 32), float("nan"), device=DEV)
-    check(gpu_lib.dtf_conv2_dgrad_conv1_wgrad(ptr(gp), ptr(arg2), ptr(packed[1]), ptr(images), ptr(idx), ptr(arg1),
-                                              ptr(got), B, stream()), "fused")
+    if imgs == 2:
+        check(gpu_lib.dtf_conv2_dgrad_conv1_wgrad(ptr(gp), ptr(arg2), ptr(packed[1]), ptr(images), ptr(idx), ptr(arg1),
+                                                  ptr(got), B, stream()), "fused")
+    elif B == 1:
+        pytest.skip("one image: the two launches coincide")
+    else:
+        check(gpu_lib.dtf_conv2_dgrad_conv1_wgrad_g(ptr(gp), ptr(arg2), ptr(packed[1]), ptr(images), ptr(idx), ptr(arg1),
+                                                    ptr(got), B, G, stream()), "fused, one image per workgroup")
     torch.cuda.synchronize()
     assert bool(torch.isfinite(got).all())
     assert rel_err(got.sum(0), ref.sum(0)) < 1e-5
