@@ -8,7 +8,9 @@ run --steps 20 --warmup 5
 run --dtype fp32 --steps 300
 run --per_gpu_batch 100 --steps 2000
 run --per_gpu_batch 100 --steps 2000 --dtype fp32
+run --per_gpu_batch 128 --steps 2000
 run --per_gpu_batch 256 --steps 2000
+run --per_gpu_batch 512 --steps 2000
 run --per_gpu_batch 4096 --steps 300
 run --per_gpu_batch 4096 --steps 100 --dtype fp32
 run --optimizer adam
