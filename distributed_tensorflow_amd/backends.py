@@ -271,8 +271,9 @@ class HipBackend(Backend):
             n = self.layout.total
             k = 3 if e.optimizer == "adam" else 1
             self._snap = dict(stream=torch.cuda.Stream(dev), dev=torch.empty((k, n), dtype=torch.float32, device=dev),
-                              host=torch.empty((k, n), dtype=torch.float32).pin_memory(),
-                              st_dev=torch.empty_like(e.state), st_host=torch.empty(e.state.shape, dtype=e.state.dtype).pin_memory(),
+                              host=torch.empty((k, n), dtype=torch.float32, pin_memory=True),
+                              st_dev=torch.empty_like(e.state),
+                              st_host=torch.empty(e.state.shape, dtype=e.state.dtype, pin_memory=True),
                               copied=torch.cuda.Event(), landed=torch.cuda.Event())
         sn = self._snap
         cur = torch.cuda.current_stream(dev)

@@ -535,12 +535,13 @@ def test_head(gpu_lib, B, H):
     assert rel_err(got[H * 10 + 12:], da.float().sum(0)) < 1e-4
 
 
-@pytest.mark.parametrize("B,KS", [(1024, 32), (1000, 7), (64, 8)])
+@pytest.mark.parametrize("B,KS", [(1024, 32), (1000, 7), (64, 8), (100, 8), (256, 8), (300, 8)])
 def test_fc1_dgrad_with_head_wgrad_workgroups_matches_the_two_kernels(gpu_lib, B, KS):
     """One launch = the fc1 dgrad GEMM tiles + the output-layer wgrad workgroups (gemm.hip HEADW).
     The GEMM result is bitwise the plain kernel's; the reduction (8 row phases instead of 4, so a
     different fp32 summation order) matches the stand-alone kernel and the fp32 reference.
-    B = 64 is below the 128-tile threshold: the call falls back to the two launches."""
+    B <= 256: the 64 x 64 tile kernel carries the reduction workgroups (one round of tiles + guests); B = 300 is
+    neither that nor a full round of 128 x 128 tiles: the call falls back to the two launches."""
     H, F_ = 1024, 3136
     g = torch.Generator(device="cpu").manual_seed(33)
     da = bf(torch.randn(B, H, generator=g) * (torch.rand(B, H, generator=g) > 0.5)).to(DEV)
