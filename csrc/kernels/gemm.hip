@@ -901,11 +901,12 @@ int dtf_gemm_nt_head_wgrad(const void* A, const void* Bw, void* C, int M, int N,
   // One launch only while the GEMM is a single round of tiles with CUs to spare (192..256 tiles on 256 CUs).
   // With more tiles the reduction workgroups -- dispatched after the last tile -- become a serial tail
   // (measured: -3 % at 4096 images, -5 % at 8192), and there the separate kernel packs 4 workgroups per CU.
-  // Small batches (the 64 x 64 x 4-wave tile): the same single launch while tiles + reduction workgroups fit the
-  // chip in one round (M <= 256 for the fc1 shapes) -- at batch 100 a launch of its own is 4.5 us of a 76 us step.
+  // Less than a round of 128 x 128 tiles (the 64 x 64 x 4-wave tile, several workgroups per CU): the same single
+  // launch -- at batch 100 a launch of its own is 4.5 us of a 76 us step; measured -4..-6.5 % on the step from 32 to
+  // 896 images (whether the tiles are 64 x 64 or 128 x 128 makes no difference between 576 and 960 images).
   const long tiles64 = (long)((M + 63) / 64) * ((N + 63) / 64);
   const long guests = (long)((H + kHeadCols - 1) / kHeadCols) * KS;
-  if (tiles < 192 && tiles64 + guests <= 256 && H % 4 == 0) {
+  if (tiles < 192 && H % 4 == 0) {
     HeadWgradArgs hw{(const bf16*)h1, (const float*)dlogits, (const bf16*)da, (float*)part, Bsz, H, (Bsz + KS - 1) / KS,
                      (H + kHeadCols - 1) / kHeadCols};
     DropoutArgs d{1.0f, 0, nullptr};

@@ -540,8 +540,7 @@ def test_fc1_dgrad_with_head_wgrad_workgroups_matches_the_two_kernels(gpu_lib, B
     """One launch = the fc1 dgrad GEMM tiles + the output-layer wgrad workgroups (gemm.hip HEADW).
     The GEMM result is bitwise the plain kernel's; the reduction (8 row phases instead of 4, so a
     different fp32 summation order) matches the stand-alone kernel and the fp32 reference.
-    B <= 256: the 64 x 64 tile kernel carries the reduction workgroups (one round of tiles + guests); B = 300 is
-    neither that nor a full round of 128 x 128 tiles: the call falls back to the two launches."""
+    Below a round of 128 x 128 tiles (B < 961 here) the 64 x 64 tile kernel carries the reduction workgroups."""
     H, F_ = 1024, 3136
     g = torch.Generator(device="cpu").manual_seed(33)
     da = bf(torch.randn(B, H, generator=g) * (torch.rand(B, H, generator=g) > 0.5)).to(DEV)
