@@ -97,6 +97,8 @@ __device__ __forceinline__ void sum_slabs4(const float* p, size_t stride, int S,
 //    (in-kernel stamps, tools/conv_timeline.py run 1024 head: workgroup starts spread over 2.7 us of a 5.4 us kernel).
 //    ONE wave per row (16 units per lane, no LDS, no barriers, four rows to a workgroup) was measured too: its row
 //    takes 4.4 us against 2.8 us, step 0.1429 vs 0.1416 ms -- the latency chain of a lone wave per SIMD again.
+//    TWO rows per 256-thread workgroup (half as many workgroups to dispatch, same waves): 0.1405 vs 0.1408 ms --
+//    the start spread is a wave-launch rate, not a workgroup-dispatch rate; not kept.
 template <typename AT, int NW, int V, bool ONEPASS>
 __global__ __launch_bounds__(NW * 64) void head_fwd_bwd(
     AT* __restrict__ h1, Fc1Epilogue epi, const float* __restrict__ wT, const float* __restrict__ bias,
