@@ -156,7 +156,7 @@ class HipEngine:
         tiles = ((B + 127) // 128) * ((H + 127) // 128)
         # split-K of the fc1 forward GEMM (csrc/runtime/engine.hip auto_splits: ~256 workgroups; the fp32 kernels go to
         # 32 splits, which is what fills the chip at the reference's batch 100)
-        self.fc1_splits = max(1, min(32 if dtype == "fp32" else 8, -(-256 // tiles)))
+        self.fc1_splits = max(1, min(32 if dtype == "fp32" else (16 if tiles <= 8 else 8), -(-256 // tiles)))
         self.fc1_part = torch.empty((self.fc1_splits, B, H), **f32)
         # fp32 fc1 dgrad at a small batch: ceil(B / 128) * ceil(FLAT / 128) output tiles do not fill 256 CUs (batch
         # 100: 25) -> split-K partial products, summed by the slab-reduction kernel.  (The bf16 dgrad uses 64-row
