@@ -16,6 +16,7 @@
 // Register-prefetched double buffering, one barrier per K tile: a tile is 2048 cycles of MFMA per wave
 // against ~150 cycles of LDS traffic, so this simple pipeline already leaves the matrix pipe as the bound.
 #include "f32_common.hpp"
+#include "head_wgrad_core.hpp"
 #include <hip/hip_ext.h>
 
 // csrc/kernels/optim.hip: sums part[G][stride] slabs into out (the split-K dgrad below reuses it)
@@ -27,10 +28,14 @@ namespace dtf {
 enum { F32_KCONTIG = 0, F32_KSLOW = 1 };
 enum { F32_EPI_STORE = 0, F32_EPI_SGD = 1 };
 
-template <int LA, int LB, int EPI>
+// HEADW: the grid has one extra z layer whose workgroups compute the output-layer weight gradient
+// (head_wgrad_core.hpp) -- dispatched after the tiles, into the CUs the fc1 dgrad's 200 tiles leave idle, instead of
+// a launch of their own (the bf16 kernel set does the same, gemm.hip HEADW).
+template <int LA, int LB, int EPI, bool HEADW = false>
 __global__ __launch_bounds__(512) void gemm_f32(const float* A, const float* Bm, float* __restrict__ C, int M, int N,
                                                 int K, int lda, int ldb, int ldc, int tiles_per_split,
-                                                const float* __restrict__ hyper) {
+                                                const float* __restrict__ hyper,
+                                                HeadWgradArgsT<float> hw = HeadWgradArgsT<float>{}, int hw_guests = 0) {
   constexpr int BM = 128, BN = 128, BK = 32, NT = 512;
   constexpr int PK = BK + 4;
   constexpr int A_FLOATS = (LA == F32_KCONTIG) ? BM * PK : BK * BM;
@@ -38,6 +43,14 @@ __global__ __launch_bounds__(512) void gemm_f32(const float* A, const float* Bm,
   extern __shared__ __attribute__((aligned(16))) float smem_f32[];
   float* sA = smem_f32;                  // [2][A_FLOATS]
   float* sB = smem_f32 + 2 * A_FLOATS;   // [2][B_FLOATS]
+  if constexpr (HEADW) {
+    static_assert(2 * (A_FLOATS + B_FLOATS) >= head_wgrad_lds_floats<8>(), "head wgrad scratch must fit in the tile buffers");
+    if (blockIdx.z + 1 == gridDim.z) {   // the guest layer
+      const int id = blockIdx.y * gridDim.x + blockIdx.x;
+      if (id < hw_guests) head_wgrad_block<8, float>(hw, id % hw.nbx, id / hw.nbx, smem_f32);
+      return;
+    }
+  }
 
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wave >> 2, wn = wave & 3;
@@ -193,7 +206,7 @@ static int launch_gemm_f32(const void* A, const void* B, void* C, int M, int N, 
   }
   // done: bound to the kernel's own completion (see dtf_gemm_tn_ev in gemm.hip)
   hipExtLaunchKernelGGL(kern, dim3((N + 127) / 128, (M + 127) / 128, S), dim3(512), lds, s, nullptr, done, 0, (const float*)A,
-                        (const float*)B, (float*)C, M, N, K, lda, ldb, ldc, tps, (const float*)hyper);
+                        (const float*)B, (float*)C, M, N, K, lda, ldb, ldc, tps, (const float*)hyper, HeadWgradArgsT<float>{}, 0);
   return (int)hipGetLastError();
 }
 
@@ -226,6 +239,37 @@ int dtf_gemm_f32_nn_partial(const void* A, const void* B, void* part, int M, int
 int dtf_gemm_f32_nt(const void* A, const void* B, void* C, int M, int N, int K, int lda, int ldb, int ldc, hipStream_t s) {
   if ((K & 31) || (lda & 3) || (ldb & 3)) return -3;
   return launch_gemm_f32<F32_KCONTIG, F32_KCONTIG, F32_EPI_STORE>(A, B, C, M, N, K, lda, ldb, ldc, 1, K / 32, nullptr, s);
+}
+
+// fc1 dgrad and the output-layer weight gradient in ONE launch (see gemm_f32 HEADW) while the GEMM is a single round of
+// tiles with CUs to spare; otherwise the two launches.
+int dtf_head_f32_wgrad(const void* h1, const void* dlogits, const void* da, void* part, int B, int H, int KS, hipStream_t s);
+int dtf_gemm_f32_nt_head_wgrad(const void* A, const void* B, void* C, int M, int N, int K, int lda, int ldb, int ldc,
+                               const void* h1, const void* dlogits, const void* da, void* part, int Bsz, int H, int KS,
+                               hipStream_t s) {
+  if ((K & 31) || (lda & 3) || (ldb & 3)) return -3;
+  if (KS <= 0) return -2;
+  const int gx = (N + 127) / 128, gy = (M + 127) / 128;
+  const long tiles = (long)gx * gy;
+  const int nbx = (H + kHeadCols - 1) / kHeadCols;
+  const long guests = (long)nbx * KS;
+  if (tiles < 128 || tiles > 256 || guests > tiles || (H % 4)) {
+    int rc = dtf_head_f32_wgrad(h1, dlogits, da, part, Bsz, H, KS, s);
+    if (rc) return rc;
+    return dtf_gemm_f32_nt(A, B, C, M, N, K, lda, ldb, ldc, s);
+  }
+  HeadWgradArgsT<float> hw{(const float*)h1, (const float*)dlogits, (const float*)da, (float*)part, Bsz, H,
+                           (Bsz + KS - 1) / KS, nbx};
+  constexpr size_t lds = (size_t)(4 * 128 * 36) * 4;
+  auto kern = gemm_f32<F32_KCONTIG, F32_KCONTIG, F32_EPI_STORE, true>;
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    attr_set = true;
+  }
+  hipLaunchKernelGGL(kern, dim3(gx, gy, 2), dim3(512), lds, s, (const float*)A, (const float*)B, (float*)C, M, N, K, lda,
+                     ldb, ldc, K / 32, (const float*)nullptr, hw, (int)guests);
+  return (int)hipGetLastError();
 }
 
 // The same product for a small batch: M / 128 * N / 128 output tiles do not fill 256 CUs (batch 100: 25 workgroups,

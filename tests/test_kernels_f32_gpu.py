@@ -264,6 +264,37 @@ def test_head_f32(gpu_lib, B, H):
     assert rel_err(got[H * 10 + 12:], da.double().sum(0)) < TOL
 
 
+@pytest.mark.parametrize("B,KS", [(1024, 16), (1000, 7), (640, 10), (100, 8)])
+def test_fc1_dgrad_f32_with_head_wgrad_workgroups_matches_the_two_kernels(gpu_lib, B, KS):
+    """One launch = the fp32 fc1 dgrad GEMM tiles + one extra grid layer of output-layer wgrad workgroups (gemm_f32
+    HEADW).  The GEMM result is bitwise the plain kernel's; the reduction (8 row phases instead of 4: another fp32
+    summation order) matches the stand-alone kernel and the fp64 reference.  B = 100 is less than half a round of
+    tiles: the call falls back to the two launches."""
+    H, F_ = 1024, 3136
+    g = torch.Generator(device="cpu").manual_seed(61)
+    da = (torch.randn(B, H, generator=g) * (torch.rand(B, H, generator=g) > 0.5)).to(DEV)
+    w = (torch.randn(F_, H, generator=g) * 0.03).to(DEV)
+    h1 = torch.randn(B, H, generator=g).clamp_min(0).to(DEV)
+    dlog = (torch.randn(B, 10, generator=g) / B).to(DEV)
+    stride = H * 10 + 12 + H
+    C0 = torch.empty(B, F_, device=DEV)
+    C1 = torch.full((B, F_), 7.0, device=DEV)
+    part0 = torch.empty(KS, stride, device=DEV)
+    part1 = torch.full((KS, stride), 3.0, device=DEV)
+    check(gpu_lib.dtf_gemm_f32_nt(ptr(da), ptr(w), ptr(C0), B, F_, H, H, H, F_, stream()), "nt")
+    check(gpu_lib.dtf_head_f32_wgrad(ptr(h1), ptr(dlog), ptr(da), ptr(part0), B, H, KS, stream()), "head_wgrad")
+    check(gpu_lib.dtf_gemm_f32_nt_head_wgrad(ptr(da), ptr(w), ptr(C1), B, F_, H, H, H, F_, ptr(h1), ptr(dlog), ptr(da),
+                                             ptr(part1), B, H, KS, stream()), "nt+head_wgrad")
+    torch.cuda.synchronize()
+    assert torch.equal(C0, C1)
+    assert rel_err(C1, (da.double() @ w.double().t())) < 1e-5
+    assert rel_err(part1, part0) < 1e-5
+    got = part1.double().sum(0)
+    assert rel_err(got[:H * 10].reshape(H, 10), h1.double().t() @ dlog.double()) < 1e-5
+    assert rel_err(got[H * 10:H * 10 + 10], dlog.double().sum(0)) < 1e-5
+    assert rel_err(got[H * 10 + 12:], da.double().sum(0)) < 1e-5
+
+
 @pytest.mark.parametrize("keep", [1.0, 0.6])
 def test_head_f32_fused_fc1_epilogue(gpu_lib, keep):
     """split-K partials -> (bias, ReLU, dropout, h1, logits, loss, dlogits, da) in one launch, fp32 activations:
