@@ -110,9 +110,9 @@ int dtf_conv2_f32_wgrad(const void* x, const void* gpool, const void* arg, void*
 int dtf_gemm_f32_nn_partial(const void* A, const void* B, void* part, int M, int N, int K, int lda, int ldb, int S,
                             hipStream_t s);
 int dtf_gemm_f32_nt(const void* A, const void* B, void* C, int M, int N, int K, int lda, int ldb, int ldc, hipStream_t s);
-int dtf_gemm_f32_nt_head_wgrad(const void* A, const void* B, void* C, int M, int N, int K, int lda, int ldb, int ldc,
-                               const void* h1, const void* dlogits, const void* da, void* part, int Bsz, int H, int KS,
-                               hipStream_t s);
+int dtf_gemm_f32_nt_head_wgrad(const void* A, const void* B, void* splitk_part, void* C, int M, int N, int K, int lda,
+                               int ldb, int ldc, int S, const void* h1, const void* dlogits, const void* da, void* part,
+                               int Bsz, int H, int KS, hipStream_t s);
 int dtf_gemm_f32_nt_splitk(const void* A, const void* B, void* part, void* C, int M, int N, int K, int lda, int ldb,
                            int ldc, int S, hipStream_t s);
 int dtf_gemm_f32_tn_ev(const void* A, const void* B, void* C, int M, int N, int K, int lda, int ldb, int ldc,

@@ -28,14 +28,15 @@ namespace dtf {
 enum { F32_KCONTIG = 0, F32_KSLOW = 1 };
 enum { F32_EPI_STORE = 0, F32_EPI_SGD = 1 };
 
-// HEADW: the grid has one extra z layer whose workgroups compute the output-layer weight gradient
+// HEADW: the grid has hw_layers extra z layers whose workgroups compute the output-layer weight gradient
 // (head_wgrad_core.hpp) -- dispatched after the tiles, into the CUs the fc1 dgrad's 200 tiles leave idle, instead of
 // a launch of their own (the bf16 kernel set does the same, gemm.hip HEADW).
 template <int LA, int LB, int EPI, bool HEADW = false>
 __global__ __launch_bounds__(512) void gemm_f32(const float* A, const float* Bm, float* __restrict__ C, int M, int N,
                                                 int K, int lda, int ldb, int ldc, int tiles_per_split,
                                                 const float* __restrict__ hyper,
-                                                HeadWgradArgsT<float> hw = HeadWgradArgsT<float>{}, int hw_guests = 0) {
+                                                HeadWgradArgsT<float> hw = HeadWgradArgsT<float>{}, int hw_guests = 0,
+                                                int hw_layers = 0) {
   constexpr int BM = 128, BN = 128, BK = 32, NT = 512;
   constexpr int PK = BK + 4;
   constexpr int A_FLOATS = (LA == F32_KCONTIG) ? BM * PK : BK * BM;
@@ -45,8 +46,9 @@ __global__ __launch_bounds__(512) void gemm_f32(const float* A, const float* Bm,
   float* sB = smem_f32 + 2 * A_FLOATS;   // [2][B_FLOATS]
   if constexpr (HEADW) {
     static_assert(2 * (A_FLOATS + B_FLOATS) >= head_wgrad_lds_floats<8>(), "head wgrad scratch must fit in the tile buffers");
-    if (blockIdx.z + 1 == gridDim.z) {   // the guest layer
-      const int id = blockIdx.y * gridDim.x + blockIdx.x;
+    const int first_guest_layer = (int)gridDim.z - hw_layers;
+    if ((int)blockIdx.z >= first_guest_layer) {
+      const int id = (((int)blockIdx.z - first_guest_layer) * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;
       if (id < hw_guests) head_wgrad_block<8, float>(hw, id % hw.nbx, id / hw.nbx, smem_f32);
       return;
     }
@@ -206,7 +208,7 @@ static int launch_gemm_f32(const void* A, const void* B, void* C, int M, int N, 
   }
   // done: bound to the kernel's own completion (see dtf_gemm_tn_ev in gemm.hip)
   hipExtLaunchKernelGGL(kern, dim3((N + 127) / 128, (M + 127) / 128, S), dim3(512), lds, s, nullptr, done, 0, (const float*)A,
-                        (const float*)B, (float*)C, M, N, K, lda, ldb, ldc, tps, (const float*)hyper, HeadWgradArgsT<float>{}, 0);
+                        (const float*)B, (float*)C, M, N, K, lda, ldb, ldc, tps, (const float*)hyper, HeadWgradArgsT<float>{}, 0, 0);
   return (int)hipGetLastError();
 }
 
@@ -241,22 +243,31 @@ int dtf_gemm_f32_nt(const void* A, const void* B, void* C, int M, int N, int K, 
   return launch_gemm_f32<F32_KCONTIG, F32_KCONTIG, F32_EPI_STORE>(A, B, C, M, N, K, lda, ldb, ldc, 1, K / 32, nullptr, s);
 }
 
-// fc1 dgrad and the output-layer weight gradient in ONE launch (see gemm_f32 HEADW) while the GEMM is a single round of
-// tiles with CUs to spare; otherwise the two launches.
+// fc1 dgrad and the output-layer weight gradient in ONE launch (see gemm_f32 HEADW) while tiles x K splits + guests are
+// a single round with CUs to spare; otherwise the two launches.  splitk_part != NULL and S > 1: the small-batch split-K
+// product of dtf_gemm_f32_nt_splitk (partials summed into C by the slab-reduction kernel).
 int dtf_head_f32_wgrad(const void* h1, const void* dlogits, const void* da, void* part, int B, int H, int KS, hipStream_t s);
-int dtf_gemm_f32_nt_head_wgrad(const void* A, const void* B, void* C, int M, int N, int K, int lda, int ldb, int ldc,
-                               const void* h1, const void* dlogits, const void* da, void* part, int Bsz, int H, int KS,
-                               hipStream_t s) {
+int dtf_gemm_f32_nt_splitk(const void* A, const void* B, void* part, void* C, int M, int N, int K, int lda, int ldb,
+                           int ldc, int S, hipStream_t s);
+int dtf_gemm_f32_nt_head_wgrad(const void* A, const void* B, void* splitk_part, void* C, int M, int N, int K, int lda,
+                               int ldb, int ldc, int S, const void* h1, const void* dlogits, const void* da, void* part,
+                               int Bsz, int H, int KS, hipStream_t s) {
   if ((K & 31) || (lda & 3) || (ldb & 3)) return -3;
   if (KS <= 0) return -2;
+  const int T = K / 32;
+  if (S < 1 || !splitk_part) S = 1;
+  if (S > T) S = T;
+  const int tps = (T + S - 1) / S;
+  S = (T + tps - 1) / tps;
   const int gx = (N + 127) / 128, gy = (M + 127) / 128;
-  const long tiles = (long)gx * gy;
+  const long tiles = (long)gx * gy, wgs = tiles * S;
   const int nbx = (H + kHeadCols - 1) / kHeadCols;
   const long guests = (long)nbx * KS;
-  if (tiles < 128 || tiles > 256 || guests > tiles || (H % 4)) {
+  const int layers = (int)((guests + tiles - 1) / tiles);
+  if (wgs < 128 || wgs + guests > 288 || (H % 4) || (S > 1 && (ldc != N || (long)M * N > 0x7fffffffL))) {
     int rc = dtf_head_f32_wgrad(h1, dlogits, da, part, Bsz, H, KS, s);
     if (rc) return rc;
-    return dtf_gemm_f32_nt(A, B, C, M, N, K, lda, ldb, ldc, s);
+    return dtf_gemm_f32_nt_splitk(A, B, splitk_part, C, M, N, K, lda, ldb, ldc, S, s);
   }
   HeadWgradArgsT<float> hw{(const float*)h1, (const float*)dlogits, (const float*)da, (float*)part, Bsz, H,
                            (Bsz + KS - 1) / KS, nbx};
@@ -267,9 +278,16 @@ int dtf_gemm_f32_nt_head_wgrad(const void* A, const void* B, void* C, int M, int
     (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     attr_set = true;
   }
-  hipLaunchKernelGGL(kern, dim3(gx, gy, 2), dim3(512), lds, s, (const float*)A, (const float*)B, (float*)C, M, N, K, lda,
-                     ldb, ldc, K / 32, (const float*)nullptr, hw, (int)guests);
-  return (int)hipGetLastError();
+  hipLaunchKernelGGL(kern, dim3(gx, gy, S + layers), dim3(512), lds, s, (const float*)A, (const float*)B,
+                     (float*)(S > 1 ? splitk_part : C), M, N, K, lda, ldb, S > 1 ? N : ldc, tps, (const float*)nullptr, hw,
+                     (int)guests, layers);
+  if (hipGetLastError() != hipSuccess) return -1;
+  if (S <= 1) return 0;
+  const void* parts[1] = {splitk_part};
+  void* outs[1] = {C};
+  int G[1] = {S}, n[1] = {M * N};
+  long st[1] = {(long)M * N};
+  return dtf_reduce_segments(1, parts, outs, G, n, st, s);
 }
 
 // The same product for a small batch: M / 128 * N / 128 output tiles do not fill 256 CUs (batch 100: 25 workgroups,

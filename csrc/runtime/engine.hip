@@ -225,11 +225,10 @@ int dtf_engine_backward_dense(const DtfEngineDesc* e, hipStream_t s) { return ba
 // record_dgrad != 0: e->ev_dgrad is recorded right after fc1 dgrad (the last reader of bf16 wd1).
 static int fc1_dgrad(const DtfEngineDesc* e, int head_w, hipStream_t s) {
   if (is_f32(e)) {
-    if (head_w && e->dgrad_splits <= 1)   // + the output-layer weight gradient as extra workgroups of the same launch
-      return dtf_gemm_f32_nt_head_wgrad(e->da, f32at(e->params, e->off_wd1), e->dflat, e->B, e->flat, e->hidden, e->hidden,
-                                        e->hidden, e->flat, e->h1, e->dlogits, e->da, e->head_part, e->B, e->hidden,
-                                        e->head_ks, s);
-    if (head_w) DTF_TRY(dtf_head_f32_wgrad(e->h1, e->dlogits, e->da, e->head_part, e->B, e->hidden, e->head_ks, s));
+    if (head_w)   // + the output-layer weight gradient as extra workgroups of the same launch
+      return dtf_gemm_f32_nt_head_wgrad(e->da, f32at(e->params, e->off_wd1), e->dgrad_part, e->dflat, e->B, e->flat,
+                                        e->hidden, e->hidden, e->hidden, e->flat, e->dgrad_splits, e->h1, e->dlogits, e->da,
+                                        e->head_part, e->B, e->hidden, e->head_ks, s);
     return dtf_gemm_f32_nt_splitk(e->da, f32at(e->params, e->off_wd1), e->dgrad_part, e->dflat, e->B, e->flat, e->hidden,
                                   e->hidden, e->hidden, e->flat, e->dgrad_splits, s);
   }
