@@ -273,10 +273,13 @@ __global__ __launch_bounds__(256) void metrics_reduce(const float* __restrict__ 
 
 // grid = (H/256, KS).  slab layout per k-split: [H*10 dW_out][12: db_out padded][H db_d1]
 // (body in head_wgrad_core.hpp: the training step runs it inside the fc1 dgrad GEMM launch instead)
-template <typename AT>
-__global__ __launch_bounds__(256) void head_wgrad(HeadWgradArgsT<AT> a) {
-  __shared__ __attribute__((aligned(16))) float red[head_wgrad_lds_floats<4>()];
-  head_wgrad_block<4, AT>(a, blockIdx.x, blockIdx.y, red);
+// NSUB waves per workgroup.  The fp32 set runs 8, like the guest workgroups of its fc1 dgrad launch (gemm_f32 HEADW):
+// the two routes then sum in the same order, and the data-parallel step (guests) stays bit-identical to a replay
+// through the stand-alone kernel -- fp32 has no bf16 rounding of the weights to absorb a last-bit difference.
+template <typename AT, int NSUB>
+__global__ __launch_bounds__(NSUB * 64) void head_wgrad(HeadWgradArgsT<AT> a) {
+  __shared__ __attribute__((aligned(16))) float red[head_wgrad_lds_floats<NSUB>()];
+  head_wgrad_block<NSUB, AT>(a, blockIdx.x, blockIdx.y, red);
 }
 
 }  // namespace dtf
@@ -383,7 +386,7 @@ int dtf_head_wgrad(const void* h1, const void* dlogits, const void* da, void* pa
   if (H % 4) return -3;
   HeadWgradArgs a{(const bf16*)h1, (const float*)dlogits, (const bf16*)da, (float*)part, B, H, rps,
                   (H + kHeadCols - 1) / kHeadCols};
-  hipLaunchKernelGGL(head_wgrad<bf16>, dim3(a.nbx, KS), dim3(256), 0, s, a);
+  hipLaunchKernelGGL((head_wgrad<bf16, 4>), dim3(a.nbx, KS), dim3(256), 0, s, a);
   return (int)hipGetLastError();
 }
 
@@ -394,7 +397,7 @@ int dtf_head_f32_wgrad(const void* h1, const void* dlogits, const void* da, void
   if (H % 4) return -3;
   HeadWgradArgsT<float> a{(const float*)h1, (const float*)dlogits, (const float*)da, (float*)part, B, H, rps,
                           (H + kHeadCols - 1) / kHeadCols};
-  hipLaunchKernelGGL(head_wgrad<float>, dim3(a.nbx, KS), dim3(256), 0, s, a);
+  hipLaunchKernelGGL((head_wgrad<float, 8>), dim3(a.nbx, KS), dim3(512), 0, s, a);
   return (int)hipGetLastError();
 }
 
