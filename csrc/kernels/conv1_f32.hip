@@ -30,7 +30,9 @@ __device__ __forceinline__ void c1f_store_px(float* img, int i4, const f32x4& v)
   *reinterpret_cast<f32x2*>(d + 2) = (f32x2){v[2], v[3]};
 }
 
-// grid = (min(B, ..), C/32), 256 threads = 8 half-waves.  w: fp32 HWIO [25][C].
+// grid = (min(B, ..), C/32, NS), 256 threads = 8 half-waves.  w: fp32 HWIO [25][C].  gridDim.z = NS workgroups share
+// an image's 196 pooling windows (small batches: one workgroup per image is 100 workgroups on 256 CUs at batch 100,
+// each a chain of 25 window rounds).
 __global__ __launch_bounds__(256) void conv1_pool_fwd_f32(const float* __restrict__ images, const int* __restrict__ idx,
                                                           SampleArgs smp, const float* __restrict__ w,
                                                           const float* __restrict__ bias, float* __restrict__ pooled,
@@ -50,7 +52,7 @@ __global__ __launch_bounds__(256) void conv1_pool_fwd_f32(const float* __restric
 
   f32x4 px = {0.f, 0.f, 0.f, 0.f};
   auto fetch = [&](int b) {
-    const size_t row = sample_row(smp, cur, idx, b, tid == 0 && blockIdx.y == 0);
+    const size_t row = sample_row(smp, cur, idx, b, tid == 0 && blockIdx.y == 0 && blockIdx.z == 0);
     if (tid < 196) px = reinterpret_cast<const f32x4*>(images + row * 784)[tid];
   };
   if ((int)blockIdx.x < B) fetch(blockIdx.x);
@@ -59,7 +61,7 @@ __global__ __launch_bounds__(256) void conv1_pool_fwd_f32(const float* __restric
     if (tid < 196) c1f_store_px(img, tid, px);
     __syncthreads();
     if (b + (int)gridDim.x < B) fetch(b + gridDim.x);   // next image's pixels fly during this one's stencil
-    for (int win = hw; win < 196; win += 8) {
+    for (int win = hw + 8 * (int)blockIdx.z; win < 196; win += 8 * (int)gridDim.z) {
       const int py = win / 14, pxw = win % 14;
       float p[6][6];
 #pragma unroll
@@ -179,7 +181,11 @@ static int conv1_f32_fwd_launch(const void* images, const void* idx, SampleArgs 
                                 void* pooled, void* arg, int B, int cout, int grid, hipStream_t s) {
   if (cout % 32) return -1;
   if (grid <= 0) grid = B < 2048 ? B : 2048;
-  hipLaunchKernelGGL(conv1_pool_fwd_f32, dim3(grid, cout / 32), dim3(256), 0, s, (const float*)images, (const int*)idx, smp,
+  // window split: fill ~256 CUs when the batch alone does not
+  const int per_img = cout / 32;
+  int ns = 256 / (grid * per_img > 0 ? grid * per_img : 1);
+  ns = ns < 1 ? 1 : (ns > 4 ? 4 : ns);
+  hipLaunchKernelGGL(conv1_pool_fwd_f32, dim3(grid, cout / 32, ns), dim3(256), 0, s, (const float*)images, (const int*)idx, smp,
                      (const float*)w, (const float*)bias, (float*)pooled, (uint8_t*)arg, B, cout);
   return (int)hipGetLastError();
 }
