@@ -112,8 +112,9 @@ torch.cuda.synchronize()
 if DTYPE == "bf16":        # after the gather the compute copy is exactly the rounded master everywhere
     assert torch.equal(eng.shadow[0:dp.n_dense], eng.params[0:dp.n_dense].to(torch.bfloat16)), "shadow != bf16(master)"
 
+p2p_status = None if tail_p2p is None else (tail_p2p.status(), dense_p2p.status())   # nonzero: a peer wait timed out
 for mine, ref in losses:                  # this rank saw the batches its replayed twin saw
-    assert abs(mine - ref) <= LOSS_TOL * max(1.0, abs(ref)), losses
+    assert abs(mine - ref) <= LOSS_TOL * max(1.0, abs(ref)), (losses, "p2p status (tail, dense)", p2p_status)
 assert losses[-1][0] < losses[0][0], losses
 err = (eng.params - refs[rank].params).abs().max().item()
 assert err <= TOL, f"data-parallel parameters differ from the replayed {WORLD}-rank step by {err}"
