@@ -98,6 +98,9 @@ for _ in range(STEPS):
             msg.append(f"m dense {(eng.adam_m[:nd] - r.adam_m[:nd]).abs().max().item():.3g} "
                        f"tail {(eng.adam_m[nd:] - r.adam_m[nd:]).abs().max().item():.3g}")
         print(f"DIAG rank {rank} " + " | ".join(msg), flush=True)
+        if os.environ.get("DPW2_DIAG_DIR"):   # the test harness only keeps the tail of a rank's output
+            with open(os.path.join(os.environ["DPW2_DIAG_DIR"], f"dpw2_{optimizer}_{tail}_{WORLD}_{DTYPE}_r{rank}.txt"), "a") as f:
+                f.write(" | ".join(msg) + "\n")
 dp.flush()
 if dp.shard and DTYPE == "bf16":
     # the other ranks' shards of the fp32 master are stale until the (collective) gather; the compute copy is not
