@@ -49,8 +49,11 @@ tail_p2p = dense_p2p = None
 if tail.startswith("p2p"):     # both messages through the peer-to-peer kernels instead of the process group
     from distributed_tensorflow_amd.parallel.p2p import P2PAllReduce
     n_dense = eng.layout.segment("wd1", "wd1")[1]
-    tail_p2p = P2PAllReduce(eng.layout.total - n_dense, eng.device)
-    dense_p2p = P2PAllReduce(n_dense, eng.device, two_shot=True)
+    # (generous wait bound: WORLD processes share ONE GPU here, and while three of them spin in an exchange kernel the
+    #  fourth one's kernel may not be scheduled for seconds -- with the default 2 s a wait of rank 3 expired about one
+    #  run in four, the step went on with partial sums (status 1 on that rank only) and every rank diverged)
+    tail_p2p = P2PAllReduce(eng.layout.total - n_dense, eng.device, timeout_s=60.0)
+    dense_p2p = P2PAllReduce(n_dense, eng.device, two_shot=True, timeout_s=60.0)
 # "pg": both messages as all-reduces of the process group; "pg-sharded": the dense one as reduce-scatter -> update of
 # this rank's 1/WORLD of wd1 -> all-gather of the compute copy
 dp = SyncDataParallel(eng, tail_group=dist.new_group(), tail_p2p=tail_p2p, dense_p2p=dense_p2p,
@@ -116,6 +119,10 @@ if DTYPE == "bf16":        # after the gather the compute copy is exactly the ro
     assert torch.equal(eng.shadow[0:dp.n_dense], eng.params[0:dp.n_dense].to(torch.bfloat16)), "shadow != bf16(master)"
 
 p2p_status = None if tail_p2p is None else (tail_p2p.status(), dense_p2p.status())   # nonzero: a peer wait timed out
+if p2p_status is not None:                # on ANY rank: a timed-out wait there spoils everybody's sums from the next step on
+    every = [None] * WORLD
+    dist.all_gather_object(every, p2p_status)
+    assert all(st == (0, 0) for st in every), f"a peer-to-peer wait timed out: (tail, dense) status per rank {every}"
 for mine, ref in losses:                  # this rank saw the batches its replayed twin saw
     assert abs(mine - ref) <= LOSS_TOL * max(1.0, abs(ref)), (losses, "p2p status (tail, dense)", p2p_status)
 assert losses[-1][0] < losses[0][0], losses

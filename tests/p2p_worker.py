@@ -16,7 +16,9 @@ dev = torch.device("cuda", 0)
 comm.init_process_group("gloo", rank, world, "127.0.0.1", port, timeout_s=90)
 two = mode == "twoshot"
 N = 3136 * 1024 if two else 63372          # the dense and the tail message of the deep-MNIST step
-p2p = P2PAllReduce(N, dev, two_shot=two)
+# (generous wait bound: the ranks share ONE GPU, and a spinning exchange kernel can keep a peer's kernel off it for
+#  seconds -- see tests/dp_world2_worker.py)
+p2p = P2PAllReduce(N, dev, two_shot=two, timeout_s=60.0)
 assert p2p.self_check(N, iters=6), "self check against the process group's all-reduce failed"
 
 # back-to-back launches without host synchronisation: exact integer sums, both parities, slot reuse

@@ -230,15 +230,7 @@ def test_async_parameter_server_hip_backend_over_gloo(gpu_lib, tmp_path, impl):
     ("sgd", "p2p-plain", 2, "bf16"),
     # dense message as reduce-scatter -> sharded update -> all-gather of the compute copy (sync_dp.py shard_dense)
     ("sgd", "pg-sharded", 2, "bf16"), ("adam", "pg-sharded", 2, "bf16"), ("sgd", "pg-sharded", 4, "bf16"),
-    ("sgd", "pg-sharded", 2, "fp32"),
-    # KNOWN INTERMITTENT FAILURE (found at the end of round 2, not understood yet): four ranks sharing the one GPU, both
-    # messages through the peer-to-peer kernels.  About one run in four INSIDE this file's suite the data-parallel losses
-    # leave the replay's at step 2 or 3 by 1e-3 .. 1e-1 (different on every rank: somebody summed partial data) with
-    # both status words 0 (no timed-out wait); 0 failures in 8 runs of the case alone and 0 in 4 suite runs with a
-    # device synchronisation after every step (DPW2_DIAG=1).  The two-rank peer-to-peer cases have never failed.
-    # docs/ROUND2.md "Still open" has the evidence; non-strict xfail keeps the report honest without hiding a pass.
-    pytest.param("sgd", "p2p", 4, "bf16", marks=pytest.mark.xfail(strict=False, reason="intermittent: 4 ranks on one GPU, "
-                 "peer-to-peer kernels, partial sums about 1 run in 4 inside the suite (see the comment above)")),
+    ("sgd", "pg-sharded", 2, "fp32"), ("sgd", "p2p", 4, "bf16"),
     # the fc1 weight gradient produced, summed and consumed in bf16 (grad_comm="bf16"); the replay rounds the same way
     ("sgd", "pg-g16", 2, "bf16"), ("adam", "pg-sharded-g16", 2, "bf16")])
 # (Adam is compared at world 2 only, where the sums are exact: with three or more addends the rounding of a near-zero
