@@ -127,7 +127,9 @@ def main():
             """-> (P2PAllReduce or None, why not)"""
             try:
                 from distributed_tensorflow_amd.parallel.p2p import P2PAllReduce
-                cand = P2PAllReduce(n, dev, timeout_s=2.0, two_shot=two_shot)   # bounded waits: a dead path costs seconds
+                # bounded waits: a dead path costs seconds.  (A rehearsal's ranks share ONE GPU, where a spinning
+                # exchange kernel can keep a peer's kernel off the device for many seconds: a longer bound there.)
+                cand = P2PAllReduce(n, dev, timeout_s=30.0 if args.rehearse_one_gpu else 2.0, two_shot=two_shot)
                 if n % cand.quantum:
                     cand.close()
                     return None, "rccl (length not a multiple of 4 x world)"
