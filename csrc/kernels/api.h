@@ -84,10 +84,41 @@ int dtf_fused_reduce_adam(int count, const void** part, const int* G, const int*
                           long dense_lo, long dense_hi, void* wc2T, long wc2_off, int c1, int c2, void* out_wT,
                           long out_w_off, int H, void* state, int adam_slot, long cursor_inc, long step_inc,
                           long drop_inc, hipStream_t s);
-int dtf_p2p_tail_update(int adam, void* w, void* g, void* m, void* v, void* shadow, const void* hyper, void* wc2T,
-                        long wc2_off, int c1, int c2, void* out_wT, long out_w_off, int H, void* state, int adam_slot,
-                        long cursor_inc, long step_inc, long drop_inc, void* const* bases, int world, int rank, long n,
-                        long n_max, unsigned seq, int* status, double timeout_s, long tail_off, hipStream_t s);
+// ---- data-parallel exchange fabric (dp.hip): peer-to-peer reduce-scatter / sharded update / all-gather of the dense
+// gradient and the one-shot exchange + commit of the tail, with every per-step counter in device memory ----
+// Mirrored by ctypes in distributed_tensorflow_amd/parallel/dp_fabric.py.
+struct DtfDpFabric {
+  void* base[8];               // every rank's uncached exchange buffer as mapped into THIS process (base[rank]: own)
+  int world, rank;
+  int dense_blocks;            // workgroups of the dense exchange kernel (<= 256, the same on every rank)
+  int commit_blocks;           // workgroups of the tail kernel that commit the dense shard (<= 256)
+  long n_tail, n_tail_max;     // floats, multiples of 4
+  long n_dense, csz;           // floats: the dense range (wd1) and this job's shard size n_dense / world
+  int ag_bytes;                // what the all-gather carries: 2 = bf16 compute copy, 4 = fp32 weights (fp32 engine)
+  int reserved;
+  // byte offsets of the areas inside every rank's buffer (dtf_dp_fabric_layout fills them)
+  long off_tail_stage, off_tail_flags, off_tail_done, off_dense_a, off_dense_b, off_flag_a, off_flag_b, off_done_a,
+      off_done_b;
+  // local, ordinary device memory of this rank
+  unsigned* seq_tail;          // [64 + commit_blocks] per-workgroup sequence numbers of the tail kernel
+  unsigned* seq_dense;         // [dense_blocks] the same for the dense kernel
+  int* ctl;                    // [0] poison (sticky) [1] why: 1 a wait timed out, 2 a peer was poisoned
+                               // [2] sequence number of the last dense exchange that completed here
+                               // [3] test hook: the step with this sequence number raises no flags
+  float* gsum;                 // [csz] the summed gradient of this rank's shard (dense kernel -> commit)
+  long long timeout_ticks;     // bound of every wait, in 100 MHz wall-clock ticks
+};
+long dtf_dp_fabric_layout(DtfDpFabric* f);   // fills the offsets; returns the bytes every rank allocates
+// dense exchange of one step on `s` (a branch next to the conv backward); adam_t = &state[slot] or NULL for SGD
+int dtf_dp_dense_exchange(const DtfDpFabric* f, int adam, const void* grads_dense, const void* w_dense,
+                          const void* m_dense, const void* v_dense, void* shadow_dense, const void* hyper,
+                          const void* adam_t, hipStream_t s);
+// tail exchange + launch-wide verdict + commit (tail update, step state, and -- with_dense -- this rank's shard of the
+// dense master weights / moments from f->gsum, plus the foreign fp32 shards when ag_bytes == 4)
+int dtf_dp_tail_commit(const DtfDpFabric* f, int adam, int with_dense, void* w, void* g, void* m, void* v, void* shadow,
+                       const void* hyper, void* wc2T, long wc2_off, int c1, int c2, void* out_wT, long out_w_off, int H,
+                       void* state, int adam_slot, int adam_slot2, long cursor_inc, long step_inc, long drop_inc,
+                       long tail_off, long dense_off, hipStream_t s);
 int dtf_sample_indices(const void* state, void* idx, int B, unsigned n, unsigned hb, unsigned seed, int shuffle,
                        hipStream_t s);
 

@@ -12,45 +12,9 @@
 // reduce_segments sums the deterministic split-K slabs the wgrad kernels write
 // (no float atomics anywhere in backward -> bitwise reproducible gradients).
 #include "common.hpp"
+#include "optim_core.hpp"
 
 namespace dtf {
-
-// hyper[0]=lr [1]=beta1 [2]=beta2 [3]=eps [4]=grad_scale (e.g. 1/world) [5]=weight_decay
-// state[0]=sample cursor  [1]=global_step  [2]=dropout offset  [3..]=adam t counters (one per
-// independently updated arena range, so range updates on different streams never share a word)
-struct StepAdvance {
-  int64_t* state;       // nullptr -> no advance
-  int64_t cursor_inc;
-  int64_t step_inc;
-  int64_t drop_inc;
-  int adam_slot;        // >= 3 -> state[adam_slot] += 1
-};
-
-__device__ __forceinline__ void advance_state(const StepAdvance& a) {
-  if (a.state && blockIdx.x == 0 && threadIdx.x == 0) {
-    // Only the counters this launch actually advances are touched: "+= 0" is still a read-modify-write, and the
-    // data-parallel Adam step runs two of these on different streams at once (the dense range's counter bump on the
-    // comm stream, the tail kernel's cursor / step advance on the compute stream) -- an untouched "+= 0" there wrote
-    // the OLD cursor / global step / dropout offset back over the other stream's increment (seen as a step that
-    // trained on the previous batch again, 2 runs in 8 of the two-rank Adam replay test).
-    if (a.cursor_inc) a.state[0] += a.cursor_inc;
-    if (a.step_inc) a.state[1] += a.step_inc;
-    if (a.drop_inc) a.state[2] += a.drop_inc;
-    if (a.adam_slot >= 3) a.state[a.adam_slot] += 1;
-  }
-}
-
-__device__ __forceinline__ void store_bf16x4(bf16* p, float a, float b, float c, float d) {
-  bf16x4 v = {(bf16)a, (bf16)b, (bf16)c, (bf16)d};
-  *reinterpret_cast<bf16x4*>(p) = v;
-}
-
-// four consecutive gradient values: fp32, or bf16 (the 16-bit dense collective of parallel/sync_dp.py)
-__device__ __forceinline__ f32x4 load_grad4(const float* g, long i) { return reinterpret_cast<const f32x4*>(g)[i]; }
-__device__ __forceinline__ f32x4 load_grad4(const bf16* g, long i) {
-  const bf16x4 v = reinterpret_cast<const bf16x4*>(g)[i];
-  return (f32x4){(float)v[0], (float)v[1], (float)v[2], (float)v[3]};
-}
 
 // n must be a multiple of 4 (arena tensors are padded to 4 floats)
 template <typename GT>
@@ -176,114 +140,6 @@ __global__ __launch_bounds__(256) void reduce_segments(ReduceSegs segs) {
 // reduced gradient (so the gradient arena stays inspectable) and apply the update to exactly those
 // elements.  The remaining blocks stream the dense range whose gradient is already final (wd1).
 // ---------------------------------------------------------------------------------------------
-struct FusedSeg {
-  const float* part;  // [G][stride]
-  int G, n;
-  long stride;
-  long arena_off;     // float offset of the segment in the parameter / gradient arenas
-};
-struct FusedSgdArgs {
-  FusedSeg s[3];
-  int blocks_end[3];
-  int count, reduce_blocks;
-  float* w;
-  float* g;
-  bf16* shadow;
-  const float* hyper;
-  long dense_lo4, dense_hi4;   // dense range in float4 units
-  float* out_wT;               // fp32 [10][H] transpose of the output weight for head_fwd_bwd (nullptr: none)
-  long out_w_off;
-  int H;
-  bf16* wc2T;                  // [fwd pack | dgrad pack] of the wc2 shadow (nullptr: none); with shadow == nullptr
-                               // (the fp32 configuration) it points at the FP32 packs of conv2_f32.hip instead
-  long wc2_off;
-  int c1, c2;
-  StepAdvance adv;
-  // Adam variant only: moment arenas and the step counter of this update.  Every workgroup reads *adam_t, so it
-  // cannot be advanced inside this kernel: a "last workgroup to finish" counter was measured at ~35 ns per
-  // workgroup (3000 serialised same-address atomics = +100 us), so a 1-thread kernel bumps it BEFORE the launch.
-  float* m;
-  float* v;
-  const int64_t* adam_t;
-};
-
-// One-shot peer-to-peer exchange state of the data-parallel tail (p2p_tail_allreduce_update below; protocol in p2p.hip).
-constexpr int kTailFlagSlots = 1024;   // flag slots per (parity, rank): p2p.hip sizes its allocation for this
-struct TailP2P {
-  float* stage[8];      // [2][world][n_max] of every rank, as mapped here
-  unsigned* flags[8];   // [2][world][kTailFlagSlots]
-  int* status;
-  int world, rank, n_max;
-  unsigned seq;
-  long long timeout_ticks;
-  long tail_off;        // arena float offset of the first tail element (slot index = arena offset - tail_off)
-};
-
-// TF AdamOptimizer on one float4 (same arithmetic as adam_update)
-__device__ __forceinline__ void adam4(f32x4& wv, const f32x4& gv, f32x4& mv, f32x4& vv, float lr_t, float b1, float b2,
-                                      float eps, float gs) {
-#pragma unroll
-  for (int e = 0; e < 4; ++e) {
-    const float ge = gv[e] * gs;
-    mv[e] = fmaf(b1, mv[e], (1.f - b1) * ge);
-    vv[e] = fmaf(b2, vv[e], (1.f - b2) * ge * ge);
-    wv[e] -= lr_t * mv[e] / (sqrtf(vv[e]) + eps);
-  }
-}
-
-// Update of the four tail elements at arena offset e0 with the (final) gradient gs: gradient arena, optimizer,
-// master weight, bf16 shadow, and the derived copies (out_wT, the two conv2 packs).  Shared by the fused tails.
-template <bool ADAM>
-__device__ __forceinline__ void tail_update4(const FusedSgdArgs& a, long e0, f32x4 gs, f32x4 wv, float lr, float lr_t,
-                                             float b1, float b2, float eps, float gsc) {
-  *reinterpret_cast<f32x4*>(a.g + e0) = gs;
-  if (ADAM) {
-    f32x4 mv = *reinterpret_cast<const f32x4*>(a.m + e0), vv = *reinterpret_cast<const f32x4*>(a.v + e0);
-    adam4(wv, gs, mv, vv, lr_t, b1, b2, eps, gsc);
-    *reinterpret_cast<f32x4*>(a.m + e0) = mv;
-    *reinterpret_cast<f32x4*>(a.v + e0) = vv;
-  } else {
-#pragma unroll
-    for (int e = 0; e < 4; ++e) wv[e] = fmaf(-lr, gs[e], wv[e]);
-  }
-  *reinterpret_cast<f32x4*>(a.w + e0) = wv;
-  if (a.shadow) store_bf16x4(a.shadow + e0, wv[0], wv[1], wv[2], wv[3]);
-  // (32-bit index arithmetic: with `long` operands the divisions below are 64-bit software divisions, a few hundred
-  // instructions on the one wave of the workgroup that runs the update)
-  const long ro64 = e0 - a.out_w_off;
-  if (a.out_wT && ro64 >= 0 && ro64 < 10L * a.H) {
-    const unsigned ro = (unsigned)ro64;
-#pragma unroll
-    for (int e = 0; e < 4; ++e) a.out_wT[(size_t)((ro + e) % 10u) * a.H + (ro + e) / 10u] = wv[e];
-  }
-  const long r64 = e0 - a.wc2_off;
-  const long nw = 25L * a.c1 * a.c2;
-  if (a.wc2T && r64 >= 0 && r64 < nw && !a.shadow) {
-    // fp32 configuration (no bf16 shadow): wc2T holds the fp32 fragment packs of conv2_f32.hip
-    // (pack_conv2_weights_f32): [fwd pack | dgrad pack], one lane slot = four consecutive k
-    float* pk = reinterpret_cast<float*>(a.wc2T);
-    const unsigned r = (unsigned)r64, cc = (unsigned)(a.c1 * a.c2), c1 = (unsigned)a.c1, c2 = (unsigned)a.c2;
-    const unsigned tap = r / cc, rem = r - tap * cc;
-    const unsigned ci = rem / c2, co = rem - ci * c2;
-    const long f0 = (((long)tap * (c1 / 16) + ci / 16) * (c2 / 16) + co / 16) * 256 + (((ci % 16) / 4) * 16 + co % 16) * 4 + ci % 4;
-#pragma unroll
-    for (int e = 0; e < 4; ++e) pk[f0 + 4 * e] = wv[e];   // co+e -> next lane slot (co % 16 + e <= 15)
-    const long d0 = (((long)tap * (c2 / 16) + co / 16) * (c1 / 16) + ci / 16) * 256 + (((co % 16) / 4) * 16 + ci % 16) * 4;
-    *reinterpret_cast<f32x4*>(pk + nw + d0) = wv;          // co .. co+3 = the four k of one lane slot
-  } else if (a.wc2T && r64 >= 0 && r64 < nw) {
-    // HWIO element (tap, ci, co..co+3) -> the two fragment-ordered packs of conv2.hip
-    // (pack_conv2_weights): [fwd pack | dgrad pack]
-    const unsigned r = (unsigned)r64, cc = (unsigned)(a.c1 * a.c2), c1 = (unsigned)a.c1, c2 = (unsigned)a.c2;
-    const unsigned tap = r / cc, rem = r - tap * cc;
-    const unsigned ci = rem / c2, co = rem - ci * c2;
-    const long f0 = (((long)tap * (c1 / 32) + ci / 32) * (c2 / 16) + co / 16) * 512 + (((ci % 32) / 8) * 16 + co % 16) * 8 + ci % 8;
-#pragma unroll
-    for (int e = 0; e < 4; ++e) a.wc2T[f0 + 8 * e] = (bf16)wv[e];   // co+e -> next lane slot (co % 16 + e <= 15)
-    const long d0 = (((long)tap * (c2 / 32) + co / 32) * (c1 / 16) + ci / 16) * 512 + (((co % 32) / 8) * 16 + ci % 16) * 8 + co % 8;
-    store_bf16x4(a.wc2T + nw + d0, wv[0], wv[1], wv[2], wv[3]);       // 4 consecutive k of one lane slot
-  }
-}
-
 template <bool ADAM>
 __global__ __launch_bounds__(256) void fused_reduce_sgd(FusedSgdArgs a) {
   __shared__ f32x4 red[16][17];
@@ -372,67 +228,6 @@ __global__ __launch_bounds__(256) void fused_reduce_sgd(FusedSgdArgs a) {
     }
   }
   advance_state(a.adv);   // cursor / global_step / dropout offset: nothing in this kernel reads them
-}
-
-// ---------------------------------------------------------------------------------------------
-// Data-parallel tail, coarse-grained: the already slab-reduced tail of the gradient arena (reduce_segments) makes
-// the one-shot peer-to-peer round trip of p2p.hip in kTailXBlocks fat workgroups (64 system-scope fences instead of
-// one per 64 elements) and the SAME launch applies the update to what it has just summed: the separate update
-// launch of the data-parallel step (fused_reduce_sgd with G = 1) disappears.
-// ---------------------------------------------------------------------------------------------
-constexpr int kTailXBlocks = 64;
-
-template <bool ADAM>
-__global__ __launch_bounds__(256) void p2p_tail_allreduce_update(FusedSgdArgs a, TailP2P pp, int n) {
-  const int tid = threadIdx.x, b = blockIdx.x, W = pp.world;
-  const float lr = a.hyper[0] * a.hyper[4];
-  float lr_t = 0.f, b1 = 0.f, b2 = 0.f, eps = 0.f, gsc = 0.f;
-  if (ADAM) {
-    b1 = a.hyper[1]; b2 = a.hyper[2]; eps = a.hyper[3]; gsc = a.hyper[4];
-    const float t = (float)*a.adam_t;
-    lr_t = a.hyper[0] * sqrtf(1.f - powf(b2, t)) / (1.f - powf(b1, t));
-  }
-  const int par = pp.seq & 1u;
-  const int per = (n / 4 + kTailXBlocks - 1) / kTailXBlocks;
-  const int lo4 = b * per, hi4 = min(n / 4, lo4 + per);
-  const size_t slot = ((size_t)par * W + pp.rank) * pp.n_max;
-  const f32x4* src = reinterpret_cast<const f32x4*>(a.g + pp.tail_off);
-  for (int i = lo4 + tid; i < hi4; i += 256) {
-    const f32x4 v = src[i];
-#pragma unroll 1
-    for (int k = 0; k < W; ++k) reinterpret_cast<f32x4*>(pp.stage[(pp.rank + k) % W] + slot)[i] = v;
-  }
-  __shared__ int p2p_bad;
-  __threadfence_system();
-  if (tid == 0) p2p_bad = 0;
-  __syncthreads();
-  if (tid < W) {
-    __hip_atomic_store(pp.flags[tid] + ((size_t)par * W + pp.rank) * kTailFlagSlots + b, pp.seq, __ATOMIC_RELEASE,
-                       __HIP_MEMORY_SCOPE_SYSTEM);
-    const unsigned* f = pp.flags[pp.rank] + ((size_t)par * W + tid) * kTailFlagSlots + b;
-    const long long t0 = wall_clock64();
-    while (__hip_atomic_load(f, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) != pp.seq) {
-      if (wall_clock64() - t0 > pp.timeout_ticks) {
-        *pp.status = 1;
-        p2p_bad = 1;
-        break;
-      }
-      __builtin_amdgcn_s_sleep(2);
-    }
-  }
-  __syncthreads();
-  // a peer never arrived: the sum would be incomplete.  Leave parameters, moments and step state untouched (the host
-  // sees *status at its next health check and ends the run; a checkpoint taken meanwhile is clean)
-  if (p2p_bad) return;
-  const float* mine = pp.stage[pp.rank] + (size_t)par * W * pp.n_max;
-  for (int i = lo4 + tid; i < hi4; i += 256) {
-    const long e0 = pp.tail_off + 4L * i;
-    const f32x4 wv = *reinterpret_cast<const f32x4*>(a.w + e0);
-    f32x4 gs = reinterpret_cast<const f32x4*>(mine)[i];
-    for (int q = 1; q < W; ++q) gs += reinterpret_cast<const f32x4*>(mine + (size_t)q * pp.n_max)[i];
-    tail_update4<ADAM>(a, e0, gs, wv, lr, lr_t, b1, b2, eps, gsc);
-  }
-  advance_state(a.adv);
 }
 
 }  // namespace dtf
@@ -590,59 +385,6 @@ int dtf_fused_reduce_adam(int count, const void** part, const int* G, const int*
                           long drop_inc, hipStream_t s) {
   return fused_tail_launch(true, m, v, adam_slot, count, part, G, n, stride, seg_off, w, g, shadow, hyper, dense_lo,
                            dense_hi, wc2T, wc2_off, c1, c2, out_wT, out_w_off, H, state, cursor_inc, step_inc, drop_inc, s);
-}
-
-// Data-parallel tail, coarse-grained (p2p_tail_allreduce_update): g[tail_off, tail_off + n) holds this rank's reduced
-// tail gradient; after the launch it holds the sum over ranks and the update has been applied to those elements.
-int dtf_p2p_tail_update(int adam, void* w, void* g, void* m, void* v, void* shadow, const void* hyper, void* wc2T,
-                        long wc2_off, int c1, int c2, void* out_wT, long out_w_off, int H, void* state, int adam_slot,
-                        long cursor_inc, long step_inc, long drop_inc, void* const* bases, int world, int rank, long n,
-                        long n_max, unsigned seq, int* status, double timeout_s, long tail_off, hipStream_t s) {
-  if (world < 1 || world > 8 || rank < 0 || rank >= world || (n & 3) || (n_max & 3) || n > n_max || seq == 0 ||
-      (tail_off & 3) || (wc2_off & 3))
-    return -2;
-  if (adam && (!m || !v || !state || adam_slot < 3 || adam_slot > 6)) return -3;
-  if (wc2T && ((c1 % 32) || (c2 % 32))) return -3;
-  FusedSgdArgs a;
-  for (int k = 0; k < 3; ++k) {
-    a.s[k] = FusedSeg{nullptr, 0, 0, 0, 0};
-    a.blocks_end[k] = 0;
-  }
-  a.count = 0;
-  a.reduce_blocks = 0;
-  a.w = (float*)w;
-  a.g = (float*)g;
-  a.shadow = (bf16*)shadow;
-  a.hyper = (const float*)hyper;
-  a.dense_lo4 = a.dense_hi4 = 0;
-  a.out_wT = (float*)out_wT;
-  a.out_w_off = out_w_off;
-  a.H = H;
-  a.wc2T = (bf16*)wc2T;
-  a.wc2_off = wc2_off;
-  a.c1 = c1;
-  a.c2 = c2;
-  a.adv = StepAdvance{(int64_t*)state, cursor_inc, step_inc, drop_inc, -1};
-  a.m = (float*)m;
-  a.v = (float*)v;
-  a.adam_t = adam ? (const int64_t*)state + adam_slot : nullptr;
-  TailP2P pp;
-  for (int r = 0; r < 8; ++r) {
-    char* base = static_cast<char*>(bases[r < world ? r : rank]);
-    pp.stage[r] = reinterpret_cast<float*>(base);
-    pp.flags[r] = reinterpret_cast<unsigned*>(base + 2L * world * n_max * 4);
-  }
-  pp.status = status;
-  pp.world = world;
-  pp.rank = rank;
-  pp.n_max = (int)n_max;
-  pp.seq = seq;
-  pp.timeout_ticks = (long long)(timeout_s * 1e8);
-  pp.tail_off = tail_off;
-  if (adam) hipLaunchKernelGGL(advance_state_kernel, dim3(1), dim3(1), 0, s, StepAdvance{(int64_t*)state, 0, 0, 0, adam_slot});
-  if (adam) hipLaunchKernelGGL(p2p_tail_allreduce_update<true>, dim3(kTailXBlocks), dim3(256), 0, s, a, pp, (int)n);
-  else hipLaunchKernelGGL(p2p_tail_allreduce_update<false>, dim3(kTailXBlocks), dim3(256), 0, s, a, pp, (int)n);
-  return (int)hipGetLastError();
 }
 
 }  // extern "C"

@@ -485,18 +485,52 @@ int dtf_engine_dp_phase3(const DtfEngineDesc* e, long dense_hi, int tail_adam_sl
   return 0;
 }
 
-// phase 3 with the tail all-reduce and the tail update in ONE launch on the compute stream (optim.hip
-// p2p_tail_allreduce_update): the reduced tail (phase 2 with reduce_tail == 1) goes through 64 fat workgroups that
-// exchange it peer to peer and apply the update to what they have just summed
-int dtf_engine_dp_phase3_p2p(const DtfEngineDesc* e, int tail_adam_slot, long step_inc, int wait_dense, hipStream_t s,
-                             void* const* bases, int world, int rank, long n_max, unsigned seq, int* status,
-                             double timeout_s) {
-  DTF_TRY(dtf_p2p_tail_update(e->optimizer != 0, e->params, e->grads, e->adam_m, e->adam_v, shadow_of(e), e->hyper, e->wc2T,
-                              e->off_wc2, e->c1, e->c2, e->out_wT, e->off_out_w, e->hidden, e->state, tail_adam_slot,
-                              e->B, step_inc, 1, bases, world, rank, e->n_total - e->off_out_w, n_max, seq, status,
-                              timeout_s, e->off_out_w, s));
-  if (wait_dense) HIP_TRY(hipStreamWaitEvent(s, e->ev_dense_updated, 0));
-  return 0;
+// ---------------------------------------------------------------------------------------------
+// The whole data-parallel step through the exchange fabric (csrc/kernels/dp.hip): both messages as peer-to-peer
+// stores, every per-step counter in device memory.  Enqueue-only and free of per-step arguments, so Python captures it
+// ONCE into a HIP graph and a step costs the host one graph launch (parallel/sync_dp.py).
+//   s:     conv fwd, fc1 fwd, head, fc1 dgrad (+ head wgrad), fc1 wgrad -> gradient arena
+//   comm:    dense exchange (reduce-scatter -> shard sum -> optimizer arithmetic -> all-gather of the compute copy)
+//   s:     conv2 wgrad, conv2 dgrad + conv1 wgrad, slab reduce (+ control flags)        | comm joins here
+//   s:     tail exchange + verdict + commit: tail update, step state, this rank's shard of the dense master
+// collapse_world1: a one-rank job has nobody to exchange the dense gradient with, and SGD then applies it in the
+// epilogue of the wgrad GEMM exactly as the single-GPU step does (bitwise the same kernel); the tail still goes through
+// the exchange kernel (slot of its own, flags, verdict), which is what a one-GPU box can measure of the protocol.
+// ---------------------------------------------------------------------------------------------
+int dtf_engine_dp_step(const DtfEngineDesc* e, const DtfDpFabric* f, int collapse_world1, long step_inc, hipStream_t s,
+                       hipStream_t comm) {
+  if (!f || f->n_dense != (long)e->flat * e->hidden || f->n_tail != e->n_total - e->off_out_w || e->off_wd1 != 0 ||
+      f->ag_bytes != (is_f32(e) ? 4 : 2) || e->dense_g16)
+    return -3;
+  const int adam = e->optimizer != 0;
+  DTF_TRY(forward_conv_impl(e, e->ds_images, nullptr, 1, e->B, s));
+  DTF_TRY(dtf_engine_forward_dense(e, e->ds_labels, e->idx, 1, e->B, 1, s));
+  DTF_TRY(fc1_dgrad(e, 1, s));              // the last reader of the old fc1 weights; + the head wgrad workgroups
+  const bool collapsed = f->world == 1 && collapse_world1 && !adam;
+  if (collapsed) {
+    if (is_f32(e))
+      DTF_TRY(dtf_gemm_f32_tn(e->p2, e->da, f32at(e->params, e->off_wd1), e->flat, e->hidden, e->B, e->flat, e->hidden,
+                              e->hidden, e->hyper, s));
+    else
+      DTF_TRY(dtf_gemm_tn_sgd(e->p2, e->da, f32at(e->params, e->off_wd1), bf16at(e->shadow, e->off_wd1), e->hyper, e->flat,
+                              e->hidden, e->B, e->flat, e->hidden, e->hidden, s));
+  } else {
+    DTF_TRY(backward_dense_impl(e, -1, s));
+    if (comm != s) {
+      HIP_TRY(hipEventRecord(e->ev_dense_ready, s));
+      HIP_TRY(hipStreamWaitEvent(comm, e->ev_dense_ready, 0));
+    }
+    DTF_TRY(dtf_dp_dense_exchange(f, adam, f32at(e->grads, e->off_wd1), f32at(e->params, e->off_wd1),
+                                  adam ? f32at(e->adam_m, e->off_wd1) : nullptr, adam ? f32at(e->adam_v, e->off_wd1) : nullptr,
+                                  is_f32(e) ? nullptr : (void*)bf16at(e->shadow, e->off_wd1), e->hyper,
+                                  adam ? (const void*)((const int64_t*)e->state + 3) : nullptr, comm));
+    if (comm != s) HIP_TRY(hipEventRecord(e->ev_dense_updated, comm));
+  }
+  DTF_TRY(backward_conv_impl(e, e->ds_images, e->idx, 0, 2, -1, s));
+  if (!collapsed && comm != s) HIP_TRY(hipStreamWaitEvent(s, e->ev_dense_updated, 0));
+  return dtf_dp_tail_commit(f, adam, collapsed ? 0 : 1, e->params, e->grads, e->adam_m, e->adam_v, shadow_of(e), e->hyper,
+                            e->wc2T, e->off_wc2, e->c1, e->c2, e->out_wT, e->off_out_w, e->hidden, e->state, 3, 4, e->B,
+                            step_inc, 1, e->off_out_w, e->off_wd1, s);
 }
 
 int dtf_engine_dp_record_updated(const DtfEngineDesc* e, hipStream_t comm) {

@@ -29,6 +29,38 @@ from .ops import native
 from .ops.native import check, ptr
 
 
+@dataclass(frozen=True)
+class Tuning:
+    """Every launch-geometry override the engine takes from the environment, read in ONE place (A/B switches for the
+    tools under tools/; unset = the measured defaults).  ``env_overrides()`` lists every ``DTF_*`` variable that is
+    set -- these and the ones the kernels read themselves (DTF_GEMM_DMA, DTF_IMGS1_MAX_B, DTF_F32_MSPLIT, ...) -- and
+    bench.py writes that list into its result line, so a number taken under a non-default configuration says so."""
+
+    dgrad_splits: Optional[int] = None    # DTF_DGRAD_SPLITS  fp32 fc1 dgrad: K ranges
+    head_ks: Optional[int] = None         # DTF_HEAD_KS       output-layer wgrad: batch splits
+    c2w_nt: Optional[int] = None          # DTF_C2W_NT        bf16 conv2 wgrad: co tiles per wave (2 | 4)
+    c2_g: Optional[int] = None            # DTF_C2_G          conv2 wgrad: image slabs
+    fused_c1w: bool = True                # DTF_FUSED_C1W     conv2 dgrad + conv1 wgrad as one kernel
+
+    @staticmethod
+    def from_env(env=None) -> "Tuning":
+        env = os.environ if env is None else env
+
+        def num(name):
+            v = env.get(name)
+            return int(v) if v else None
+
+        nt = env.get("DTF_C2W_NT")
+        return Tuning(dgrad_splits=num("DTF_DGRAD_SPLITS"), head_ks=num("DTF_HEAD_KS"),
+                      c2w_nt=int(nt) if nt in ("2", "4") else None, c2_g=num("DTF_C2_G"),
+                      fused_c1w=env.get("DTF_FUSED_C1W", "1") == "1")
+
+    @staticmethod
+    def env_overrides(env=None) -> Dict[str, str]:
+        env = os.environ if env is None else env
+        return {k: env[k] for k in sorted(env) if k.startswith("DTF_")}
+
+
 def _half_bits(n: int) -> int:
     hb = 1
     while (1 << (2 * hb)) < n:
@@ -95,10 +127,11 @@ class HipEngine:
                  optimizer: str = "sgd", learning_rate: float = 1e-3, keep_prob: float = 1.0,
                  seed: int = 0, device="cuda", grad_scale: float = 1.0, shuffle: bool = True,
                  adam_betas=(0.9, 0.999), adam_eps: float = 1e-8, step_inc: int = 1, multi_stream: Optional[bool] = None,
-                 fuse_dense_update: bool = False, dtype: str = "bf16"):
+                 fuse_dense_update: bool = False, dtype: str = "bf16", tuning: Optional[Tuning] = None):
         if not torch.cuda.is_available():
             raise RuntimeError("HipEngine needs a GPU (use backend='cpu' / models.oracle on CPU)")
         self.lib = native.load()
+        self.tuning = tun = Tuning.from_env() if tuning is None else tuning
         if dtype not in ("bf16", "fp32"):
             raise ValueError(f"dtype must be 'bf16' or 'fp32', got {dtype!r}")
         # "bf16": bf16 MFMA compute copies, fp32 accumulation and fp32 master weights.
@@ -163,8 +196,8 @@ class HipEngine:
         # tiles and H / 32 = 32 K steps; it is not K-bound the same way.)
         d_tiles = ((B + 127) // 128) * ((FLAT + 127) // 128)
         self.dgrad_splits = max(1, min(8, H // 128, 256 // d_tiles)) if dtype == "fp32" else 1
-        if os.environ.get("DTF_DGRAD_SPLITS"):                  # tuning override
-            self.dgrad_splits = max(1, min(int(os.environ["DTF_DGRAD_SPLITS"]), H // 32)) if dtype == "fp32" else 1
+        if tun.dgrad_splits:                                    # tuning override
+            self.dgrad_splits = max(1, min(tun.dgrad_splits, H // 32)) if dtype == "fp32" else 1
         self.dgrad_part = torch.empty((self.dgrad_splits, B, FLAT) if self.dgrad_splits > 1 else (4,), **f32)
         self.logits = torch.empty((B, spec.classes), **f32)
         self.loss_rows = torch.empty(B, **f32)
@@ -179,8 +212,8 @@ class HipEngine:
         # split-K geometry
         # output-layer wgrad: 256-column workgroups x head_ks batch splits (slabs summed by the fused tail)
         self.head_ks = max(1, min(128, max(B // 64, min(8, B // 8))))   # 64 rows per split (measured: 8..16 splits best at 1024)
-        if os.environ.get("DTF_HEAD_KS"):                       # tuning override
-            self.head_ks = max(1, min(int(os.environ["DTF_HEAD_KS"]), B))
+        if tun.head_ks:                                         # tuning override
+            self.head_ks = max(1, min(tun.head_ks, B))
         self.head_stride = H * spec.classes + 12 + H
         self.head_part = torch.empty((self.head_ks, self.head_stride), **f32)
         # conv2 wgrad split-K over images: G slabs x (C1/16 * C2/32) output tiles workgroups.  64 slabs fill the
@@ -189,22 +222,22 @@ class HipEngine:
         # many output tiles) for the widened model and, with twice the image chunks, for the 32/64 model from 4096
         # images per GPU (-2 %; a wash at 1024, where the doubled slab traffic eats the gain)
         self.c2_nt = 4 if (C1 >= 128 or B >= 4096) else 2
-        if os.environ.get("DTF_C2W_NT") in ("2", "4"):          # A/B switch for tools
-            self.c2_nt = int(os.environ["DTF_C2W_NT"])
+        if tun.c2w_nt:                                          # A/B switch for tools
+            self.c2_nt = tun.c2w_nt
         c2_tiles = (C1 // 16) * (C2 // (16 * self.c2_nt))
-        default_g = "8" if C1 >= 128 else ("64" if c2_tiles >= 4 else "128")
-        self.c2_g = max(1, min((B + 1) // 2, int(os.environ.get("DTF_C2_G", default_g))))
+        default_g = 8 if C1 >= 128 else (64 if c2_tiles >= 4 else 128)
+        self.c2_g = max(1, min((B + 1) // 2, tun.c2_g or default_g))
         if dtype == "fp32":
             # conv5x5_wgrad_f32: one workgroup per (image range, 32 ci x 64 co tile), one workgroup per CU
             f32_tiles = (C1 // 32) * (C2 // 64)
-            self.c2_g = max(1, min(B, int(os.environ.get("DTF_C2_G", str(max(1, 256 // f32_tiles))))))
+            self.c2_g = max(1, min(B, tun.c2_g or max(1, 256 // f32_tiles)))
         self.c2_stride = 25 * C1 * C2 + C2
         self.c2_part = torch.empty((self.c2_g, self.c2_stride), **f32)
         # conv1 wgrad slabs: the fused conv2-dgrad -> conv1-wgrad kernel of the 32/64 model writes one per
         # workgroup (2 images each); the stand-alone kernel takes any grid
         # Measured (bench.py A/B): +2.7 % at batch 256, neutral at 1024, -10 % at 4096+ (lower occupancy of the
         # dgrad phase, one slab per two images) -> fused up to 1024 images per GPU.  Env var: A/B switch for tools.
-        fused_c1w = (C1, C2) == (32, 64) and B <= 1024 and dtype == "bf16" and os.environ.get("DTF_FUSED_C1W", "1") == "1"
+        fused_c1w = (C1, C2) == (32, 64) and B <= 1024 and dtype == "bf16" and tun.fused_c1w
         # up to dtf_conv2_small_batch() images the fused kernels take ONE image per workgroup (twice the workgroups,
         # half the serial work of each: at batch 100 two images per workgroup are 50 workgroups on 256 CUs)
         self.c1w_imgs = 0 if not fused_c1w else (1 if 1 < B <= int(self.lib.dtf_conv2_small_batch()) else 2)

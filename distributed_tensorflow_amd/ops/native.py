@@ -172,8 +172,9 @@ _ENGINE_SIGS = {
     "dtf_engine_dp_phase1": [_EP, c_int, c_void_p, c_void_p],
     "dtf_engine_dp_phase2": [_EP, c_long, c_long, c_int, c_int, c_void_p, c_int, c_void_p, c_void_p, c_void_p],
     "dtf_engine_dp_record_updated": [_EP, c_void_p],
-    "dtf_engine_dp_phase3_p2p": [_EP, c_int, c_long, c_int, c_void_p, ctypes.POINTER(c_void_p), c_int, c_int, c_long, c_uint,
-                                 c_void_p, c_double],
+    # (the fabric descriptor -- parallel/dp_fabric.py FabricDesc -- is passed by reference as an opaque pointer)
+    "dtf_engine_dp_step": [_EP, c_void_p, c_int, c_long, c_void_p, c_void_p],
+    "dtf_dp_fabric_layout": [c_void_p],
     "dtf_engine_dp_phase3": [_EP, c_long, c_int, c_long, c_int, c_void_p, c_void_p],
     "dtf_engine_dp_flush": [_EP, c_void_p],
 }
@@ -202,7 +203,7 @@ def load() -> ctypes.CDLL:
     for name, argtypes in list(_SIGS.items()) + list(_ENGINE_SIGS.items()):
         fn = getattr(lib, name)
         fn.argtypes = argtypes
-        fn.restype = c_long if name in ("dtf_p2p_bytes", "dtf_p2p2_bytes") else c_int
+        fn.restype = c_long if name in ("dtf_p2p_bytes", "dtf_p2p2_bytes", "dtf_dp_fabric_layout") else c_int
     lib.dtf_build_flavour.restype = c_char_p
     lib.dtf_build_flavour.argtypes = []
     flavour = lib.dtf_build_flavour().decode()

@@ -20,7 +20,8 @@ def init_process_group(backend: str, rank: int, world_size: int, master_addr: Op
     """Rendezvous over a TCPStore at master_addr:master_port (env MASTER_ADDR/PORT by default)."""
     if dist.is_initialized():
         return
-    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # dmabuf IPC only on this driver
+    # (HSA_ENABLE_IPC_MODE_LEGACY=0 -- dmabuf IPC, which peer mappings need on this driver -- is set at package import,
+    # before the HIP runtime initialises: distributed_tensorflow_amd/__init__.py)
     if master_addr is not None:
         os.environ["MASTER_ADDR"] = master_addr
     if master_port is not None:

@@ -112,7 +112,8 @@ class SyncAllReduce:
     coordinated_stop = True
 
     def __init__(self, backend: Backend, task: TaskInfo, worker_group, chief_rank: int, tail_group=None,
-                 p2p: bool = False, log=None, stop_check_steps: int = 20, shard_dense=None, grad_comm: str = "fp32"):
+                 p2p: bool = False, log=None, stop_check_steps: int = 20, shard_dense=None, grad_comm: str = "fp32",
+                 hip_graph: bool = True, p2p_timeout_s: float = 60.0):
         if grad_comm not in ("fp32", "bf16"):
             raise ValueError(f"--grad_comm must be fp32 or bf16, not {grad_comm!r}")
         if grad_comm == "bf16" and (backend.name != "hip" or backend.engine.dtype != "bf16"):
@@ -121,7 +122,7 @@ class SyncAllReduce:
         self.world = task.num_workers
         self.step_count = backend.get_global_step()
         self._dp = None
-        self._p2p = []
+        self._fabric = None
         self._stop_requested = False
         self.stop = False
         # Sharded dense update (parallel/sync_dp.py): the chief's timed checkpoints need every worker to join a
@@ -137,52 +138,48 @@ class SyncAllReduce:
         if backend.name == "hip" and (dist.get_backend(worker_group) != "gloo" or p2p or shard_dense
                                       or grad_comm == "bf16"):
             from .sync_dp import SyncDataParallel
-            tail_p2p = dense_p2p = None
-            if p2p:
-                # (the 16-bit dense collective goes through the process group as well)
-                tail_p2p, dense_p2p = self._bring_up_p2p(backend.engine, worker_group, log or (lambda *a: None),
-                                                         dense=not shard_dense and grad_comm != "bf16")
-            self._dp = SyncDataParallel(backend.engine, group=worker_group, tail_group=tail_group, tail_p2p=tail_p2p,
-                                        dense_p2p=dense_p2p, shard_dense=shard_dense, grad_comm=grad_comm)
+            fabric = None
+            if p2p and grad_comm != "bf16":
+                fabric = self._bring_up_fabric(backend.engine, worker_group, log or (lambda *a: None), p2p_timeout_s)
+            self._fabric = fabric
+            self._dp = SyncDataParallel(backend.engine, group=worker_group, tail_group=tail_group, fabric=fabric,
+                                        shard_dense=shard_dense, grad_comm=grad_comm)
+            if fabric is not None and not self._dp.fabric_self_check():
+                # (collective, unanimous) peer stores or their visibility do not work on this node: process group
+                (log or print)(f"worker/{task.task_index}: exchange fabric failed its self-check; collectives go through "
+                               "the process group")
+                self._dp.use_fabric(None)
+                fabric.close()
+                fabric = self._fabric = None
+                self._dp.set_shard(self.world > 1 if shard_dense is None else bool(shard_dense))
+            if fabric is not None and hip_graph:
+                self._dp.capture()       # the whole step becomes one graph launch (collective: every worker is here)
             if grad_comm == "bf16" and log:
                 log(f"worker/{task.task_index}: fc1 weight gradient communicated in bf16 (--grad_comm=bf16)")
             if self._dp.shard and log:
                 log(f"worker/{task.task_index}: dense update sharded over {self.world} workers "
-                    f"(reduce-scatter -> update of 1/{self.world} -> all-gather of the compute copy)")
+                    f"(reduce-scatter -> update of 1/{self.world} -> all-gather of the compute copy)"
+                    + (", peer-to-peer exchange fabric" + (", one HIP graph per step" if hip_graph else "") if fabric else ""))
 
-    def _bring_up_p2p(self, eng, group, log, dense: bool = True):
-        """Both messages through csrc/kernels/p2p.hip if the kernels reproduce the process group's sums here
-        (collective decisions: every worker ends up with the same pair)."""
-        from .p2p import P2PAllReduce
+    def _bring_up_fabric(self, eng, group, log, timeout_s: float):
+        """Both messages through the exchange fabric (csrc/kernels/dp.hip) if every worker can map every peer
+        (collective and unanimous: all workers end up with the fabric or all with the process group)."""
+        from .dp_fabric import DpFabric
         n_dense = eng.layout.segment("wd1", "wd1")[1]
-        out = []
-        for name, n, two_shot in (("tail", eng.layout.total - n_dense, False), ("dense", n_dense, True)):
-            obj = None
-            if name == "dense" and not dense:      # an explicitly sharded dense update goes through the process group
-                out.append(None)
-                continue
-            try:
-                if n % (4 * self.world if two_shot else 4) == 0:
-                    # generous bound: the chief's checkpoint writes and evaluations stall its peers inside the kernel
-                    obj = P2PAllReduce(n, eng.device, group=group, timeout_s=60.0, two_shot=two_shot)
-                    if not obj.self_check(n, iters=4):
-                        obj.close()
-                        obj = None
-            except RuntimeError as e:      # unanimous (see P2PAllReduce.__init__)
-                log(f"p2p all-reduce ({name}) unavailable: {e}")
-                obj = None
-            log(f"worker/{self.task.task_index}: {name} all-reduce: {'peer-to-peer kernel' if obj else 'process group'}")
-            if obj is not None:
-                self._p2p.append(obj)
-            out.append(obj)
-        return out
+        try:
+            # generous bound: the chief's evaluations stall its peers inside the exchange kernels
+            fab = DpFabric(n_dense, eng.layout.total - n_dense, eng.device, dtype=eng.dtype, group=group, timeout_s=timeout_s)
+        except RuntimeError as e:
+            log(f"worker/{self.task.task_index}: exchange fabric unavailable ({e}); collectives go through the process group")
+            return None
+        log(f"worker/{self.task.task_index}: gradient exchange: peer-to-peer fabric")
+        return fab
 
     def check_health(self):
-        """Called where the trainer synchronises anyway (display steps, end): a timed-out peer-to-peer wait means
-        wrong sums, which must end the run rather than train on."""
-        for obj in self._p2p:
-            if obj.status():
-                raise RuntimeError("peer-to-peer all-reduce: a wait for a peer timed out (lost or stalled worker)")
+        """A timed-out peer-to-peer wait (or a peer that reports one) has stopped every update on this worker; the run
+        must end (parallel/dp_fabric.py P2PHealthError -> exit status 3 in the trainer)."""
+        if getattr(self, "_fabric", None) is not None:
+            self._fabric.health()
 
     def broadcast_initial(self):
         broadcast_state(self.b, self.chief_rank)
@@ -194,7 +191,7 @@ class SyncAllReduce:
     @property
     def sharded(self) -> bool:
         """True when checkpoints need a job-wide gather first (the dense update is sharded over the workers)."""
-        return self._dp is not None and self._dp.shard and self.b.engine.dtype != "fp32" and self.world > 1
+        return self._dp is not None and self._dp.needs_gather
 
     def request_gather(self):
         """Chief: ask every worker to join a gather of the master weights at the next control poll."""
@@ -245,8 +242,12 @@ class SyncAllReduce:
         """Every worker calls this after the same last step."""
         if self._dp is not None:
             self._dp.flush()
+            self.check_health()                # before any collective: a poisoned worker must not gather
             self._dp.gather_master()           # collective; no-op unless the dense update is sharded
-        self.check_health()
+        if self._fabric is not None:
+            dist.barrier(group=self.group)     # nobody unmaps a buffer a peer's last step may still store into
+            self._fabric.close()
+            self._fabric = None
 
 
 def broadcast_state(backend: Backend, src_rank: int, group=None):

@@ -30,6 +30,12 @@ Design for xGMI (point-to-point links, ring collectives are per-link bound):
     kernel touches 1/N of the arena.  The fp32 master weights (and Adam moments) of the other ranks' shards go stale in
     between; ``gather_master()`` (a collective: every rank calls it) brings them up to date before anything reads
     them -- checkpoints, parameter dumps, the end of training (parallel/strategies.py arranges the agreement).
+  * ``fabric`` (parallel/dp_fabric.py, csrc/kernels/dp.hip): BOTH messages as peer-to-peer stores over the xGMI mesh
+    instead of RCCL -- the dense one sharded the same way (reduce-scatter / shard update / all-gather of the compute
+    copy), the tail as a one-shot exchange whose kernel is also the step's commit point -- with every per-step counter
+    in device memory: the step is ONE native call with constant arguments, captured once into a HIP graph
+    (``capture()``), and a step then costs the host one graph launch.  Timed-out waits are all-or-nothing (a poisoned
+    rank applies nothing any more, and says so in its flags).
   * ``grad_comm="bf16"`` (opt-in, mixed-precision configuration, RCCL / process-group paths): the fc1 weight gradient
     is produced, communicated and consumed in bf16 -- half the bytes of the dominant message ((N-1)/N x (6.4 + 6.4) MB
     per rank when sharded).  The sum over ranks is then a bf16 sum (each hop rounds to 8 bits of mantissa), which is
@@ -82,14 +88,14 @@ class SyncDataParallel:
     DENSE_SLOT, TAIL_SLOT = 3, 4   # per-range Adam step counters in the device state
 
     def __init__(self, engine: HipEngine, bucket_mb: float = 64.0, group=None, tail_group=None,
-                 defer_dense_update: bool = True, tail_p2p=None, dense_p2p=None, p2p_tail_update: bool = True,
+                 defer_dense_update: bool = True, fabric=None, collapse_world1: bool = True,
                  shard_dense=None, grad_comm: str = "fp32"):
         if grad_comm not in ("fp32", "bf16"):
             raise ValueError(f"grad_comm must be fp32 or bf16, not {grad_comm!r}")
         if grad_comm == "bf16" and engine.dtype != "bf16":
             raise ValueError("grad_comm=bf16 needs the bf16 configuration (the fp32 configuration is exact end to end)")
-        if grad_comm == "bf16" and dense_p2p is not None:
-            raise ValueError("grad_comm=bf16 uses the process-group collectives; the peer-to-peer dense kernel sums fp32")
+        if grad_comm == "bf16" and fabric is not None:
+            raise ValueError("grad_comm=bf16 uses the process-group collectives; the exchange fabric sums fp32")
         self.grad_comm = grad_comm
         self.eng = engine
         self.group = group
@@ -101,29 +107,25 @@ class SyncDataParallel:
         # (5-8 us of host time each on this stack, and the step is host-bound).  What it does need is its own
         # communicator (tail_group), so that it is not ordered behind the long dense all-reduce inside RCCL.
         # Without a second communicator it has to queue on the comm stream behind the dense collective.
-        # tail_p2p (parallel/p2p.py): the tail goes through the one-shot peer-to-peer kernel instead of RCCL, also on
-        # the compute stream.
-        self.tail_p2p = tail_p2p
-        # (A variant with the exchange INSIDE the fused tail kernel -- ~1000 workgroups each doing their own peer
-        # round trip -- was removed: +22 us per step at world 1 from the per-workgroup system-scope fences, and it
-        # needs every one of those spinning workgroups co-resident next to the overlapped dense kernel, which held
-        # only by accident of the stream -> hardware-queue mapping.)
-        # p2p_tail_update (default with tail_p2p): the exchange kernel also applies the tail update to what it has just
-        # summed (csrc/kernels/optim.hip p2p_tail_allreduce_update: 64 fat workgroups, 64 fences), so the step ends
-        # {slab reduce, exchange + update} instead of {slab reduce, exchange, update}.
-        self.p2p_tail_update = bool(p2p_tail_update) and tail_p2p is not None
-        # dense_p2p: the 12.8 MB message through the two-shot peer-to-peer kernel (on the comm stream, like RCCL's)
-        self.dense_p2p = dense_p2p
-        self.tail_stream = None if (tail_group is not None or tail_p2p is not None) else self.comm_stream
+        self.tail_stream = None if tail_group is not None else self.comm_stream
+        # fabric (parallel/dp_fabric.py): both messages peer to peer, the step one graph-capturable native call.
+        # collapse_world1: a one-rank job applies the dense SGD update in the wgrad epilogue like the single-GPU step
+        # (False keeps the N > 1 kernels in the step -- what a one-GPU box can measure of their local cost).
+        self.fabric = fabric
+        self.collapse_world1 = bool(collapse_world1)
+        self._graph = None
         self.defer = defer_dense_update
         lay = engine.layout
         self.n_dense = lay.segment("wd1", "wd1")[1]     # the dense collective covers wd1 only; head + conv form the tail
+        if fabric is not None and (fabric.desc.n_dense != self.n_dense or fabric.desc.n_tail != lay.total - self.n_dense
+                                   or fabric.world != self.world):
+            raise ValueError("the exchange fabric was built for another model / group")
         be = max(1, int(bucket_mb * (1 << 20) / 4)) & ~3
         self.dense_buckets = make_buckets(0, self.n_dense, be)
         self.tail_bucket = (self.n_dense, lay.total)
         engine.set_grad_scale(1.0 / self.world)
         self._have_pending_dense = False
-        # sharded dense update (module docstring): needs equal, 32-byte aligned shards and the process group path
+        # sharded dense update (module docstring): needs equal, 32-byte aligned shards
         self.rank = dist.get_rank(group)
         # what the all-gather carries: the tensor the fc1 kernels read
         self._dense_weights = (engine.params if engine.dtype == "fp32" else engine.shadow)[0:self.n_dense]
@@ -133,10 +135,23 @@ class SyncDataParallel:
         else:
             engine.disable_dense_g16()
             self._dense_grad = engine.grads[0:self.n_dense]
-        self.master_stale = False      # True while other ranks' shards of the fp32 master / moments are out of date
+        # Sharded updates leave the OTHER ranks' shards of the fp32 master weights stale (mixed precision: the all-gather
+        # carries the bf16 copy) and -- with Adam, in either precision -- of the moments, which never travel.
+        self.weights_stale = False
+        self.moments_stale = False
         self.shard = False
         self.shard_lo, self.shard_hi = 0, self.n_dense
-        self.set_shard(self.world > 1 if shard_dense is None else bool(shard_dense))
+        self.set_shard(self.world > 1 if (shard_dense is None or fabric is not None) else bool(shard_dense))
+
+    @property
+    def master_stale(self) -> bool:
+        """True while other ranks' shards of the fp32 master weights / optimizer moments are out of date here."""
+        return self.weights_stale or self.moments_stale
+
+    @property
+    def needs_gather(self) -> bool:
+        """Checkpoints of this job need a job-wide gather_master() first."""
+        return self.shard and self.world > 1 and (self.eng.dtype != "fp32" or self.eng.optimizer == "adam")
 
     def can_shard(self) -> bool:
         return self.n_dense % (8 * self.world) == 0
@@ -145,6 +160,8 @@ class SyncDataParallel:
         """Switch the dense message between all-reduce and reduce-scatter / sharded update / all-gather.  Collective
         when it switches sharding OFF after sharded steps (the master weights are gathered first)."""
         on = bool(on) and self.can_shard()
+        if self.fabric is not None and on != (self.world > 1):
+            raise ValueError("the exchange fabric always shards the dense update over the ranks")
         if not on and self.shard:
             self.gather_master()
         self.shard = on
@@ -177,6 +194,14 @@ class SyncDataParallel:
         the two collectives on their streams, so the host cost of a step is 3 foreign calls + 2
         all-reduce enqueues (the pure-Python choreography measured 245 us/step at world 1, more than
         the 180 us of GPU work it was feeding)."""
+        if self._graph is not None:
+            self._graph.replay()
+            self._mark_stale()
+            return
+        if self.fabric is not None:
+            self._fabric_step()
+            self._mark_stale()
+            return
         eng = self.eng
         lib, d = eng.lib, eng._d()
         tr = trace if trace.enabled() else None     # roctx ranges (utils/trace.py), off by default
@@ -187,21 +212,18 @@ class SyncDataParallel:
         check(lib.dtf_engine_dp_phase1(d, int(self._have_pending_dense), cur, comm), "dp_phase1")
         if tr: tr.pop(); tr.push("allreduce dense (enqueue)")
         dense_src = None     # where the deferred dense update reads the summed gradient (None: the gradient arena)
-        if self.master_stale and not (self.shard and self.dense_p2p is None):
+        if self.master_stale and not self.shard:
             raise RuntimeError("sharded dense updates were followed by an unsharded step without gather_master(): "
                                "use set_shard(False)")
-        if self.shard and self.dense_p2p is None:
+        if self.shard:
             with torch.cuda.stream(self.comm_stream):
                 self._reduce_scatter()
-        elif self.dense_p2p is not None:
-            # the result stays in the kernel's staging buffer: no copy back into the arena (a third of its local traffic)
-            dense_src = self.dense_p2p.allreduce(eng.grads[0:self.n_dense], comm, gather=False)
         else:
             with torch.cuda.stream(self.comm_stream):
                 for lo, hi in self.dense_buckets:
                     self._allreduce(lo, hi, self.group)
         if tr: tr.pop(); tr.push("dp_phase2: conv backward")
-        shard = self.shard and self.dense_p2p is None
+        shard = self.shard
         lo, hi = (self.shard_lo, self.shard_hi) if shard else (0, self.n_dense)
         check(lib.dtf_engine_dp_phase2(d, lo, hi, self.DENSE_SLOT, 1, dense_src, int(not shard), cur, comm, tail),
               "dp_phase2")
@@ -210,20 +232,9 @@ class SyncDataParallel:
             with torch.cuda.stream(self.comm_stream):
                 self._all_gather()
             check(lib.dtf_engine_dp_record_updated(d, comm), "dp_record_updated")
-            self.master_stale = eng.dtype != "fp32" and self.world > 1
-        if self.tail_p2p is not None and self.p2p_tail_update:
-            if tr: tr.pop(); tr.push("dp_phase3: p2p all-reduce + update (one launch)")
-            p = self.tail_p2p
-            p.seq += 1
-            check(lib.dtf_engine_dp_phase3_p2p(d, self.TAIL_SLOT, eng.step_inc, int(not self.defer), cur, p._bases, p.world,
-                                               p.rank, p.n_max, p.seq, p._status.data_ptr(), p.timeout_s), "dp_phase3_p2p")
-            if tr: tr.pop()
-            self._have_pending_dense = self.defer
-            return
+            self._mark_stale()
         if tr: tr.pop(); tr.push("allreduce tail (enqueue)")
-        if self.tail_p2p is not None:
-            self.tail_p2p.allreduce(eng.grads[self.tail_bucket[0]:self.tail_bucket[1]], cur)
-        elif self.tail_stream is None:
+        if self.tail_stream is None:
             self._allreduce(*self.tail_bucket, self.tail_group)
         else:
             with torch.cuda.stream(self.tail_stream):
@@ -234,6 +245,113 @@ class SyncDataParallel:
         if tr: tr.pop()
         self._have_pending_dense = self.defer
 
+    def _mark_stale(self):
+        if self.shard and self.world > 1:
+            self.weights_stale = self.eng.dtype != "fp32"
+            self.moments_stale = self.eng.optimizer == "adam"
+
+    def use_fabric(self, fabric):
+        """Switch between the exchange fabric and the process-group path (collective when sharded masters are stale:
+        they are gathered before the fabric is dropped).  A captured graph is released."""
+        self._graph = None
+        if fabric is None:
+            if self.fabric is not None:
+                self.flush()
+                self.gather_master()
+            self.fabric = None
+            return
+        if self.grad_comm == "bf16":
+            raise ValueError("grad_comm=bf16 uses the process-group collectives; the exchange fabric sums fp32")
+        lay = self.eng.layout
+        if fabric.desc.n_dense != self.n_dense or fabric.desc.n_tail != lay.total - self.n_dense or fabric.world != self.world:
+            raise ValueError("the exchange fabric was built for another model / group")
+        self.flush()
+        self.fabric = fabric
+        self.set_shard(self.world > 1)
+
+    def fabric_self_check(self, steps: int = 2) -> bool:
+        """Collective: run real steps through the fabric (both parities) and verify on EVERY rank that
+          * nothing timed out and nobody is poisoned;
+          * the tail exchange delivered everybody's vector: a control word published as rank + 1 sums to W (W + 1) / 2;
+          * the summed gradient of this rank's dense shard agrees with the process group's all-reduce of the same data;
+          * the reduced tail is bit-identical on all ranks (rank-ordered sums).
+        True only on a unanimous vote.  Parameters, moments and step state are restored: invisible to training."""
+        eng, fab, W = self.eng, self.fabric, self.world
+        keep = [eng.params, eng.state, eng.shadow, eng.wc2T, eng.out_wT, eng.hyper]
+        if eng.optimizer == "adam":
+            keep += [eng.adam_m, eng.adam_v]
+        snap = [t.clone() for t in keep]
+        ok = True
+        ctrl = eng.layout.total - 4
+        try:
+            eng.hyper[11] = float(self.rank + 1)
+            for _ in range(max(2, steps)):
+                self._fabric_step()
+            torch.cuda.synchronize(eng.device)
+            ok = fab.poisoned() == 0
+            ok = ok and abs(float(eng.grads[ctrl + 3].item()) - W * (W + 1) / 2) < 1e-3
+            per = self.n_dense // W
+            ref = eng.grads[0:self.n_dense].clone()          # this rank's own dense gradient is still in the arena
+            _pg.all_reduce_sum(ref, group=self.group)
+            mine = ref[self.rank * per:(self.rank + 1) * per]
+            tol = 1e-5 * W * float(mine.abs().max().item() + 1e-6)
+            if W > 1 or not (self.collapse_world1 and eng.optimizer == "sgd"):
+                ok = ok and bool((fab.gsum - mine).abs().max().item() <= tol)
+            tails = [torch.empty(eng.layout.total - self.n_dense) for _ in range(W)]
+            dist.all_gather(tails, eng.grads[self.n_dense:].cpu(), group=self.group)
+            ok = ok and all(torch.equal(tails[0], t) for t in tails[1:])
+        except Exception as e:          # a failed launch on one rank is a "no" vote, not a stranded peer
+            import sys
+            print(f"[dp] fabric self-check: {type(e).__name__}: {e}", file=sys.stderr)
+            ok = False
+        for t, s0 in zip(keep, snap):
+            t.copy_(s0)
+        self.weights_stale = self.moments_stale = False     # the snapshot restored every shard
+        torch.cuda.synchronize(eng.device)
+        vote = torch.tensor([1 if ok else 0], dtype=torch.int32)
+        if dist.get_backend(self.group) != "gloo":
+            vote = vote.to(eng.device)
+        dist.all_reduce(vote, op=dist.ReduceOp.MIN, group=self.group)
+        return bool(vote.item())
+
+    def _fabric_step(self):
+        eng = self.eng
+        check(eng.lib.dtf_engine_dp_step(eng._d(), self.fabric.byref(), int(self.collapse_world1), eng.step_inc,
+                                         torch.cuda.current_stream(eng.device).cuda_stream, self.comm_stream.cuda_stream),
+              "dp_step")
+
+    def capture(self, warmup: int = 2):
+        """Capture the fabric step into ONE HIP graph (collective: every rank calls it at the same point).  The warm-up
+        launches are real steps -- lazy kernel set-up must not happen under capture, and both parities of the exchange
+        buffers get used once -- so parameters, moments and step state are snapshotted and restored: capturing is
+        invisible to training.  Afterwards train_step() is a graph launch: no per-step host work besides it."""
+        if self.fabric is None:
+            raise RuntimeError("only the exchange-fabric step has constant launch arguments (the RCCL path is issued by "
+                               "torch.distributed per step)")
+        eng = self.eng
+        keep = [eng.params, eng.state, eng.shadow, eng.wc2T, eng.out_wT]
+        if eng.optimizer == "adam":
+            keep += [eng.adam_m, eng.adam_v]
+        snap = [t.clone() for t in keep]
+        st = torch.cuda.Stream(eng.device)
+        st.wait_stream(torch.cuda.current_stream(eng.device))
+        with torch.cuda.stream(st):
+            for _ in range(max(2, warmup)):
+                self._fabric_step()
+        torch.cuda.current_stream(eng.device).wait_stream(st)
+        torch.cuda.synchronize(eng.device)
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g, stream=st):
+            self._fabric_step()
+        for t, s0 in zip(keep, snap):
+            t.copy_(s0)
+        torch.cuda.synchronize(eng.device)
+        self._graph = g
+        return g
+
+    def release_graph(self):
+        self._graph = None
+
     def gather_master(self):
         """Collective (every rank of the group): bring the fp32 master weights -- and the Adam moments -- of the dense
         range up to date on every rank after sharded updates.  No-op when nothing is stale."""
@@ -241,10 +359,10 @@ class SyncDataParallel:
             return
         self.flush()
         eng = self.eng
-        arenas = [eng.params] + ([eng.adam_m, eng.adam_v] if eng.optimizer == "adam" else [])
+        arenas = ([eng.params] if self.weights_stale else []) + ([eng.adam_m, eng.adam_v] if self.moments_stale else [])
         for a in arenas:
             _pg.all_gather_inplace(a[0:self.n_dense], self.rank, self.world, group=self.group)
-        self.master_stale = False
+        self.weights_stale = self.moments_stale = False
 
     def flush(self):
         """Make every pending update visible to the current stream (call before reading parameters)."""

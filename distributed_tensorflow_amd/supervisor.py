@@ -96,8 +96,17 @@ class Supervisor:
         finally:
             self._stop = True
             if self._writer is not None:
-                self._writer.close()          # every queued checkpoint is on disk before the session ends
-                self._writer = None
+                import sys
+                in_flight = sys.exc_info()[1]
+                try:
+                    self._writer.close()      # every queued checkpoint is on disk before the session ends
+                except Exception as e:
+                    # a failed write must be heard, but never INSTEAD of the error that is already propagating
+                    if in_flight is None:
+                        raise
+                    self.log(f"background checkpoint writer also failed while closing: {type(e).__name__}: {e}")
+                finally:
+                    self._writer = None
 
     # -- stop coordination ---------------------------------------------------
     def should_stop(self) -> bool:

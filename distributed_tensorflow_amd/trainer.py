@@ -210,7 +210,8 @@ def run(F, log=print) -> dict:
                                  stop_check_steps=F.health_check_steps,
                                  shard_dense={"auto": None, "sharded": True, "replicated": False}[
                                      getattr(F, "dense_update", "auto")],
-                                 grad_comm=getattr(F, "grad_comm", "fp32"))
+                                 grad_comm=getattr(F, "grad_comm", "fp32"), hip_graph=bool(F.hip_graph),
+                                 p2p_timeout_s=float(getattr(F, "p2p_timeout", 60.0)))
     elif async_impl == "push":
         strategy = push_obj
     elif async_impl == "p2p":
@@ -254,7 +255,7 @@ def run(F, log=print) -> dict:
         # it first) or as the collective's own error (gloo: connection reset; RCCL: watchdog timeout).
         if live is not None:
             live.announce_death(f"{type(e).__name__}: {e}")
-            lost = isinstance(e, PeerLost) or (mode == "sync" and isinstance(e, RuntimeError))
+            lost = _is_peer_loss(e, mode)
             if lost:
                 log(f"{task.job_name}/{task.task_index}: lost contact with a peer in {mode} mode ({type(e).__name__}: "
                     f"{str(e).splitlines()[0][:200]}); aborting.  Restart the job: it resumes from the last checkpoint "
@@ -276,6 +277,28 @@ def run(F, log=print) -> dict:
     metrics.close()
     log("Optimization Finished!")    # reference M:193
     return result
+
+
+def _is_peer_loss(e: BaseException, mode: str) -> bool:
+    """Only what a lost or stalled peer produces ends the job with the "lost contact" message and exit status 3:
+    the heartbeat monitor's PeerLost, the exchange fabric's health error, and the process group's own failures
+    (gloo: connection reset / closed by peer; RCCL: DistBackendError, watchdog timeouts).  Everything else -- a failed
+    checkpoint write, a launch error, a bug -- propagates with its traceback: a restart would only loop on it."""
+    from .parallel.dp_fabric import P2PHealthError
+    if isinstance(e, (PeerLost, P2PHealthError)):
+        return True
+    if mode != "sync":
+        return False
+    dist_errors = tuple(t for t in (getattr(dist, "DistBackendError", None), getattr(dist, "DistNetworkError", None),
+                                    getattr(dist, "DistError", None)) if isinstance(t, type))
+    if dist_errors and isinstance(e, dist_errors):
+        return True
+    if isinstance(e, (ConnectionError, TimeoutError)):
+        return True
+    msg = str(e)
+    return isinstance(e, RuntimeError) and any(k in msg for k in (
+        "Connection reset", "Connection closed", "closed by peer", "Socket Timeout", "Timed out waiting", "timed out",
+        "Broken pipe", "NCCL", "RCCL", "ProcessGroup", "connection refused", "Connection refused"))
 
 
 def _finish_control_plane(live, task: TaskInfo, world: int):
@@ -331,6 +354,11 @@ def _train_loop(F, task, mode, backend, strategy, sv, live, timer, metrics, resu
                     # (a strategy with updates in flight on other streams orders them first)
                     getattr(strategy, "set_learning_rate", backend.set_learning_rate)(lr)
                     cur_lr = lr
+            if getattr(F, "fault_mute_step", -1) >= 0 and local_steps == F.fault_mute_step and \
+                    (F.fault_inject_task < 0 or F.fault_inject_task == task.task_index) and \
+                    getattr(strategy, "_fabric", None) is not None:
+                log(f"worker/{task.task_index}: injected stall: the next step raises no peer-to-peer flags")
+                strategy._fabric.mute_step(strategy._fabric.next_seq())
             if tracing: trace.push(f"step {prev}")
             step = strategy.step()
             if tracing: trace.pop()

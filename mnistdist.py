@@ -62,7 +62,9 @@ flags.DEFINE_string("metrics_file", "", "append JSONL metrics here")
 flags.DEFINE_string("comm_backend", "auto", "auto (gloo for the cpu backend, RCCL for GPU tensors) | nccl | gloo "
                     "(gloo also carries GPU tensors, staged through the host: several tasks sharing ONE GPU, which RCCL refuses)")
 flags.DEFINE_boolean("p2p_allreduce", False, "sync mode, hip backend: both gradient messages through the peer-to-peer "
-                     "push kernels (one-shot tail, two-shot dense) instead of RCCL, after a self-check")
+                     "exchange fabric (csrc/kernels/dp.hip: sharded dense update, one-shot tail, the step one HIP graph) instead of RCCL")
+flags.DEFINE_float("p2p_timeout", 60.0, "bound of every in-kernel wait for a peer (seconds); a wait that runs out poisons the "
+                   "worker: no update is applied any more and the job ends with exit status 3")
 flags.DEFINE_string("lr_scaling", "none", "none (reference: fixed --learning_rate) | linear | sqrt: scale --learning_rate by "
                     "(global batch / --lr_base_batch) or its square root (utils/lr_schedule.py)")
 flags.DEFINE_integer("lr_base_batch", 128, "the batch size --learning_rate is meant for (the reference's default batch)")
@@ -76,6 +78,8 @@ flags.DEFINE_string("grad_comm", "fp32", "sync mode, hip backend, bf16 configura
 flags.DEFINE_boolean("trace", False, "roctx ranges around steps/collectives/checkpoints (rocprofv3 --marker-trace)")
 flags.DEFINE_integer("fault_inject_step", -1, "test hook: crash this worker after N local steps")
 flags.DEFINE_integer("fault_inject_task", -1, "test hook: which worker task crashes (-1 = any)")
+flags.DEFINE_integer("fault_mute_step", -1, "test hook (--p2p_allreduce): after N local steps this worker's next step raises none "
+                     "of its peer-to-peer flags -- a stalled sender; its peers' waits time out (--p2p_timeout)")
 flags.DEFINE_string("dump_params", "", "test hook: write this task's flat fp32 parameter arena to this .npy file at the end")
 flags.DEFINE_integer("request_stop_step", -1, "test hook: this worker calls Supervisor.request_stop() after N local steps")
 flags.DEFINE_integer("request_stop_task", -1, "test hook: which worker task requests the stop (-1 = any)")

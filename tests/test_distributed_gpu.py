@@ -28,9 +28,9 @@ def test_sync_1ps_2workers_hip_backend_over_gloo(gpu_lib, tmp_path, p2p):
                  logdir, backend="hip")
     _ok(out)
     w0, w1 = out[("worker", 0)][1], out[("worker", 1)][1]
-    if p2p:     # the overlapped schedule with both messages through the peer-to-peer kernels
+    if p2p:     # both messages through the peer-to-peer exchange fabric, the step one replayed HIP graph
         for o in (w0, w1):
-            assert "tail all-reduce: peer-to-peer kernel" in o and "dense all-reduce: peer-to-peer kernel" in o, o
+            assert "gradient exchange: peer-to-peer fabric" in o and "one HIP graph per step" in o, o
     for o in (w0, w1):
         assert [int(m.group(2)) for m in DISPLAY.finditer(o)] == [0, 4, 8, 12, 16, 20], o
     l0 = [float(m.group(3)) for m in DISPLAY.finditer(w0)]
@@ -51,7 +51,7 @@ def test_sync_lr_warmup_keeps_the_replicas_identical(gpu_lib, tmp_path):
                         "--lr_base_batch=16", "--lr_warmup_steps=36"] + COMMON, logdir, backend="hip",
                  per_task_extra={("worker", w): [f"--dump_params={dumps[w]}"] for w in (0, 1)})
     _ok(out)
-    assert "dense all-reduce: peer-to-peer kernel" in out[("worker", 0)][1]
+    assert "gradient exchange: peer-to-peer fabric" in out[("worker", 0)][1]
     p0, p1 = (np.load(d) for d in dumps)
     assert np.array_equal(p0, p1), "workers ended with different master weights"
 
@@ -226,11 +226,14 @@ def test_async_parameter_server_hip_backend_over_gloo(gpu_lib, tmp_path, impl):
 
 
 @pytest.mark.parametrize("optimizer,tail,world,dtype", [
-    ("sgd", "pg", 2, "bf16"), ("adam", "pg", 2, "bf16"), ("sgd", "p2p", 2, "bf16"), ("adam", "p2p", 2, "bf16"),
-    ("sgd", "p2p-plain", 2, "bf16"),
+    ("sgd", "pg", 2, "bf16"), ("adam", "pg", 2, "bf16"),
+    # both messages through the peer-to-peer exchange fabric (csrc/kernels/dp.hip), eager and as ONE replayed HIP graph
+    ("sgd", "fabric", 2, "bf16"), ("adam", "fabric", 2, "bf16"), ("sgd", "fabric-graph", 2, "bf16"),
+    ("adam", "fabric-graph", 2, "bf16"), ("sgd", "fabric-graph", 4, "bf16"), ("adam", "fabric", 4, "bf16"),
+    ("sgd", "fabric", 2, "fp32"), ("adam", "fabric-graph", 2, "fp32"), ("sgd", "fabric-graph", 4, "fp32"),
     # dense message as reduce-scatter -> sharded update -> all-gather of the compute copy (sync_dp.py shard_dense)
     ("sgd", "pg-sharded", 2, "bf16"), ("adam", "pg-sharded", 2, "bf16"), ("sgd", "pg-sharded", 4, "bf16"),
-    ("sgd", "pg-sharded", 2, "fp32"), ("sgd", "p2p", 4, "bf16"),
+    ("sgd", "pg-sharded", 2, "fp32"), ("adam", "pg-sharded", 2, "fp32"),
     # the fc1 weight gradient produced, summed and consumed in bf16 (grad_comm="bf16"); the replay rounds the same way
     ("sgd", "pg-g16", 2, "bf16"), ("adam", "pg-sharded-g16", 2, "bf16")])
 # (Adam is compared at world 2 only, where the sums are exact: with three or more addends the rounding of a near-zero
@@ -264,13 +267,43 @@ def test_overlapped_dp_schedule_world2_over_gloo(gpu_lib, optimizer, tail, world
                          for r, (rc, o) in enumerate(outs))
 
 
+@pytest.mark.parametrize("optimizer,mode,world,dtype", [("sgd", "eager", 2, "bf16"), ("adam", "graph", 2, "bf16"),
+                                                        ("sgd", "graph", 4, "bf16"), ("adam", "eager", 2, "fp32")])
+def test_fabric_stalled_peer_is_all_or_nothing(gpu_lib, optimizer, mode, world, dtype):
+    """One rank's step raises none of its peer-to-peer flags (tests/dp_fault_worker.py): the waits of its peers time
+    out, the launch-wide verdicts turn bad, every rank ends poisoned within that step, and no rank's parameters,
+    moments or step state differ from the snapshot taken before the fault -- not by a single workgroup's slice."""
+    import socket
+    import subprocess
+    import sys
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    worker = os.path.join(os.path.dirname(os.path.abspath(__file__)), "dp_fault_worker.py")
+    procs = [subprocess.Popen([sys.executable, "-u", worker, str(r), str(port), optimizer, mode, str(world), dtype],
+                              stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True) for r in range(world)]
+    outs = []
+    for p in procs:
+        try:
+            o, _ = p.communicate(timeout=150)
+        except subprocess.TimeoutExpired:
+            for q in procs:
+                q.kill()
+            raise AssertionError("timed out:\n" + p.communicate()[0][-3000:])
+        outs.append((p.returncode, o))
+    ok = all(rc == 0 and f"DPFAULT rank {r} ok" in o for r, (rc, o) in enumerate(outs))
+    assert ok, "\n".join(f"--- rank {r} (rc {rc}) ---\n" + "\n".join(l for l in o.splitlines() if "Gloo" not in l)[-1500:]
+                         for r, (rc, o) in enumerate(outs))
+
+
 def _bench(args, launcher=(), env=None):
     import json
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     r = subprocess.run([sys.executable, *launcher, os.path.join(root, "bench.py"), *args], capture_output=True,
-                       text=True, cwd=root, timeout=150, env=dict(os.environ, **(env or {})))
+                       text=True, cwd=root, timeout=240, env=dict(os.environ, **(env or {})))
     assert r.returncode == 0, (r.stdout + r.stderr)[-3000:]
     lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
     assert len(lines) == 1, r.stdout          # the contract: ONE JSON line, from rank 0
@@ -281,13 +314,31 @@ CONTRACT = ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step
             "vs_baseline", "dtype", "data", "config")
 
 
+# Committed single-GPU numbers at 1024 images (profiles/r3_*): the contract test holds the benchmark
+# inside +-15 % of them for BOTH precisions, so a regression -- or a silent fallback path -- fails the suite.
+COMMITTED_MS = {"bf16": 0.1434, "fp32": 0.7607}
+
+
 def test_bench_contract_single_gpu(gpu_lib):
     d = _bench(["--steps", "30", "--warmup", "5"])
     assert all(k in d for k in CONTRACT)
     assert d["n_gpus"] == 1 and d["steps"] == 30 and d["warmup"] == 5 and d["dtype"] == "bf16"
     assert d["config"]["global_batch"] == 1024 and d["config"]["parallelism"] == "dp1"
     assert abs(d["value"] - 1024 * 30 / (d["ms_per_step"] * 30 / 1e3)) / d["value"] < 1e-3
-    assert d["value"] > 1e6                   # two orders of magnitude below that means a fallback path ran
+    # the line describes itself: library, flavour, every DTF_* override (none in this process)
+    assert d["config"]["build_flavour"] == "release" and d["config"]["kernels_lib"].endswith("libdtf_kernels.so")
+    assert d["config"]["env_overrides"] == {k: v for k, v in os.environ.items() if k.startswith("DTF_")}
+    # the reference's precision rides in the same line, timed with the same --warmup / --steps
+    f = d["fp32"]
+    assert set(("value", "ms_per_step", "model_tflops", "final_loss")) <= set(f), f
+    assert abs(f["value"] - 1024 / (f["ms_per_step"] / 1e3)) / f["value"] < 1e-3
+    for dtype, ms in (("bf16", d["ms_per_step"]), ("fp32", f["ms_per_step"])):
+        assert abs(ms / COMMITTED_MS[dtype] - 1.0) <= 0.15, (dtype, ms, COMMITTED_MS[dtype])
+
+
+def test_bench_records_environment_overrides(gpu_lib):
+    d = _bench(["--steps", "10", "--warmup", "2", "--no_fp32"], env={"DTF_HEAD_KS": "8"})
+    assert d["config"]["env_overrides"].get("DTF_HEAD_KS") == "8" and "fp32" not in d
 
 
 @pytest.mark.parametrize("fake_timeout", [False, True])
@@ -300,21 +351,23 @@ def test_bench_torchrun_launch_rehearsal_world2(gpu_lib, fake_timeout):
     s.bind(("127.0.0.1", 0))
     port = s.getsockname()[1]
     s.close()
-    d = _bench(["--gpus", "2", "--steps", "10", "--warmup", "3", "--rehearse_one_gpu"],
+    d = _bench(["--gpus", "2", "--steps", "10", "--warmup", "3", "--rehearse_one_gpu"] + (["--no_fp32"] if fake_timeout else []),
                launcher=("-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
                          "127.0.0.1", "--master-port", str(port)),
                env={"DTF_BENCH_FAKE_P2P_TIMEOUT": "1"} if fake_timeout else None)
     assert all(k in d for k in CONTRACT)
-    if fake_timeout:     # one rank reports a timed-out peer-to-peer wait after the warm-up: everybody back to the process group
-        assert d["config"]["tail_allreduce"] == d["config"]["dense_allreduce"] == "rccl (p2p wait timed out during warm-up)"
+    cfg = d["config"]
+    if fake_timeout:     # one rank turns up poisoned after the self-check: everybody back to the process group
+        assert cfg["gradient_exchange"].startswith("rccl (") and cfg["dense"] == "rccl all-reduce" and not cfg["graph"], cfg
+        assert cfg["step_ms_by_path"]["p2p fabric"] is None
     else:
-        assert d["config"]["tail_allreduce"].startswith("p2p one-shot") and d["config"]["dense_allreduce"].startswith("p2p two-shot")
-    assert d["n_gpus"] == 2 and d["config"]["global_batch"] == 2048 and d["scaling"] == "weak"
-    assert d["config"]["parallelism"].startswith("dp2")
-    diag = d["comm_diag"]
-    assert "error" not in diag, diag
-    assert diag["dense_allreduce_bytes"] == 4 * 3136 * 1024 and diag["dense_allreduce_us"] > 0
-    assert diag["step_ms_no_allreduce"] < d["ms_per_step"]
+        # (ranks that time-slice ONE GPU and talk over gloo: the fabric wins by a wide margin here)
+        assert cfg["gradient_exchange"].startswith("p2p fabric") and cfg["graph"], cfg
+        assert cfg["step_ms_by_path"]["p2p fabric"] > 0
+    assert d["n_gpus"] == 2 and cfg["global_batch"] == 2048 and d["scaling"] == "weak"
+    assert cfg["parallelism"].startswith("dp2")
+    if not fake_timeout:
+        assert d["fp32"]["value"] > 0 and d["fp32"]["gradient_exchange"]
 
 
 @pytest.mark.parametrize("world,mode", [(2, "oneshot"), (4, "oneshot"), (2, "twoshot"), (4, "twoshot")])
