@@ -400,6 +400,8 @@ def main():
         global_batch = B * world
         info = head["info"]
         par = f"dp{world}" + ("(forced dp step)" if args.force_dp and world == 1 else "") + \
+            (f"(TIMING ONLY: dense shard of a {os.environ['DTF_DP_FAKE_WORLD']}-rank job, results invalid)"
+             if os.environ.get("DTF_DP_FAKE_WORLD") and world == 1 and args.force_dp else "") + \
             ("(rehearsal: gloo, one GPU)" if args.rehearse_one_gpu else "")
         config = {"model": spec.name, "global_batch": global_batch, "per_gpu_batch": B, "seq_len": None, "parallelism": par,
                   "optimizer": args.optimizer, "keep_prob": args.keep_prob, "graph": bool(info.get("graph")),

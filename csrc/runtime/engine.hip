@@ -515,9 +515,14 @@ int dtf_engine_dp_step(const DtfEngineDesc* e, const DtfDpFabric* f, int collaps
       DTF_TRY(dtf_gemm_tn_sgd(e->p2, e->da, f32at(e->params, e->off_wd1), bf16at(e->shadow, e->off_wd1), e->hyper, e->flat,
                               e->hidden, e->B, e->flat, e->hidden, e->hidden, s));
   } else {
-    DTF_TRY(backward_dense_impl(e, -1, s));
+    // the hand-over event rides on the wgrad kernel itself where that is possible (eager launches: a recorded event
+    // is a marker packet, a 5-7 us hole in the compute stream); under graph capture it is a plain dependency edge
+    hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+    (void)hipStreamIsCapturing(s, &cap);
+    const bool bind = comm != s && cap == hipStreamCaptureStatusNone;
+    DTF_TRY(backward_dense_impl(e, -1, s, bind ? e->ev_dense_ready : nullptr));
     if (comm != s) {
-      HIP_TRY(hipEventRecord(e->ev_dense_ready, s));
+      if (!bind) HIP_TRY(hipEventRecord(e->ev_dense_ready, s));
       HIP_TRY(hipStreamWaitEvent(comm, e->ev_dense_ready, 0));
     }
     DTF_TRY(dtf_dp_dense_exchange(f, adam, f32at(e->grads, e->off_wd1), f32at(e->params, e->off_wd1),

@@ -83,6 +83,13 @@ class DpFabric:
         nbytes = int(self.lib.dtf_dp_fabric_layout(ctypes.byref(d)))
         if nbytes <= 0:
             raise RuntimeError("dtf_dp_fabric_layout rejected the configuration")
+        # DTF_DP_FAKE_WORLD=k (one rank only; TIMING DIAGNOSTIC, the training result is wrong): the dense kernels work
+        # on a shard of 1/k of wd1, as each rank of a k-rank job would -- what their local cost is at that world size
+        self.fake_world = int(os.environ.get("DTF_DP_FAKE_WORLD", "0")) if self.world == 1 else 0
+        if self.fake_world > 1:
+            d.csz = n_dense // self.fake_world // 8 * 8
+            if os.environ.get("DTF_DP_COMMIT_BLOCKS") is None:
+                d.commit_blocks = max(16, min(MAX_BLOCKS, -(-(int(d.csz) // 4) // (256 * 6))))
         # protocol state in ordinary device memory of this rank
         self.seq_tail = torch.ones(TAIL_BLOCKS + MAX_BLOCKS, dtype=torch.int32, device=self.device)
         self.seq_dense = torch.ones(MAX_BLOCKS, dtype=torch.int32, device=self.device)

@@ -267,6 +267,33 @@ def test_overlapped_dp_schedule_world2_over_gloo(gpu_lib, optimizer, tail, world
                          for r, (rc, o) in enumerate(outs))
 
 
+def test_cli_stalled_peer_ends_the_job_with_status_3_and_a_restart_resumes(gpu_lib, tmp_path):
+    """The same fault through the CLI (--fault_mute_step): both workers find the poison at their next health check,
+    say that they lost a peer and leave with exit status 3; no checkpoint is written after the fault; the restarted
+    job restores the last checkpoint -- taken at a step every worker had completed -- and trains on to the end with
+    bit-identical replicas."""
+    import numpy as np
+    logdir = str(tmp_path / "logs")
+    args = ["--mode=sync", "--batch_size=64", "--p2p_allreduce", "--p2p_timeout=5", "--health_check_steps=5",
+            "--save_model_secs=0.02", "--heartbeat_timeout=30", "--display_step=500"] + [a for a in COMMON if "display" not in a]
+    # (a step takes ~0.1 ms here: the fault comes late enough for a few timed checkpoints to exist)
+    out = launch(1, 2, args + ["--steps=6000", "--fault_mute_step=2002", "--fault_inject_task=1"], logdir, backend="hip")
+    for w in (0, 1):
+        rc, o = out[("worker", w)]
+        assert rc == 3, (w, rc, o[-2500:])
+        assert "lost contact with a peer" in o and "P2PHealthError" in o, o[-2500:]
+    assert "injected stall" in out[("worker", 1)][1]
+    steps = sorted(int(f.split("-")[1].split(".")[0]) for f in os.listdir(logdir) if f.endswith(".index"))
+    assert steps and steps[-1] <= 2002, steps        # nothing was saved from the poisoned state
+    dumps = [str(tmp_path / f"w{i}.npy") for i in range(2)]
+    out = launch(1, 2, args + [f"--steps={steps[-1] + 30}"], logdir, backend="hip",
+                 per_task_extra={("worker", w): [f"--dump_params={dumps[w]}"] for w in (0, 1)})
+    _ok(out)
+    assert f"Restored from checkpoint" in out[("worker", 0)][1] and f"global_step={steps[-1]}" in out[("worker", 0)][1]
+    p0, p1 = (np.load(d) for d in dumps)
+    assert np.array_equal(p0, p1), "workers ended with different master weights"
+
+
 @pytest.mark.parametrize("optimizer,mode,world,dtype", [("sgd", "eager", 2, "bf16"), ("adam", "graph", 2, "bf16"),
                                                         ("sgd", "graph", 4, "bf16"), ("adam", "eager", 2, "fp32")])
 def test_fabric_stalled_peer_is_all_or_nothing(gpu_lib, optimizer, mode, world, dtype):
