@@ -164,12 +164,15 @@ int dtf_ps_blocks();
 int dtf_ps_max_workers();
 int dtf_ps_push(const void* grads, void* dst, void* flags, void* hdr, const void* version, int nr, const long* lo,
                 const long* hi, long n_total, unsigned seq, unsigned kind, hipStream_t s);
-int dtf_ps_poll(const void* flags, const void* hdr, int W, int NB, int start, const unsigned* expect, void* out,
-                double timeout_s, hipStream_t s);
-int dtf_ps_apply_push(int adam, void* w, void* m, void* v, const void* hyper, const void* grad, int nr, const long* lo,
-                      const long* hi, long n_total, int apply, double adam_t, void* box_f32, void* box_bf16, long n_dense,
-                      void* box_flags, void* box_hdr, void* full, void* full_flags, const void* full_src, unsigned adam_count,
-                      unsigned seq, unsigned long long step, unsigned stop, hipStream_t s);
+// resident service loop of a ps task (ps_serve): control block in uncached memory, summary in pinned host memory
+long dtf_ps_ctl_bytes();
+int dtf_ps_out_words();
+int dtf_ps_serve_init(void* ctl, int W, unsigned long long step, hipStream_t s);
+int dtf_ps_ctl_set_dropped(void* ctl, unsigned mask, hipStream_t s);
+int dtf_ps_serve(int adam, void* ctl, void* own, void* const* boxes, int W, int NB, int p, long n_total, long n_dense,
+                 const long* layout9, int nr, const long* lo, const long* hi, void* w, void* m, void* v, const void* hyper,
+                 unsigned adam_t0, unsigned long long training_iter, unsigned round0, double budget_s, double idle_s,
+                 void* out, hipStream_t s);
 int dtf_ps_install(const void* box_flags, const void* box_hdr, const void* box_f32, const void* box_bf16, long n_dense,
                    int nr, const long* lo, const long* hi, long n_total, unsigned seq, void* params, void* shadow,
                    const void* full, const void* full_flags, void* full_dst, void* state, void* version, void* host_hdr,

@@ -41,6 +41,7 @@
 #include "api.h"
 #include "common.hpp"
 #include "optim_core.hpp"
+#include "peer_store.hpp"
 
 namespace dtf {
 
@@ -122,23 +123,6 @@ __device__ __forceinline__ int dp_verdict(unsigned* done, int nblk, int b, unsig
   }
   __syncthreads();
   return *sh;
-}
-
-// Stores into a PEER's exchange buffer: write-through past every cache (sc0 sc1), and the "release" that publishes
-// them is a wait for their completion -- NOT a system-scope fence.  A fence (buffer_wbl2 sc0 sc1) writes back every
-// dirty line of this XCD's L2, i.e. whatever the conv backward kernels running next to the dense exchange have just
-// produced: 64 of them per launch made the overlapped conv2 wgrad 13 us slower and the exchange itself 29 us long for
-// 5 MB of traffic (measured, rocprofv3 timeline).  The exchange buffers are uncached pages, nothing of them ever sits
-// in a cache, so once the write-through stores are acknowledged (vmcnt 0) there is nothing left for a write-back to do.
-__device__ __forceinline__ void dp_put16(void* p, const f32x4& v) {
-  asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" : : "v"(p), "v"(v) : "memory");
-}
-__device__ __forceinline__ void dp_put8(void* p, const u32x2& v) {
-  asm volatile("global_store_dwordx2 %0, %1, off sc0 sc1" : : "v"(p), "v"(v) : "memory");
-}
-__device__ __forceinline__ void dp_puts_done() { asm volatile("s_waitcnt vmcnt(0)" : : : "memory"); }
-__device__ __forceinline__ void dp_raise(unsigned* flag, unsigned v) {     // after dp_puts_done() + __syncthreads()
-  __hip_atomic_store(flag, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 
 // dst[i] = src[i] for i in [lo + tid, hi) with stride nthr: four loads in flight per thread, then four stores

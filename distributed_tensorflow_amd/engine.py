@@ -509,9 +509,17 @@ class HipEngine:
         torch.cuda.current_stream(self.device).synchronize()
         return float(self._metrics_host[0]), float(self._metrics_host[1])
 
+    def freeze_metrics(self):
+        """Reduce the metrics of the most recent forward NOW (one tiny launch) and make last_metrics() report that
+        value until the next freeze: a caller that has already enqueued the next step's forward (the asynchronous
+        worker's look-ahead, parallel/async_push.py) still reports the batch its last completed step trained on."""
+        self._metrics(self.B, accumulate=False)
+        self._metrics_frozen = True
+
     def last_metrics(self):
         """(mean loss, accuracy) of the most recent forward; forces a device sync."""
-        self._metrics(self.B, accumulate=False)
+        if not getattr(self, "_metrics_frozen", False):
+            self._metrics(self.B, accumulate=False)
         sl, sc = self._read_metrics()
         return sl / self.B, sc / self.B
 

@@ -85,13 +85,16 @@ _SIGS = {
     "dtf_ps_max_workers": [],
     "dtf_ps_push": [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, ctypes.POINTER(c_long), ctypes.POINTER(c_long),
                     c_long, c_uint, c_uint, c_void_p],
-    "dtf_ps_poll": [c_void_p, c_void_p, c_int, c_int, c_int, ctypes.POINTER(c_uint), c_void_p, c_double, c_void_p],
-    "dtf_ps_apply_push": [c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, ctypes.POINTER(c_long),
-                          ctypes.POINTER(c_long), c_long, c_int, c_double, c_void_p, c_void_p, c_long, c_void_p, c_void_p,
-                          c_void_p, c_void_p, c_void_p, c_uint, c_uint, ctypes.c_ulonglong, c_uint, c_void_p],
     "dtf_ps_install": [c_void_p, c_void_p, c_void_p, c_void_p, c_long, c_int, ctypes.POINTER(c_long), ctypes.POINTER(c_long),
                        c_long, c_uint, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int,
                        c_void_p, c_double, c_void_p],
+    "dtf_ps_ctl_bytes": [],
+    "dtf_ps_out_words": [],
+    "dtf_ps_serve_init": [c_void_p, c_int, ctypes.c_ulonglong, c_void_p],
+    "dtf_ps_ctl_set_dropped": [c_void_p, c_uint, c_void_p],
+    "dtf_ps_serve": [c_int, c_void_p, c_void_p, ctypes.POINTER(c_void_p), c_int, c_int, c_int, c_long, c_long,
+                     ctypes.POINTER(c_long), c_int, ctypes.POINTER(c_long), ctypes.POINTER(c_long), c_void_p, c_void_p, c_void_p,
+                     c_void_p, c_uint, ctypes.c_ulonglong, c_uint, c_double, c_double, c_void_p, c_void_p],
     "dtf_p2p_alloc": [c_long, ctypes.POINTER(c_void_p)],
     "dtf_p2p_free": [c_void_p],
     "dtf_p2p_export": [c_void_p, c_char_p],
@@ -203,7 +206,7 @@ def load() -> ctypes.CDLL:
     for name, argtypes in list(_SIGS.items()) + list(_ENGINE_SIGS.items()):
         fn = getattr(lib, name)
         fn.argtypes = argtypes
-        fn.restype = c_long if name in ("dtf_p2p_bytes", "dtf_p2p2_bytes", "dtf_dp_fabric_layout") else c_int
+        fn.restype = c_long if name in ("dtf_p2p_bytes", "dtf_p2p2_bytes", "dtf_dp_fabric_layout", "dtf_ps_ctl_bytes") else c_int
     lib.dtf_build_flavour.restype = c_char_p
     lib.dtf_build_flavour.argtypes = []
     flavour = lib.dtf_build_flavour().decode()

@@ -39,6 +39,10 @@ from ..ops import native
 from .strategies import broadcast_state, ps_shards
 
 KIND_GRAD, KIND_BYE, KIND_MASTER, KIND_ADAM_M, KIND_ADAM_V = 1, 2, 3, 4, 5
+
+
+class PsLost(RuntimeError):
+    """A parameter-server task did not answer within the bound (lost or stalled)."""
 MAX_STALENESS = 8
 
 
@@ -163,8 +167,17 @@ class AsyncPushWorker:
     name = "async-push"
     coordinated_stop = False      # asynchronous workers come and go on their own (reference M:174-176)
 
-    def __init__(self, backend: Backend, task: TaskInfo, chief_rank: int, staleness: int = 0, timeout_s: float = 30.0):
+    def __init__(self, backend: Backend, task: TaskInfo, chief_rank: int, staleness: int = 0, timeout_s: float = 30.0,
+                 look_ahead: bool = True):
         self.b, self.task, self.chief_rank = backend, task, chief_rank
+        # staleness 0 (the reference's pull-after-push) has to tell the caller the global step that includes its own
+        # update, i.e. it waits for the answer every step.  look_ahead: the kernels of the NEXT gradient are enqueued
+        # before that wait (they follow the install in stream order, so they run on exactly the parameters they should),
+        # and the wait is for the install's event only -- the GPU works through the host's launch latency instead of
+        # idling in it.  A gradient enqueued this way after the last step is simply never pushed.
+        self.look_ahead = bool(look_ahead) and int(staleness) == 0
+        self._ahead = False
+        self._installed_ev = None
         self.fab = PushFabric(backend, task, staleness)
         self.k = self.fab.k
         self.timeout_s = float(timeout_s)
@@ -227,25 +240,48 @@ class AsyncPushWorker:
     def _read_header(self, sync: bool):
         if sync:
             torch.cuda.current_stream(self.fab.eng.device).synchronize()
-            if int(self._status.item()):
-                raise RuntimeError("parameter server did not answer in time (lost or stalled ps task)")
         h = self._hdr
-        if int(h[3]) > 0:
-            self.step_count = (int(h[0]) & 0xFFFFFFFF) | ((int(h[1]) & 0xFFFFFFFF) << 32)
-            self.stop = bool(int(h[2]))
+        # h[5]: an install kernel's wait ran out (mirrored by the kernel itself: with staleness k > 0 this thread never
+        # synchronises, and must not go on pushing gradients computed on parameters that are no longer refreshed)
+        if int(h[5]) or (sync and int(self._status.item())):
+            raise PsLost("parameter server did not answer in time (lost or stalled ps task)")
+        # the GPU may be rewriting the header right now (k > 0): the sequence word is written last, so the other words
+        # are taken only between two equal, non-zero readings of it
+        for _ in range(4):
+            seq = int(h[3])
+            if seq <= 0:
+                return
+            step, stop = (int(h[0]) & 0xFFFFFFFF) | ((int(h[1]) & 0xFFFFFFFF) << 32), bool(int(h[2]))
+            if int(h[3]) == seq:
+                self.step_count, self.stop = step, stop
+                return
 
     # ------------------------------------------------------------------ strategy interface
     def step(self) -> int:
         n = self.seq + 1
-        self.b.compute_gradients()                 # on the parameters of answer n - 1 - k
-        self.b.advance_input()                     # the update happens on the ps: move on to the next batch here
+        if not self._ahead:
+            self.b.compute_gradients()             # on the parameters of answer n - 1 - k
+            self.b.advance_input()                 # the update happens on the ps: move on to the next batch here
+        self._ahead = False
         self._push(n, KIND_GRAD)
         self.seq = n
         self._catch_up(n - self.k)                 # answer n - k must be in before gradient n + 1 is computed
         # k = 0: the reference's semantics, the step returns the global step that includes this worker's update
-        # (one stream synchronisation per step, inherent in pull-after-push); k > 0: the host runs ahead and reads
-        # the newest header that has landed
-        self._read_header(sync=(self.k == 0))
+        # (one wait per step, inherent in pull-after-push); k > 0: the host runs ahead and reads the newest header
+        # that has landed
+        if self.look_ahead and not self.stop:
+            eng = self.fab.eng
+            eng.freeze_metrics()                   # display lines report the batch of the gradient just pushed
+            if self._installed_ev is None:
+                self._installed_ev = torch.cuda.Event()
+            self._installed_ev.record()
+            self.b.compute_gradients()             # gradient n + 1, behind the install of answer n in stream order
+            self.b.advance_input()
+            self._ahead = True
+            self._installed_ev.synchronize()       # the header of answer n is in pinned memory
+            self._read_header(sync=False)
+        else:
+            self._read_header(sync=(self.k == 0))
         return self.step_count
 
     def prepare_save(self):
@@ -282,8 +318,12 @@ class AsyncPushServer:
     """One ps task: polls its mailbox, applies gradients in the order the poll finds them, answers each worker."""
 
     def __init__(self, backend: Backend, task: TaskInfo, chief_rank: int, training_iter: int, staleness: int = 0,
-                 log=None, peer_lost: Optional[Callable[[int], bool]] = None):
+                 log=None, peer_lost: Optional[Callable[[int], bool]] = None, budget_s: float = 0.02, idle_s: float = 0.002):
         self.b, self.task, self.chief_rank, self.training_iter = backend, task, chief_rank, training_iter
+        # one launch of the service kernel runs at most budget_s and leaves early after idle_s without a message
+        import os
+        self.budget_s = float(os.environ.get("DTF_PS_BUDGET_S", budget_s))      # (tuning overrides for tools/async_path_cost.py)
+        self.idle_s = float(os.environ.get("DTF_PS_IDLE_S", idle_s))
         self.fab = PushFabric(backend, task, staleness)
         self.log = log or (lambda *a: None)
         self.peer_lost = peer_lost
@@ -295,65 +335,61 @@ class AsyncPushServer:
         broadcast_state(self.b, self.chief_rank)
 
     def serve(self) -> int:
+        """The service loop lives on the GPU (csrc/kernels/ps.hip ps_serve): one launch polls the mailboxes, applies
+        whatever has arrived in arrival order, answers and counts, for as long as messages keep coming (at most
+        ``budget`` seconds, or until nothing has arrived for ``idle``).  This thread only relaunches it, reads the
+        counters it leaves in pinned memory, and looks after what is not the GPU's business: lost workers."""
         f, eng, L = self.fab, self.fab.eng, self.fab.L
         p = self.task.task_index
         if p not in f.ranges:          # more ps tasks than variables: nothing to own, nobody writes to this task
             self.log(f"ps/{p}: owns no variable; nothing to serve")
             return self.b.get_global_step()
+        lib = f.lib
         W, NB = f.W, f.NB
         own = f.bases[self.task.rank]
         wr = self.task.cluster.worker_ranks()
-        expect = [1] * W
-        out = torch.zeros((W, 4), dtype=torch.int32).pin_memory()
         stream = torch.cuda.current_stream(eng.device)
         s = stream.cuda_stream
-        step = self.b.get_global_step()
         adam = eng.optimizer == "adam"
         adam_t0 = self.b.get_adam_t() if adam else 0
-        start, last_check = 0, time.monotonic()
-        nr, lo, hi = f.carr(p) if p in f.ranges else (0, None, None)
-        bf16 = f.n_dense > 0
-        while any(expect):
-            arr = (ctypes.c_uint * W)(*expect)
-            native.check(f.lib.dtf_ps_poll(own + L.mb_flags, own + L.mb_hdr, W, NB, start, arr, out.data_ptr(), 0.002, s),
-                         "ps_poll")
-            stream.synchronize()
-            ready = [w for w in ((start + i) % W for i in range(W)) if expect[w] and int(out[w, 0])]
-            if not ready:
+        nr, lo, hi = f.carr(p)
+        ctl = ctypes.c_void_p()
+        native.check(lib.dtf_p2p_alloc(int(lib.dtf_ps_ctl_bytes()), ctypes.byref(ctl)), "ps control block")
+        out = torch.zeros(int(lib.dtf_ps_out_words()), dtype=torch.int32).pin_memory()
+        boxes = (ctypes.c_void_p * W)(*[f.bases[wr[w]] for w in range(W)])
+        layout9 = (ctypes.c_long * 9)(L.mb_flags, L.mb_hdr, L.mb_data, L.bx_flags, L.bx_hdr, L.bx_full_flags, L.bx_f32,
+                                      L.bx_bf16, L.bx_full)
+        native.check(lib.dtf_ps_serve_init(ctl, W, self.b.get_global_step(), s), "ps_serve_init")
+        round0, dropped, last_check = 0, 0, time.monotonic()
+        step = self.b.get_global_step()
+        try:
+            while True:
+                native.check(lib.dtf_ps_serve(int(adam), ctl, own, boxes, W, NB, p, f.n_total, f.n_dense, layout9, nr, lo, hi,
+                                              eng.params.data_ptr(), eng.adam_m.data_ptr() if adam else None,
+                                              eng.adam_v.data_ptr() if adam else None, eng.hyper.data_ptr(), adam_t0,
+                                              self.training_iter, round0, self.budget_s, self.idle_s, out.data_ptr(), s),
+                             "ps_serve")
+                stream.synchronize()
+                o = [int(x) & 0xFFFFFFFF for x in out.tolist()]
+                round0, step, self.applied = o[0], o[1] | (o[2] << 32), o[3]
+                if o[5]:
+                    raise RuntimeError(f"ps/{p}: the service kernel gave up on a stuck workgroup")
+                if o[4]:
+                    break
                 now = time.monotonic()
                 if self.peer_lost is not None and now - last_check > 1.0:
                     last_check = now
                     for w in range(W):
-                        if expect[w] and self.peer_lost(wr[w]):
+                        if o[8 + w] and not (dropped >> w) & 1 and self.peer_lost(wr[w]):
                             self.log(f"ps/{p}: worker rank {wr[w]} lost; continuing")     # reference: workers come and go
                             self.dropped.append(wr[w])
-                            expect[w] = 0
-                continue
-            for w in ready:
-                n, kind = expect[w], int(out[w, 1])
-                version = (int(out[w, 2]) & 0xFFFFFFFF) | ((int(out[w, 3]) & 0xFFFFFFFF) << 32)
-                if kind == KIND_BYE:
-                    expect[w] = 0
-                    continue
-                apply = kind == KIND_GRAD and step < self.training_iter
-                if apply:
-                    d = max(0, step - version)
-                    self.staleness_hist[d] = self.staleness_hist.get(d, 0) + 1
-                    step += 1
-                    self.applied += 1
-                if nr:
-                    _, _, data = L.mb(own, w, n % NB)
-                    bflags, bhdr, b32, b16 = L.bx(f.bases[wr[w]], p, n % NB)
-                    full, full_flags = L.bx_master(f.bases[wr[w]], p) if kind >= KIND_MASTER else (None, None)
-                    full_src = {KIND_ADAM_M: eng.adam_m, KIND_ADAM_V: eng.adam_v}.get(kind) if adam else None
-                    native.check(f.lib.dtf_ps_apply_push(
-                        int(adam), eng.params.data_ptr(), eng.adam_m.data_ptr() if adam else None,
-                        eng.adam_v.data_ptr() if adam else None, eng.hyper.data_ptr(), data, nr, lo, hi, f.n_total,
-                        int(apply), float(adam_t0 + self.applied), b32, b16 if bf16 else None, f.n_dense, bflags, bhdr,
-                        full, full_flags, full_src.data_ptr() if full_src is not None else None, adam_t0 + self.applied,
-                        n, step, int(step >= self.training_iter), s), "ps_apply_push")
-                expect[w] = n + 1
-            start = (start + 1) % W
+                            dropped |= 1 << w
+                    native.check(lib.dtf_ps_ctl_set_dropped(ctl, dropped, s), "ps_ctl_set")
+            hist = o[24:24 + 64]
+            self.staleness_hist = {d: n for d, n in enumerate(hist) if n}
+        finally:
+            stream.synchronize()
+            lib.dtf_p2p_free(ctl)
         stream.synchronize()
         self.b.set_global_step(step)
         if adam:
