@@ -149,7 +149,9 @@ def main():
             grad_comm = args.grad_comm if dtype == "bf16" else "fp32"
             dp = SyncDataParallel(eng, tail_group=tail_group, collapse_world1=not args.no_collapse,
                                   shard_dense={"auto": None, "allreduce": False, "sharded": True}[args.dense],
-                                  grad_comm=grad_comm)
+                                  grad_comm=grad_comm,
+                                  # more than four ranks rehearsing on ONE GPU: one hardware queue per rank (see below)
+                                  fabric_single_stream=bool(args.rehearse_one_gpu and world > 4))
             dp.broadcast_parameters()
             step = dp.train_step
             info.update(grad_comm=grad_comm, gradient_exchange="rccl", dense="rccl " + ("reduce-scatter + sharded update + "
@@ -198,7 +200,11 @@ def main():
             than from the stream on this stack, the host less.  -> ms/step of the choice."""
             t_eager = float("inf") if args.graph else step_ms(TRIAL_STEPS)
             t_graph = float("inf")
-            if not args.no_graph:
+            # (a rehearsal with more than four ranks on ONE GPU skips the graph trial: eight processes' graph branches
+            #  oversubscribe the device's hardware queues, the scheduler starts time-slicing them at millisecond
+            #  quanta, and every spin-wait for a peer then costs a quantum -- 22 ms/step, observed, and it stays that
+            #  way after the graph is released.  One process per GPU has the queues to itself.)
+            if not args.no_graph and not (args.rehearse_one_gpu and world > 4):
                 dp.capture()
                 t_graph = step_ms(TRIAL_STEPS)
                 if t_eager < t_graph:
@@ -318,9 +324,10 @@ def main():
         if fabric is not None:
             # Last line of defence before the clock starts: a poisoned fabric on ANY rank (a wait timed out during the
             # warm-up) sends both messages back to RCCL, and the warm-up is repeated on that path.
-            if max_over_ranks(fabric.poisoned()):
+            why = int(max_over_ranks(fabric.poisoned()))
+            if why:
                 dp.release_graph()
-                back_to_rccl("a p2p wait timed out during warm-up")
+                back_to_rccl("a p2p wait timed out during warm-up" if why & 1 else f"fabric poisoned during warm-up (reason bits {why})")
                 for _ in range(args.warmup):
                     step()
                 barrier()

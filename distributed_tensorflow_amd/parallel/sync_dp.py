@@ -89,7 +89,7 @@ class SyncDataParallel:
 
     def __init__(self, engine: HipEngine, bucket_mb: float = 64.0, group=None, tail_group=None,
                  defer_dense_update: bool = True, fabric=None, collapse_world1: bool = True,
-                 shard_dense=None, grad_comm: str = "fp32"):
+                 shard_dense=None, grad_comm: str = "fp32", fabric_single_stream: bool = False):
         if grad_comm not in ("fp32", "bf16"):
             raise ValueError(f"grad_comm must be fp32 or bf16, not {grad_comm!r}")
         if grad_comm == "bf16" and engine.dtype != "bf16":
@@ -113,6 +113,9 @@ class SyncDataParallel:
         # (False keeps the N > 1 kernels in the step -- what a one-GPU box can measure of their local cost).
         self.fabric = fabric
         self.collapse_world1 = bool(collapse_world1)
+        # fabric_single_stream: the dense exchange runs on the compute stream itself instead of a branch next to the
+        # conv backward (no overlap, no second hardware queue: for many ranks that share ONE GPU in rehearsals)
+        self.fabric_single_stream = bool(fabric_single_stream)
         self._graph = None
         self.defer = defer_dense_update
         lay = engine.layout
@@ -317,7 +320,9 @@ class SyncDataParallel:
     def _fabric_step(self):
         eng = self.eng
         check(eng.lib.dtf_engine_dp_step(eng._d(), self.fabric.byref(), int(self.collapse_world1), eng.step_inc,
-                                         torch.cuda.current_stream(eng.device).cuda_stream, self.comm_stream.cuda_stream),
+                                         torch.cuda.current_stream(eng.device).cuda_stream,
+                                         torch.cuda.current_stream(eng.device).cuda_stream if self.fabric_single_stream
+                                         else self.comm_stream.cuda_stream),
               "dp_step")
 
     def capture(self, warmup: int = 2):
