@@ -25,14 +25,10 @@
 //   memory.  Split-K over images across workgroups; partial slabs are summed by
 //   reduce_segments (optim.hip).
 #include "conv1_core.hpp"
+#include "conv2_diag.hpp"   // DTF_ABLATED / DTF_STAMP / DTF_LAP... : empty in the shipped library
 
-// Timing-ablation hook (tools/conv_ablate.py builds diagnostic copies with -DDTF_ABLATE=<bits>;
-// the shipped library always has 0): 1 = no B global loads in the k-loop, 2 = no A LDS reads,
-// 4 = no MFMAs, 8 = no staging loads, 16 = no epilogue stores; wgrad: 32 = no x staging,
-// 64 = no MFMAs, 128 = no dY staging/expansion, 256 = no k-loop at all, 512 = no slab write.
 // Tile configuration of the 32->64 layer: KTOT, KC, NC, IMGS, NW, MODE, min waves/SIMD
 // (overridable so tools/conv_ablate.py can sweep it)
-// Diagnostic: delay the second half of the grid by DTF_STAGGER microseconds (tools/conv_ablate.py stagger)
 #ifndef DTF_FWD_CFG
 #define DTF_FWD_CFG 32, 32, 64, 2, 2, MODE_FWD, 4
 #endif
@@ -40,20 +36,7 @@
 #define DTF_DGRAD_CFG 64, 32, 32, 2, 1, MODE_DGRAD, 3
 #endif
 
-// Diagnostic (-DDTF_TIMING=1, tools/conv_timeline.py): wave 0 of every igemm workgroup stamps the 100 MHz wall
-// clock at its phase boundaries into a buffer registered with dtf_conv2_set_timing_buf
-
 namespace dtf {
-
-#if DTF_TIMING
-__device__ long long* g_timing_buf = nullptr;
-#define DTF_STAMP(slot)                                                                     \
-  do {                                                                                      \
-    if (threadIdx.x == 0 && g_timing_buf) g_timing_buf[(size_t)blockIdx.x * 16 + (slot)] = wall_clock64(); \
-  } while (0)
-#else
-#define DTF_STAMP(slot) do {} while (0)
-#endif
 
 constexpr int kTileW = 18;          // 14 + 2*2 halo
 constexpr int kTilePos = 328;       // 18*18 = 324 (+4 slack for the dummy window's reads)
@@ -141,13 +124,8 @@ __global__ __launch_bounds__(IMGS * 2 * NW * 64, MINW) void conv5x5_igemm(
   const int w_n = wave % NW;
   const int img0 = blockIdx.x * IMGS;
   DTF_STAMP(0);
-#if DTF_TIMING
-  if (threadIdx.x == 0 && g_timing_buf) g_timing_buf[(size_t)blockIdx.x * 16 + 6] = clock64();
-#endif
-  if (DTF_STAGGER > 0 && (DTF_STAGGER_MODE == 0 ? blockIdx.x >= gridDim.x / 2
-                          : DTF_STAGGER_MODE == 1 ? (blockIdx.x & 1) != 0
-                          : DTF_STAGGER_MODE == 2 ? ((blockIdx.x >> 3) & 1) != 0 : ((blockIdx.x >> 8) & 1) != 0))
-    for (int i = 0; i < DTF_STAGGER; ++i) __builtin_amdgcn_s_sleep(32);   // ~1 us per trip
+  DTF_STAMP_CYCLES(6);
+  DTF_STAGGER_HERE();
 
   // Fused conv1 stage: the dependent chain cursor -> dataset row -> image pixels (two memory round trips)
   // and the filter fragments are requested BEFORE the LDS zero fill, which then runs under their latency
@@ -203,7 +181,7 @@ __global__ __launch_bounds__(IMGS * 2 * NW * 64, MINW) void conv5x5_igemm(
       const int c = min(tid + r * NTHREADS, DG_NCHUNK - 1);
       const int ch = c % CH8, pp = (c / CH8) % 49, im = c / (CH8 * 49);
       const uint32_t off = (uint32_t)(((size_t)min(img0 + im, B - 1) * 49 + pp) * KTOT + kc + ch * 8);
-      if (DTF_ABLATE & 8) {
+      if DTF_ABLATED(8) {
         dg_g[r] = (u32x4){0u, 0u, 0u, 0u};
         dg_a[r] = (u32x2){0x04040404u, 0x04040404u};
       } else {
@@ -241,14 +219,10 @@ __global__ __launch_bounds__(IMGS * 2 * NW * 64, MINW) void conv5x5_igemm(
     }
     __syncthreads();
     DTF_STAMP(6);   // (fused forward only: overwrites the start clock) input images in LDS
-#if DTF_TIMING
-    long long tr_mma = 0, tr_copy = 0, tr_prev = wall_clock64();
-#endif
+    DTF_LAPS(tr_mma = 0, tr_copy = 0);
     for (int rp = wi; rp < 14; rp += 2 * NW) {
       conv1_pooled_row(img_w, rp, frags, orow, arow, lane);
-#if DTF_TIMING
-      { long long t = wall_clock64(); tr_mma += t - tr_prev; tr_prev = t; }
-#endif
+      DTF_LAP(tr_mma);
       __builtin_amdgcn_wave_barrier();
       if (b < B) {
         // 14 px x 32 ch: 56 x 16 B of bf16 -> global p1 AND this kernel's LDS tile; 28 x 16 B of argmax codes
@@ -263,16 +237,10 @@ __global__ __launch_bounds__(IMGS * 2 * NW * 64, MINW) void conv5x5_igemm(
         if (lane < 28) reinterpret_cast<u4*>(c1f.arg1 + obase)[lane] = reinterpret_cast<const u4*>(arow)[lane];
       }
       __builtin_amdgcn_wave_barrier();
-#if DTF_TIMING
-      { long long t = wall_clock64(); tr_copy += t - tr_prev; tr_prev = t; }
-#endif
+      DTF_LAP(tr_copy);
     }
-#if DTF_TIMING
-    if (threadIdx.x == 0 && g_timing_buf) {   // wave 0: 4 rows (0, 4, 8, 12)
-      g_timing_buf[(size_t)blockIdx.x * 16 + 8] = tr_mma;
-      g_timing_buf[(size_t)blockIdx.x * 16 + 9] = tr_copy;
-    }
-#endif
+    DTF_PUT(8, tr_mma);    // wave 0: 4 rows (0, 4, 8, 12)
+    DTF_PUT(9, tr_copy);
   } else if (MODE == MODE_FWD) {
     // all loads of a thread are issued before the first LDS write (one memory latency per
     // block, not one per chunk); indices past the end are clamped and their write is skipped
@@ -284,7 +252,7 @@ __global__ __launch_bounds__(IMGS * 2 * NW * 64, MINW) void conv5x5_igemm(
       int c = min(tid + r * NTHREADS, NCHUNK - 1);
       int ch = c % CH8, pos = (c / CH8) % 196, im = c / (CH8 * 196);
       int b = min(img0 + im, B - 1);
-      v[r] = (DTF_ABLATE & 8) ? (u32x4){0u, 0u, 0u, 0u}
+      v[r] = DTF_ABLATED(8) ? (u32x4){0u, 0u, 0u, 0u}
                               : *reinterpret_cast<const u32x4*>(in + ((size_t)b * 196 + pos) * KTOT + kc0 + ch * 8);
     }
 #pragma unroll
@@ -343,12 +311,12 @@ __global__ __launch_bounds__(IMGS * 2 * NW * 64, MINW) void conv5x5_igemm(
     bf16x8 a[7];
 #pragma unroll
     for (int i = 0; i < 7; ++i)
-      a[i] = *reinterpret_cast<const bf16x8*>((DTF_ABLATE & 2) ? a_base + i * 8 : ap + i * (2 * TW * KP));
+      a[i] = *reinterpret_cast<const bf16x8*>(DTF_ABLATED(2) ? a_base + i * 8 : ap + i * (2 * TW * KP));
 #pragma unroll
     for (int i = 0; i < 7; ++i)
 #pragma unroll
       for (int j = 0; j < NT; ++j) {
-        if (DTF_ABLATE & 4) { asm volatile("" ::"v"(a[i]), "v"(bf[j])); }
+        if DTF_ABLATED(4) { asm volatile("" ::"v"(a[i]), "v"(bf[j])); }
         else acc[i][j] = mfma16(a[i], bf[j], acc[i][j]);
       }
   };
@@ -363,9 +331,9 @@ __global__ __launch_bounds__(IMGS * 2 * NW * 64, MINW) void conv5x5_igemm(
     for (int p = 0; p < D - 1; ++p) load_b(ring[p], p < NSTEPS ? p : NSTEPS - 1);
 #pragma unroll
     for (int step = 0; step < NSTEPS; ++step) {
-      if (!(DTF_ABLATE & 1)) load_b(ring[(step + D - 1) % D], step + D - 1 < NSTEPS ? step + D - 1 : NSTEPS - 1);
+      if (!DTF_ABLATED(1)) load_b(ring[(step + D - 1) % D], step + D - 1 < NSTEPS ? step + D - 1 : NSTEPS - 1);
       __builtin_amdgcn_sched_barrier(0);
-      do_step(step, ring[(DTF_ABLATE & 1) ? 0 : step % D]);
+      do_step(step, ring[DTF_ABLATED(1) ? 0 : step % D]);
     }
   } else {
     // B fragments of step s+1 are loaded (unconditionally: the last step re-loads itself, so every
@@ -373,13 +341,13 @@ __global__ __launch_bounds__(IMGS * 2 * NW * 64, MINW) void conv5x5_igemm(
     load_b(bcur, 0);
 #pragma unroll 1
     for (int step = 0; step < NSTEPS; step += 2) {
-      if (!(DTF_ABLATE & 1)) load_b(bnxt, min(step + 1, NSTEPS - 1));
+      if (!DTF_ABLATED(1)) load_b(bnxt, min(step + 1, NSTEPS - 1));
       __builtin_amdgcn_sched_barrier(0);
       do_step(step, bcur);
       if (step + 1 >= NSTEPS) break;
-      if (!(DTF_ABLATE & 1)) load_b(bcur, min(step + 2, NSTEPS - 1));
+      if (!DTF_ABLATED(1)) load_b(bcur, min(step + 2, NSTEPS - 1));
       __builtin_amdgcn_sched_barrier(0);
-      do_step(step + 1, (DTF_ABLATE & 1) ? bcur : bnxt);
+      do_step(step + 1, DTF_ABLATED(1) ? bcur : bnxt);
     }
   }
   }  // K chunks
@@ -417,7 +385,7 @@ __global__ __launch_bounds__(IMGS * 2 * NW * 64, MINW) void conv5x5_igemm(
     }
     __syncthreads();
     DTF_STAMP(4);
-    if (!(DTF_ABLATE & 16)) {
+    if (!DTF_ABLATED(16)) {
       const int nimg = min(IMGS, B - img0);
       u32x4* gp = reinterpret_cast<u32x4*>(out + (size_t)img0 * 49 * NC);
       for (int c = tid; c < nimg * 49 * NC / 8; c += NTHREADS) gp[c] = reinterpret_cast<const u32x4*>(ot)[c];
@@ -425,9 +393,7 @@ __global__ __launch_bounds__(IMGS * 2 * NW * 64, MINW) void conv5x5_igemm(
       for (int c = tid; c < nimg * 49 * NC / 16; c += NTHREADS) ga[c] = reinterpret_cast<const u32x4*>(oa)[c];
     }
     DTF_STAMP(5);
-#if DTF_TIMING
-    if (threadIdx.x == 0 && g_timing_buf) g_timing_buf[(size_t)blockIdx.x * 16 + 7] = clock64();
-#endif
+    DTF_STAMP_CYCLES(7);
   } else {
     bf16* ot = reinterpret_cast<bf16*>(smem);  // [IMGS][196][NC]
     if (ewin < 7) {
@@ -511,7 +477,7 @@ __global__ __launch_bounds__(IMGS * 2 * NW * 64, MINW) void conv5x5_igemm(
       DTF_STAMP(5);
     } else {
       __syncthreads();
-      if (!(DTF_ABLATE & 16)) {
+      if (!DTF_ABLATED(16)) {
         const int nimg = min(IMGS, B - img0);
         u32x4* gp = reinterpret_cast<u32x4*>(out + (size_t)img0 * 196 * NC);
         for (int c = tid; c < nimg * 196 * NC / 8; c += NTHREADS) gp[c] = reinterpret_cast<const u32x4*>(ot)[c];
@@ -605,14 +571,12 @@ __global__ __launch_bounds__(512, NT == 2 ? 2 : 1) void conv5x5_wgrad(
 
   const int b_begin = blockIdx.x * imgs_per_block;
   const int b_end = min(B, b_begin + imgs_per_block);
-#if DTF_TIMING
-  // slots per workgroup (gridDim.x * blockIdx.y + blockIdx.x), 16 each: wave 0 -> 0..7, wave 7 -> 8..15:
-  // 0 start, 1 loop entered, 2 loop left, 3 reduced, 4 sum(wait for prefetched loads), 5 sum(k-loop), 6 sum(stage), 7 sum(barrier wait)
-  long long* tb = (g_timing_buf && (lane == 0) && (wave == 0 || wave == 7))
-                      ? g_timing_buf + ((size_t)(blockIdx.y * gridDim.x + blockIdx.x) * 16 + (wave ? 8 : 0)) : nullptr;
-  long long t_k = 0, t_s = 0, t_w = 0, t_v = 0, t_prev = wall_clock64();
-  if (tb) tb[0] = t_prev;
-#endif
+  // (timing build: slots per workgroup (gridDim.x * blockIdx.y + blockIdx.x), 16 each: wave 0 -> 0..7, wave 7 -> 8..15:
+  //  0 start, 1 loop entered, 2 loop left, 3 reduced, 4 sum(wait for prefetched loads), 5 sum(k-loop), 6 sum(stage), 7 sum(barrier wait))
+  DTF_TIMING_ONLY(long long* tb = (g_timing_buf && (lane == 0) && (wave == 0 || wave == 7))
+                      ? g_timing_buf + ((size_t)(blockIdx.y * gridDim.x + blockIdx.x) * 16 + (wave ? 8 : 0)) : nullptr;)
+  DTF_LAPS(t_k = 0, t_s = 0, t_w = 0, t_v = 0);
+  DTF_TIMING_ONLY(if (tb) tb[0] = dtf_lap_prev_;)
 
   f32x4 acc[7][NT];
 #pragma unroll
@@ -653,17 +617,17 @@ __global__ __launch_bounds__(512, NT == 2 ? 2 : 1) void conv5x5_wgrad(
   u32x4 gv_r = {0u, 0u, 0u, 0u};
   u32x2 ar_r = {0u, 0u};
   auto prefetch = [&](int b) {
-    if (has_x && !(DTF_ABLATE & 32))
+    if (has_x && !DTF_ABLATED(32))
       xr = *reinterpret_cast<const u32x4*>(x + ((size_t)b * 196 + x_pos) * C_IN + ci_t * 16 + x_ch * 8);
-    if (has_dy && !(DTF_ABLATE & 128)) {
+    if (has_dy && !DTF_ABLATED(128)) {
       size_t off = ((size_t)b * 49 + d_pp) * C_OUT + co_t * CO_W + d_c8 * 8;
       gv_r = *reinterpret_cast<const u32x4*>(gpool + off);
       ar_r = *reinterpret_cast<const u32x2*>(arg + off);
     }
   };
   auto stage = [&](int boff) {
-    if (has_x && !(DTF_ABLATE & 32)) *reinterpret_cast<u32x4*>(xt + boff + x_tp * 16 + x_ch * 8) = xr;
-    if (has_dy && !(DTF_ABLATE & 128)) {
+    if (has_x && !DTF_ABLATED(32)) *reinterpret_cast<u32x4*>(xt + boff + x_tp * 16 + x_ch * 8) = xr;
+    if (has_dy && !DTF_ABLATED(128)) {
       const int r = d_pp / 7, w = d_pp % 7;
       u32x4 o[4];
       expand_pool_grad(gv_r, ar_r, o);
@@ -680,35 +644,25 @@ __global__ __launch_bounds__(512, NT == 2 ? 2 : 1) void conv5x5_wgrad(
   __syncthreads();  // zero fill done
   if (b_begin < b_end) stage(0);
   if (b_begin + 1 < b_end) prefetch(b_begin + 1);
-#if DTF_TIMING
-  if (tb) tb[1] = wall_clock64();
-#endif
+  DTF_TIMING_ONLY(if (tb) tb[1] = wall_clock64();)
   for (int b = b_begin; b < b_end; ++b) {
     const int boff = ((b - b_begin) & 1) * kBufElems;
     // image b is staged in buffer boff; every wave is done reading the other buffer (image b-1),
     // which this iteration refills with image b+1
-#if DTF_TIMING
-    t_prev = wall_clock64();
-#endif
+    DTF_LAP_START();
     __syncthreads();
-#if DTF_TIMING
-    { long long t = wall_clock64(); t_w += t - t_prev; t_prev = t; }
-#endif
+    DTF_LAP(t_w);
     // Image b+1 goes into the other buffer BEFORE this wave's k-loop: the staging waves (0..3: gradient
     // expansion, ~0.6 us of VALU + LDS writes per image) then work while their SIMD partners (waves 4..7)
     // already run MFMAs, and run their own k-loop while the partners drain -- with the staging after the
     // k-loop all eight waves competed for the matrix pipe first and it then sat idle during the staging
     // (tools/conv_timeline.py: 9.1 us of staging on the critical path of a 31 us kernel).
-#if DTF_TIMING
-    { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); long long t = wall_clock64(); t_v += t - t_prev; t_prev = t; }
-#endif
+    DTF_LAP_AFTER("s_waitcnt vmcnt(0)", t_v);
     if (!DTF_WGRAD_STAGE_LAST && b + 1 < b_end) {
       stage(kBufElems - boff);
       if (b + 2 < b_end) prefetch(b + 2);
     }
-#if DTF_TIMING
-    { long long t = wall_clock64(); t_s += t - t_prev; t_prev = t; }
-#endif
+    DTF_LAP(t_s);
     // k-loop over this wave's row pairs, software-pipelined: the 18 transposed reads of step r+2
     // are in flight while the 14 MFMAs of step r issue (two fragment sets, loop unrolled by two)
     const bf16* a_img = a_lane + boff;
@@ -740,7 +694,7 @@ __global__ __launch_bounds__(512, NT == 2 ? 2 : 1) void conv5x5_wgrad(
       }
 #pragma unroll
       for (int t = 0; t < 7; ++t) {
-        if (DTF_ABLATE & 64) {
+        if DTF_ABLATED(64) {
           asm volatile("" ::"v"(af[t]), "v"(bf[0]), "v"(bf[1]));
         } else {
 #pragma unroll
@@ -764,7 +718,7 @@ __global__ __launch_bounds__(512, NT == 2 ? 2 : 1) void conv5x5_wgrad(
           __builtin_amdgcn_sched_barrier(0);
         }
       }
-    } else if (!(DTF_ABLATE & 256)) {
+    } else if (!DTF_ABLATED(256)) {
       // 4 (r = 0,2,4,6) or 3 (r = 1,3,5) steps, straight-line so every wait count is exact
       bf16x8 af0[7], bf0[NT], af1[7], bf1[NT];
       const int r = (kh + b) & 1;
@@ -787,17 +741,13 @@ __global__ __launch_bounds__(512, NT == 2 ? 2 : 1) void conv5x5_wgrad(
         mma_frags(af0, bf0);
       }
     }
-#if DTF_TIMING
-    { asm volatile("s_nop 0" ::: "memory"); long long t = wall_clock64(); t_k += t - t_prev; t_prev = t; }
-#endif
+    DTF_LAP_AFTER("s_nop 0", t_k);
     if (DTF_WGRAD_STAGE_LAST && b + 1 < b_end) {
       stage(kBufElems - boff);
       if (b + 2 < b_end) prefetch(b + 2);
     }
   }
-#if DTF_TIMING
-  if (tb) { tb[2] = wall_clock64(); tb[5] = t_k; tb[6] = t_s; tb[7] = t_w; tb[4] = t_v; }
-#endif
+  DTF_TIMING_ONLY(if (tb) { tb[2] = wall_clock64(); tb[5] = t_k; tb[6] = t_s; tb[7] = t_w; tb[4] = t_v; })
 
   // ---- sum the two kh halves through LDS; kh = 0 waves write their taps: rows ci, cols co ----
   __syncthreads();
@@ -813,9 +763,7 @@ __global__ __launch_bounds__(512, NT == 2 ? 2 : 1) void conv5x5_wgrad(
     for (int j = 0; j < NT; ++j) red[(tw * RED_ROWS + 28 * NT + j) * 64 + lane] = bsum[j];
   }
   __syncthreads();
-#if DTF_TIMING
-  if (tb) tb[3] = wall_clock64();
-#endif
+  DTF_TIMING_ONLY(if (tb) tb[3] = wall_clock64();)
   if (kh == 1) return;
   float* slab = part + (size_t)blockIdx.x * (25 * C_IN * C_OUT + C_OUT);
 #pragma unroll
@@ -829,7 +777,7 @@ __global__ __launch_bounds__(512, NT == 2 ? 2 : 1) void conv5x5_wgrad(
           int ci = ci_t * 16 + 4 * g + r;
           int co = co_t * CO_W + j * 16 + i16;
           float v = acc[t][j][r] + red[(tw * RED_ROWS + (t * NT + j) * 4 + r) * 64 + lane];
-          if ((DTF_ABLATE & 512) && v != 12345.f) continue;
+          if (DTF_ABLATED(512) && v != 12345.f) continue;
           slab[((size_t)tap * C_IN + ci) * C_OUT + co] = v;
         }
     }
