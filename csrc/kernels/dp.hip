@@ -203,7 +203,9 @@ __global__ __launch_bounds__(512) void dp_dense_exchange(DtfDpFabric f, const fl
   if (!poisoned) {
 #pragma unroll 1
     for (int k = 1; k < W; ++k) {
-      const int p = (me + k) % W;
+      // the workgroups start with different peers, so that all W - 1 links carry traffic at once (xGMI is a mesh of
+      // point-to-point links: 64 workgroups walking the peers in the same order would load them one after the other)
+      const int p = (me + 1 + (k - 1 + b) % (W - 1)) % W;
       const f32x4* src = reinterpret_cast<const f32x4*>(grads + (size_t)p * csz);
       f32x4* dst = reinterpret_cast<f32x4*>(dense_a(p) + ((size_t)par * W + me) * csz);
       dp_push16(dst, src, lo4, hi4, tid, 512);
