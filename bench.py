@@ -306,7 +306,8 @@ def main():
                         fabric_graph_or_eager(trials)
                         info["step_ms_by_path"] = {k: round(v, 4) for k, v in trials.items() if v != float("inf")}
                         info.update(gradient_exchange="p2p fabric (csrc/kernels/dp.hip)",
-                                    dense="applied in the wgrad epilogue (one rank)" if (dp.collapse_world1 and args.optimizer == "sgd")
+                                    dense=("applied in the wgrad epilogue (one rank)" if args.optimizer == "sgd" else
+                                           "applied by the tail kernel's commit workgroups (one rank)") if dp.collapse_world1
                                     else "p2p reduce-scatter + sharded update + all-gather of the compute copy",
                                     tail="p2p one-shot exchange + commit in one launch")
             except Exception as e:      # collectives inside are unanimous (max over ranks), so every rank lands here together

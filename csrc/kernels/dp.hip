@@ -380,7 +380,11 @@ __global__ __launch_bounds__(256) void dp_tail_commit(FusedSgdArgs a, DtfDpFabri
     const int c = b - kDpTailBlocks, nC = nall - kDpTailBlocks;
     const long c4 = f.csz / 4, stride = (long)nC * 256;
     const size_t shard0 = (size_t)dense_off + (size_t)me * f.csz;
-    const f32x4* gp = reinterpret_cast<const f32x4*>(f.gsum);
+    // with_dense == 2 (a one-rank job, any optimizer): no dense exchange ran -- the "sum" is this rank's own gradient,
+    // still in the arena; these workgroups then also write the compute copy, and there is no verdict to wait for
+    const bool local = with_dense == 2;
+    const f32x4* gp = local ? reinterpret_cast<const f32x4*>(a.g + shard0) : reinterpret_cast<const f32x4*>(f.gsum);
+    bf16* cp = (local && a.shadow) ? a.shadow + shard0 : nullptr;
     f32x4* wp = reinterpret_cast<f32x4*>(a.w + shard0);
     f32x4* mp = ADAM ? reinterpret_cast<f32x4*>(a.m + shard0) : nullptr;
     f32x4* vp = ADAM ? reinterpret_cast<f32x4*>(a.v + shard0) : nullptr;
@@ -403,10 +407,11 @@ __global__ __launch_bounds__(256) void dp_tail_commit(FusedSgdArgs a, DtfDpFabri
     // ONE thread per commit workgroup polls ONE word (tail workgroup 0 publishes the launch-wide verdict there): 256
     // workgroups polling all 64 barrier words made 16 K spinning threads on one memory channel, which slowed the
     // exchange they were waiting for (64 us for this kernel, measured)
-    if (tid == 0) {
+    if (tid == 0 && !local) {
       __builtin_amdgcn_s_sleep(96);                // (~3 us) the verdict cannot be there before the exchange's round trips
       sh_verdict = dp_wait(done + kDpGoWord, seq, f.timeout_ticks, 16);
     }
+    if (tid == 0 && local) sh_verdict = f.ctl[0] != 0 ? 2 : 0;
     __syncthreads();
     if (!sh_verdict) {
       auto apply = [&](long i, f32x4 gs, f32x4 wv, f32x4 mv, f32x4 vv) {
@@ -419,6 +424,7 @@ __global__ __launch_bounds__(256) void dp_tail_commit(FusedSgdArgs a, DtfDpFabri
           for (int e = 0; e < 4; ++e) wv[e] = fmaf(-lr, gs[e], wv[e]);
         }
         wp[i] = wv;
+        if (cp) store_bf16x4(cp + 4 * i, wv[0], wv[1], wv[2], wv[3]);
       };
 #pragma unroll
       for (int u = 0; u < kPre; ++u)
@@ -505,7 +511,7 @@ __global__ __launch_bounds__(256) void dp_tail_commit(FusedSgdArgs a, DtfDpFabri
     if (tid == 0) f.seq_tail[b] = dp_next_seq(seq);
   };
   const bool poisoned = f.ctl[0] != 0;
-  if (W == 1 && !with_dense) {
+  if (W == 1 && with_dense != 1) {
     // a one-rank job has no peer to hear from and no wait that could time out: the sum is this rank's own vector
     if (!poisoned) {
       commit_slice(nullptr);
@@ -515,7 +521,7 @@ __global__ __launch_bounds__(256) void dp_tail_commit(FusedSgdArgs a, DtfDpFabri
     }
     return;
   }
-  const bool dense_ok = !with_dense || (unsigned)f.ctl[2] == seq;
+  const bool dense_ok = with_dense != 1 || (unsigned)f.ctl[2] == seq;
   const bool mine_ok = !poisoned && dense_ok;
   const bool mute = (unsigned)f.ctl[3] == seq;
   auto stage = [&](int r) { return reinterpret_cast<float*>(dp_area(f, r, f.off_tail_stage)); };
@@ -546,7 +552,7 @@ __global__ __launch_bounds__(256) void dp_tail_commit(FusedSgdArgs a, DtfDpFabri
   }
   __syncthreads();
   const int bad = dp_verdict(done, kDpTailBlocks, b, seq, sh_bad, f.timeout_ticks, &sh_verdict);
-  if (b == 0 && tid == 0 && with_dense) dp_store(done + kDpGoWord, seq | (bad ? kDpPoison : 0u));   // the commit workgroups' cue
+  if (b == 0 && tid == 0 && with_dense == 1) dp_store(done + kDpGoWord, seq | (bad ? kDpPoison : 0u));   // the commit workgroups' cue
   if (bad) {
     if (b == 0 && tid == 0) {
       f.ctl[0] = 1;

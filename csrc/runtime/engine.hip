@@ -506,7 +506,11 @@ int dtf_engine_dp_step(const DtfEngineDesc* e, const DtfDpFabric* f, int collaps
   DTF_TRY(forward_conv_impl(e, e->ds_images, nullptr, 1, e->B, s));
   DTF_TRY(dtf_engine_forward_dense(e, e->ds_labels, e->idx, 1, e->B, 1, s));
   DTF_TRY(fc1_dgrad(e, 1, s));              // the last reader of the old fc1 weights; + the head wgrad workgroups
+  // a one-rank job with collapse_world1: SGD applies the dense update in the wgrad epilogue; any other optimizer lets
+  // the commit workgroups of the tail kernel do it straight from the gradient arena (with_dense == 2).  Either way
+  // there is no dense exchange kernel, no branch and no event in the step.
   const bool collapsed = f->world == 1 && collapse_world1 && !adam;
+  const bool local_dense = f->world == 1 && collapse_world1 && adam;
   if (collapsed) {
     if (is_f32(e))
       DTF_TRY(dtf_gemm_f32_tn(e->p2, e->da, f32at(e->params, e->off_wd1), e->flat, e->hidden, e->B, e->flat, e->hidden,
@@ -514,6 +518,8 @@ int dtf_engine_dp_step(const DtfEngineDesc* e, const DtfDpFabric* f, int collaps
     else
       DTF_TRY(dtf_gemm_tn_sgd(e->p2, e->da, f32at(e->params, e->off_wd1), bf16at(e->shadow, e->off_wd1), e->hyper, e->flat,
                               e->hidden, e->B, e->flat, e->hidden, e->hidden, s));
+  } else if (local_dense) {
+    DTF_TRY(backward_dense_impl(e, -1, s));
   } else {
     // the hand-over event rides on the wgrad kernel itself where that is possible (eager launches: a recorded event
     // is a marker packet, a 5-7 us hole in the compute stream); under graph capture it is a plain dependency edge
@@ -532,8 +538,8 @@ int dtf_engine_dp_step(const DtfEngineDesc* e, const DtfDpFabric* f, int collaps
     if (comm != s) HIP_TRY(hipEventRecord(e->ev_dense_updated, comm));
   }
   DTF_TRY(backward_conv_impl(e, e->ds_images, e->idx, 0, 2, -1, s));
-  if (!collapsed && comm != s) HIP_TRY(hipStreamWaitEvent(s, e->ev_dense_updated, 0));
-  return dtf_dp_tail_commit(f, adam, collapsed ? 0 : 1, e->params, e->grads, e->adam_m, e->adam_v, shadow_of(e), e->hyper,
+  if (!collapsed && !local_dense && comm != s) HIP_TRY(hipStreamWaitEvent(s, e->ev_dense_updated, 0));
+  return dtf_dp_tail_commit(f, adam, collapsed ? 0 : (local_dense ? 2 : 1), e->params, e->grads, e->adam_m, e->adam_v, shadow_of(e), e->hyper,
                             e->wc2T, e->off_wc2, e->c1, e->c2, e->out_wT, e->off_out_w, e->hidden, e->state, 3, 4, e->B,
                             step_inc, 1, e->off_out_w, e->off_wd1, s);
 }

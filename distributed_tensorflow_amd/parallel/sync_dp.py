@@ -298,7 +298,7 @@ class SyncDataParallel:
             _pg.all_reduce_sum(ref, group=self.group)
             mine = ref[self.rank * per:(self.rank + 1) * per]
             tol = 1e-5 * W * float(mine.abs().max().item() + 1e-6)
-            if W > 1 or not (self.collapse_world1 and eng.optimizer == "sgd"):
+            if W > 1 or not self.collapse_world1:      # (a collapsed one-rank step runs no dense exchange)
                 ok = ok and bool((fab.gsum - mine).abs().max().item() <= tol)
             tails = [torch.empty(eng.layout.total - self.n_dense) for _ in range(W)]
             dist.all_gather(tails, eng.grads[self.n_dense:].cpu(), group=self.group)
