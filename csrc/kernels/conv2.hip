@@ -793,6 +793,317 @@ __global__ __launch_bounds__(512, NT == 2 ? 2 : 1) void conv5x5_wgrad(
   }
 }
 
+
+// ----------------------------------------------------------------------------
+// wgrad, producer / consumer form (the 32 -> 64 model's launch).  Same output tile (16 ci x 32 co x 25 taps), same
+// LDS images and fragment reads as conv5x5_wgrad<.., NT = 2>; what differs is who does what:
+//   * waves 8..11 are PRODUCERS (one per SIMD): they fetch the two images of round p+2 into registers, expand /
+//     write those of round p+1 into the other pair of LDS buffers and meet the MFMA waves at the barrier of the
+//     round.  Their VALU / LDS-write instructions issue beside the MFMAs of the SIMD's other two waves.  In
+//     conv5x5_wgrad the MFMA waves stage themselves, and the stamps (profiles/r1_conv2_fwd_timeline.txt) show
+//     3-8 us of staging + 2.6-4.4 us of barrier skew per wave on top of a 14-18 us k-loop.
+//   * a round is TWO images: MFMA wave (tw, kh) runs all seven row pairs of image 2p + kh for taps tw, tw+4, ...
+//     -- a straight-line, branch-free 98-MFMA body (the 4-or-3-step alternation of conv5x5_wgrad needs a branch
+//     with the accumulators live across it), half as many barriers, one fragment-latency bubble per 7 k-steps.
+//   * twelve waves leave 168 registers per lane: ONE rolling set of A fragments (tap t of the next k-step is
+//     fetched right behind the two MFMAs that consumed tap t of this one) and two sets of B fragments.
+//   * rounds are handed over through two LDS progress counters, not s_barrier: three pairs of image buffers, the
+//     producers run up to two rounds ahead, and an MFMA wave never waits for another MFMA wave (with a barrier per
+//     round every wave waited 0.8 us per round for the slowest of the eight: stamps of the barrier version).
+// LDS: 6 image buffers (146 KiB), one workgroup per CU.
+// ----------------------------------------------------------------------------
+constexpr int kPcBufBytes = kWgXTileBytes + wg_dy_tile_bytes(2);   // 24832
+constexpr int kPcPairs = 3;                                        // rounds in flight (pairs of image buffers)
+constexpr int kPcFlagOff = 2 * kPcPairs * kPcBufBytes;             // two progress counters behind the buffers
+constexpr int kPcLdsBytes = kPcFlagOff + 64;                       // 149056 of the CU's 163840
+static_assert(kPcFlagOff >= wg_red_bytes(2), "the end-of-kernel reduction aliases the image buffers");
+
+// Round hand-over without s_barrier: one progress word PER WAVE (a shared counter cannot tell two rounds of a fast
+// wave from one round of two waves) -- staged[pw] = rounds producer wave pw has written, done[w] = rounds MFMA wave w
+// has finished.  LDS operations of one wave execute in order, so the word's update (release) follows the wave's
+// writes / reads; a waiting wave polls all words of the other side with one read (lane l reads word l mod n) + s_sleep.
+// The spin is bounded: a wave that gives up computes garbage but the grid always drains.
+__device__ __forceinline__ void pc_signal(unsigned* word, unsigned rounds_done, int lane) {
+  if (lane == 0) __hip_atomic_store(word, rounds_done, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+__device__ __forceinline__ void pc_wait_all_ge(unsigned* words, int n_mask, unsigned target, int lane) {
+  for (int spin = 0; spin < (1 << 22); ++spin) {
+    const unsigned v = __hip_atomic_load(words + (lane & n_mask), __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP);
+    if (__builtin_amdgcn_ballot_w64(v < target) == 0ull) return;
+    __builtin_amdgcn_s_sleep(1);
+  }
+}
+
+template <int C_IN, int C_OUT>
+__global__ __launch_bounds__(768) void conv5x5_wgrad_pc(const bf16* __restrict__ x, const bf16* __restrict__ gpool,
+                                                        const uint8_t* __restrict__ arg, float* __restrict__ part, int B,
+                                                        int imgs_per_block) {
+  constexpr int NT = 2, CI_T = C_IN / 16, CO_W = 16 * NT, CO_CH = CO_W / 8, RED_ROWS = wg_red_rows(NT);
+  constexpr int kBufElems = kPcBufBytes / 2;
+  static_assert(C_OUT % CO_W == 0 && C_IN % 16 == 0, "tile shape");
+  typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
+  typedef __attribute__((ext_vector_type(8))) short s16x8;
+  extern __shared__ __attribute__((aligned(16))) char smem[];   // kPcLdsBytes
+  bf16* xt = reinterpret_cast<bf16*>(smem);                     // buffer i: xt + i * kBufElems  [328][16]
+  bf16* dyt = reinterpret_cast<bf16*>(smem + kWgXTileBytes);    //           dyt + i * kBufElems [7][32][CO_W]
+  unsigned* staged = reinterpret_cast<unsigned*>(smem + kPcFlagOff);   // [4]
+  unsigned* done = staged + 4;                                         // [8]
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const bool is_prod = wave >= 8;
+  const int tw = wave & 3, kh = (wave >> 2) & 1;
+  const int ci_t = blockIdx.y % CI_T, co_t = blockIdx.y / CI_T;
+  const int b_begin = blockIdx.x * imgs_per_block;
+  const int b_end = min(B, b_begin + imgs_per_block);
+  const int rounds = (b_end - b_begin + 1) >> 1;
+  auto dy_swz = [](int kk) { return (kk / (8 / NT)) & (NT - 1); };
+
+  // (timing build: 16 slots per workgroup, wave 0 -> 0..7, wave 8 -> 8..15: 0 start, 1 loop entered, 2 loop left,
+  //  3 reduced, 4 sum(wait for prefetched loads), 5 sum(k-loop), 6 sum(stage), 7 sum(barrier wait))
+  DTF_TIMING_ONLY(long long* tb = (g_timing_buf && (lane == 0) && (wave == 0 || wave == 8))
+                      ? g_timing_buf + ((size_t)(blockIdx.y * gridDim.x + blockIdx.x) * 16 + (wave ? 8 : 0)) : nullptr;)
+  DTF_LAPS(t_k = 0, t_s = 0, t_w = 0, t_v = 0);
+  DTF_TIMING_ONLY(if (tb) tb[0] = dtf_lap_prev_;)
+  // Zero what no round writes: the halo (and slack) positions of the six input tiles, the x = 14, 15 dummy k rows of the
+  // six gradient tiles, the progress words -- 36 KiB, not the whole 146 KiB.
+  auto zero_fill = [&]() {
+    const u32x4 z = {0u, 0u, 0u, 0u};
+    for (int c = tid; c < 2 * kPcPairs * 2 * kTilePos; c += 768) {
+      const int buf = c / (2 * kTilePos), rem = c - buf * (2 * kTilePos), pos = rem >> 1;
+      const int row = pos / kTileW, col = pos - row * kTileW;
+      if (!(row >= 2 && row < 16 && col >= 2 && col < 16)) *reinterpret_cast<u32x4*>(xt + buf * kBufElems + pos * 16 + (rem & 1) * 8) = z;
+    }
+    for (int c = tid; c < 2 * kPcPairs * 7 * 4 * CO_CH; c += 768) {
+      const int buf = c / (28 * CO_CH), rem = c - buf * (28 * CO_CH), rr = rem / CO_CH, ch = rem - rr * CO_CH;
+      const int kk = (rr >> 2) * 32 + 14 + (rr & 1) + 16 * ((rr >> 1) & 1);
+      *reinterpret_cast<u32x4*>(dyt + buf * kBufElems + kk * CO_W + ch * 8) = z;
+    }
+    if (tid < 4) reinterpret_cast<u32x4*>(staged)[tid] = z;
+  };
+
+  if (is_prod) {
+    // ---- producers: per round 2 x 392 input chunks (13 wave-rows of 64) and 2 x 196 gradient items (7 rows) ----
+    // A gradient item (8 pooled gradients + codes -> four 16-byte window positions) costs about five input chunks
+    // (a 16-byte copy): waves 8..10 take two gradient rows + three input rows each, wave 11 the last gradient row
+    // (8 items) + four input rows.  Everything that does not change from round to round -- the item's offset in
+    // its image, its LDS destination -- is worked out once, here: a lone wave per SIMD issues a dependent VALU
+    // instruction every 5-8 cycles beside two MFMA waves, and the first version of this loop (index arithmetic per
+    // item per round) took 2.3 us per round, longer than the 2.0 us of MFMA work it was meant to hide behind.
+    __builtin_amdgcn_s_setprio(3);   // win the SIMD's issue arbitration against its two MFMA waves
+    constexpr int X_ITEMS = 196 * 2, DY_ITEMS = 49 * CO_CH, XR = 4, DR = 2;
+    constexpr int kXImg = 196 * C_IN, kDyImg = 49 * C_OUT;   // elements per image
+    const int pw = wave - 8;
+    int xsrc[XR], xdst[XR], xim[XR], dsrc[DR], ddst[DR], dim_[DR];   // src: element offset in the image; dst: in the buffer pair
+#pragma unroll
+    for (int k = 0; k < XR; ++k) {
+      const int row = pw < 3 ? 3 * pw + k : 9 + k;
+      const int it = row * 64 + lane;
+      const bool ok = (pw == 3 || k < 3) && it < 2 * X_ITEMS;
+      const int im = it >= X_ITEMS, w = it - im * X_ITEMS, x_pos = w >> 1;
+      xim[k] = im;
+      xsrc[k] = ok ? x_pos * C_IN + ci_t * 16 + (w & 1) * 8 : -1;
+      xdst[k] = im * kBufElems + ((x_pos / 14 + 2) * kTileW + (x_pos % 14 + 2)) * 16 + (w & 1) * 8;
+    }
+#pragma unroll
+    for (int k = 0; k < DR; ++k) {
+      const int row = pw < 3 ? 2 * pw + k : 6;
+      const int it = row * 64 + lane;
+      const bool ok = (pw < 3 || k == 0) && it < 2 * DY_ITEMS;
+      const int im = it >= DY_ITEMS, w = it - im * DY_ITEMS;
+      const int d_c8 = w % CO_CH, d_pp = w / CO_CH, r = d_pp / 7, c = d_pp % 7;
+      const int slot = (((d_c8 >> 1) ^ dy_swz(2 * c)) << 1) | (d_c8 & 1);   // the same for the four window positions
+      dim_[k] = im;
+      dsrc[k] = ok ? d_pp * C_OUT + co_t * CO_W + d_c8 * 8 : -1;
+      ddst[k] = im * kBufElems + (r * 32 + 2 * c) * CO_W + slot * 8;
+    }
+    u32x4 xr[XR], gv_r[DR];
+    u32x2 ar_r[DR];
+    auto prefetch = [&](int p) {
+      const int b0 = b_begin + 2 * p;
+      const int second = (b0 + 1 < b_end) ? 1 : 0;   // odd image count: the last round re-reads its only image
+      const bf16* xg = x + (size_t)b0 * kXImg;
+      const bf16* gg = gpool + (size_t)b0 * kDyImg;
+      const uint8_t* ag = arg + (size_t)b0 * kDyImg;
+#pragma unroll
+      for (int k = 0; k < XR; ++k)
+        if (xsrc[k] >= 0 && !DTF_ABLATED(32)) xr[k] = *reinterpret_cast<const u32x4*>(xg + xsrc[k] + (xim[k] & second) * kXImg);
+#pragma unroll
+      for (int k = 0; k < DR; ++k)
+        if (dsrc[k] >= 0 && !DTF_ABLATED(128)) {
+          const int off = dsrc[k] + (dim_[k] & second) * kDyImg;
+          gv_r[k] = *reinterpret_cast<const u32x4*>(gg + off);
+          ar_r[k] = *reinterpret_cast<const u32x2*>(ag + off);
+        }
+    };
+    auto stage = [&](int p) {
+      bf16* xp = xt + (p % kPcPairs) * 2 * kBufElems;
+      bf16* dp = dyt + (p % kPcPairs) * 2 * kBufElems;
+#pragma unroll
+      for (int k = 0; k < XR; ++k)
+        if (xsrc[k] >= 0 && !DTF_ABLATED(32)) *reinterpret_cast<u32x4*>(xp + xdst[k]) = xr[k];
+#pragma unroll
+      for (int k = 0; k < DR; ++k)
+        if (dsrc[k] >= 0 && !DTF_ABLATED(128)) {
+          u32x4 o[4];
+          expand_pool_grad(gv_r[k], ar_r[k], o);
+#pragma unroll
+          for (int q = 0; q < 4; ++q)   // k row (q >> 1) * 16 + 2c + (q & 1): same swizzle slot (see dy_swz)
+            *reinterpret_cast<u32x4*>(dp + ddst[k] + ((q >> 1) * 16 + (q & 1)) * CO_W) = o[q];
+        }
+    };
+    if (rounds > 0) prefetch(0);   // in flight under the zero fill
+    zero_fill();
+    __syncthreads();   // zero fill done
+    DTF_TIMING_ONLY(if (tb) tb[1] = wall_clock64();)
+    for (int q = 0; q < rounds; ++q) {
+      // pair q % 3 was last read in round q - 3
+      DTF_LAP_START();
+      if (q >= kPcPairs) pc_wait_all_ge(done, 7, (unsigned)(q - kPcPairs + 1), lane);
+      DTF_LAP(t_w);
+      DTF_LAP_AFTER("s_waitcnt vmcnt(0)", t_v);
+      stage(q);
+      if (q + 1 < rounds) prefetch(q + 1);
+      pc_signal(staged + pw, (unsigned)(q + 1), lane);
+      DTF_LAP_AFTER("s_waitcnt lgkmcnt(0)", t_s);
+    }
+    DTF_TIMING_ONLY(if (tb) { tb[2] = wall_clock64(); tb[5] = t_k; tb[6] = t_s; tb[7] = t_w; tb[4] = t_v; })
+    __syncthreads();
+    __syncthreads();
+    DTF_TIMING_ONLY(if (tb) tb[3] = wall_clock64();)
+    return;
+  }
+
+  // ---- MFMA waves ----
+  const int g = lane >> 4, i16 = lane & 15;
+  const int qr = i16 >> 2, pc = i16 & 3;
+  // Bias gradient = column sums of the gradient tile = ones x dY: tap group 1's seventh tap slot does not exist (it is
+  // clamped, computed and discarded in groups 1..3), so in the ci_t == 0 workgroups that slot multiplies an all-ones
+  // A fragment instead -- every row of acc[6][j] is then the bias sum, for free (the VALU sum of the B fragments
+  // it replaces cost the tap-0 waves 32 instructions per k-step and made them the last to finish).
+  const bool do_bias = (ci_t == 0) && (tw == 1);
+  f32x4 acc[7][NT];
+#pragma unroll
+  for (int t = 0; t < 7; ++t)
+#pragma unroll
+    for (int j = 0; j < NT; ++j) acc[t][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  zero_fill();
+  const int tr_pos = (g >> 1) * kTileW + 4 * (g & 1) + qr;   // A: row pair 0, tap (0,0), first read
+  const int kkrow = (g >> 1) * 16 + 4 * (g & 1) + qr;        // B: k row of the first read
+  const int bsw = dy_swz(kkrow);
+  int tap_off[7];   // taps tw + 4t; the 7th of groups 1..3 is clamped to tap 24, computed and discarded
+#pragma unroll
+  for (int t = 0; t < 7; ++t) {
+    const int tap = min(tw + 4 * t, 24);
+    tap_off[t] = ((tap / 5) * kTileW + tap % 5) * 16;
+  }
+  const bf16* a_lane = xt + tr_pos * 16 + pc * 4;
+  const bf16* b_lane = dyt + kkrow * CO_W + pc * 4;
+
+  __syncthreads();   // zero fill done
+  DTF_TIMING_ONLY(if (tb) tb[1] = wall_clock64();)
+  DTF_TIMING_ONLY(t_v = clock64();)   // MFMA wave: slots 4 / 6 = shader-clock cycles at loop entry / exit
+  for (int p = 0; p < rounds; ++p) {
+    DTF_LAP(t_k);
+    pc_wait_all_ge(staged, 3, (unsigned)(p + 1), lane);
+    DTF_LAP(t_w);
+    if (b_begin + 2 * p + kh >= b_end || DTF_ABLATED(256)) {   // odd image count: the kh = 1 waves sit out the last round
+      pc_signal(done + wave, (unsigned)(p + 1), lane);
+      continue;
+    }
+    const int boff = ((p % kPcPairs) * 2 + kh) * kBufElems;
+    const bf16* a_img = a_lane + boff;
+    const bf16* b_img = b_lane + boff;
+    bf16x8 af[7], bq[2][NT];
+    auto load_b = [&](int r, bf16x8 (&bf)[NT]) {
+#pragma unroll
+      for (int j = 0; j < NT; ++j) {
+        const bf16* p0 = b_img + r * 32 * CO_W + ((j ^ bsw) << 4);
+        s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)p0);
+        s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(p0 + 8 * CO_W));
+        s16x8 v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+        bf[j] = __builtin_bit_cast(bf16x8, v);
+      }
+    };
+    auto load_a = [&](int r, int t) {
+      const bf16* p0 = a_img + 2 * r * kTileW * 16 + tap_off[t];
+      s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)p0);
+      s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(p0 + 8 * 16));
+      s16x8 av = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+      af[t] = __builtin_bit_cast(bf16x8, av);
+    };
+    load_b(0, bq[0]);
+#pragma unroll
+    for (int t = 0; t < 7; ++t) load_a(0, t);
+    load_b(1, bq[1]);
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int r = 0; r < 7; ++r) {
+      bf16x8(&bf)[NT] = bq[r & 1];
+#pragma unroll
+      for (int t = 0; t < 7; ++t) {
+        if DTF_ABLATED(64) {
+          asm volatile("" ::"v"(af[t]), "v"(bf[0]), "v"(bf[1]));
+        } else {
+          bf16x8 a = af[t];
+          if (t == 6) {   // wave-uniform select, four v_cndmask
+            const u32x4 ld = __builtin_bit_cast(u32x4, a);
+            const unsigned one2 = 0x3F803F80u;   // bf16 (1.0, 1.0)
+            const u32x4 sel = {do_bias ? one2 : ld[0], do_bias ? one2 : ld[1], do_bias ? one2 : ld[2], do_bias ? one2 : ld[3]};
+            a = __builtin_bit_cast(bf16x8, sel);
+          }
+#pragma unroll
+          for (int j = 0; j < NT; ++j) acc[t][j] = mfma16(a, bf[j], acc[t][j]);
+        }
+        if (r + 1 < 7 && !DTF_ABLATED(1024)) load_a(r + 1, t);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      if (r + 2 < 7 && !DTF_ABLATED(1024)) {
+        load_b(r + 2, bq[r & 1]);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    }
+    pc_signal(done + wave, (unsigned)(p + 1), lane);   // every fragment read of the round has been waited for by the MFMA that used it
+  }
+
+  // ---- sum the two kh halves through LDS; kh = 0 waves write their taps: rows ci, cols co ----
+  DTF_LAP_AFTER("s_nop 0", t_k);
+  DTF_TIMING_ONLY(t_s = clock64();)
+  DTF_TIMING_ONLY(if (tb) { tb[2] = wall_clock64(); tb[5] = t_k; tb[6] = t_s; tb[7] = t_w; tb[4] = t_v; })
+  __syncthreads();
+  float* red = reinterpret_cast<float*>(smem);  // [tw][RED_ROWS][64 lanes]
+  if (kh == 1) {
+#pragma unroll
+    for (int t = 0; t < 7; ++t)
+#pragma unroll
+      for (int j = 0; j < NT; ++j)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) red[(tw * RED_ROWS + (t * NT + j) * 4 + r) * 64 + lane] = acc[t][j][r];
+  }
+  __syncthreads();
+  DTF_TIMING_ONLY(if (tb) tb[3] = wall_clock64();)
+  if (kh == 1) return;
+  float* slab = part + (size_t)blockIdx.x * (25 * C_IN * C_OUT + C_OUT);
+#pragma unroll
+  for (int t = 0; t < 7; ++t) {
+    const int tap = tw + 4 * t;
+    if (tap < 25) {
+#pragma unroll
+      for (int j = 0; j < NT; ++j)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          int ci = ci_t * 16 + 4 * g + r;
+          int co = co_t * CO_W + j * 16 + i16;
+          slab[((size_t)tap * C_IN + ci) * C_OUT + co] = acc[t][j][r] + red[(tw * RED_ROWS + (t * NT + j) * 4 + r) * 64 + lane];
+        }
+    }
+  }
+  if (do_bias && g == 0) {   // row 0 of the ones product: lanes 0..15, element 0
+#pragma unroll
+    for (int j = 0; j < NT; ++j)
+      slab[25 * C_IN * C_OUT + co_t * CO_W + j * 16 + i16] = acc[6][j][0] + red[(tw * RED_ROWS + (6 * NT + j) * 4) * 64 + lane];
+  }
+}
+
 }  // namespace dtf
 
 // ---------------------------------------------------------------------------
@@ -845,6 +1156,20 @@ static int launch_wgrad(const void* x, const void* gpool, const void* arg, void*
   }
   const int ipb = (B + G - 1) / G;
   hipLaunchKernelGGL(kern, dim3(G, (C_IN / 16) * (C_OUT / (16 * NT))), dim3(512), lds, s, (const bf16*)x, (const bf16*)gpool,
+                     (const uint8_t*)arg, (float*)part, B, ipb);
+  return DTF_LAUNCH_CHECK();
+}
+
+template <int C_IN, int C_OUT>
+static int launch_wgrad_pc(const void* x, const void* gpool, const void* arg, void* part, int B, int G, hipStream_t s) {
+  auto kern = conv5x5_wgrad_pc<C_IN, C_OUT>;
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, kPcLdsBytes);
+    attr_set = true;
+  }
+  const int ipb = (B + G - 1) / G;
+  hipLaunchKernelGGL(kern, dim3(G, (C_IN / 16) * (C_OUT / 32)), dim3(768), kPcLdsBytes, s, (const bf16*)x, (const bf16*)gpool,
                      (const uint8_t*)arg, (float*)part, B, ipb);
   return DTF_LAUNCH_CHECK();
 }
@@ -926,18 +1251,23 @@ int dtf_conv2_dgrad_conv1_wgrad(const void* gpool, const void* arg2, const void*
 // engine.py reads the same variable to size the conv1 slabs)
 int dtf_conv2_small_batch(void) { return conv2_small_batch(); }
 
-// wgrad partial slabs: part [G][25*cin*cout + cout].  nt = 16-wide co tiles per wave (2 or 4; see conv5x5_wgrad);
-// 0 picks 4 for the widened model (32 output tiles x G) and 2 for the 32/64 model, DTF_C2W_NT overrides (tools).
+// wgrad partial slabs: part [G][25*cin*cout + cout].  nt = 16-wide co tiles per wave of conv5x5_wgrad (2 or 4);
+// 0 = the default launch: the producer / consumer kernel for the 32/64 model (DTF_C2W_PC=0: conv5x5_wgrad<2>),
+// conv5x5_wgrad<4> for the widened one (32 output tiles x G); DTF_C2W_NT=2|4 forces conv5x5_wgrad (tools).
 int dtf_conv2_wgrad_nt(const void* x, const void* gpool, const void* arg, void* part, int B, int cin, int cout, int G,
                        int nt, hipStream_t s) {
   if (G <= 0 || B <= 0) return -2;
   if (nt == 0) {
-    static int forced = -1;
+    static int forced = -1, pc = -1;
     if (forced < 0) {
       const char* v = getenv("DTF_C2W_NT");
       forced = v ? atoi(v) : 0;
+      v = getenv("DTF_C2W_PC");
+      pc = (v && *v) ? atoi(v) : 1;
     }
-    nt = (forced == 2 || forced == 4) ? forced : (cin >= 128 ? 4 : 2);
+    if (forced == 2 || forced == 4) nt = forced;
+    else if (cin == 32 && cout == 64 && pc) return launch_wgrad_pc<32, 64>(x, gpool, arg, part, B, G, s);
+    else nt = cin >= 128 ? 4 : 2;
   }
   if (nt != 2 && nt != 4) return -3;
   if (cin == 32 && cout == 64)

@@ -5,7 +5,8 @@
 //   DTF_ABLATED(bits)      timing ablations (tools/conv_ablate.py, -DDTF_ABLATE=<bits>): igemm 1 = no B global loads in
 //                          the k-loop, 2 = no A LDS reads, 4 = no MFMAs, 8 = no staging loads, 16 = no epilogue stores;
 //                          wgrad 32 = no x staging, 64 = no MFMAs, 128 = no dY staging/expansion, 256 = no k-loop,
-//                          512 = no slab write
+//                          512 = no slab write; conv5x5_wgrad_pc also 1024 = no fragment reads behind the MFMAs (the
+//                          first k-step's fragments are multiplied seven times)
 //   DTF_STAGGER_HERE()     delay part of the grid by DTF_STAGGER us at kernel start (tools/conv_ablate.py stagger)
 //   DTF_STAMP / DTF_PUT / DTF_LAP...   in-kernel wall-clock stamps and per-phase time sums (-DDTF_TIMING=1,
 //                          tools/conv_timeline.py): thread 0 (or the lanes named at the call site) of a workgroup writes

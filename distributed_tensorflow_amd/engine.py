@@ -221,10 +221,11 @@ class HipEngine:
         # Wave tile of the bf16 kernel: 16 ci x 64 co (4 co tiles per wave: -39 % LDS fragment bytes per MFMA, half as
         # many output tiles) for the widened model and, with twice the image chunks, for the 32/64 model from 4096
         # images per GPU (-2 %; a wash at 1024, where the doubled slab traffic eats the gain)
-        self.c2_nt = 4 if (C1 >= 128 or B >= 4096) else 2
+        # 0 = the library's default launch for 16 ci x 32 co tiles: the producer / consumer kernel (conv5x5_wgrad_pc)
+        self.c2_nt = 4 if (C1 >= 128 or B >= 4096) else 0
         if tun.c2w_nt:                                          # A/B switch for tools
             self.c2_nt = tun.c2w_nt
-        c2_tiles = (C1 // 16) * (C2 // (16 * self.c2_nt))
+        c2_tiles = (C1 // 16) * (C2 // (16 * (self.c2_nt or 2)))
         default_g = 8 if C1 >= 128 else (64 if c2_tiles >= 4 else 128)
         self.c2_g = max(1, min((B + 1) // 2, tun.c2_g or default_g))
         if dtype == "fp32":

@@ -8,6 +8,8 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 OUT = os.path.join(ROOT, "diag_build")
 WG = {0: "full", 32: "no x staging", 128: "no dY staging", 160: "no staging at all", 64: "no MFMA",
       256: "no k-loop", 416: "syncs+slab write only", 512: "no slab write", 928: "empty"}
+WG_PC = {0: "full", 64: "no MFMA", 1024: "no fragment reads in the k-loop", 1088: "no MFMA, no fragment reads", 160: "no staging at all",
+         256: "no k-loop", 1184: "k-loop MFMAs only (no staging, no reads)"}
 IG = {0: "full", 1: "no B global loads", 2: "no A LDS reads", 4: "no MFMA", 8: "no staging loads", 16: "no epilogue stores",
       7: "no k-loop work", 23: "staging only", 31: "shell only"}
 CFGS = {"fwd": ["32,32,64,1,2,MODE_FWD,4", "32,32,64,2,1,MODE_FWD,2", "32,32,64,1,1,MODE_FWD,2", "32,32,64,4,1,MODE_FWD,2",
@@ -31,6 +33,13 @@ elif sys.argv[1] == "buildstagger":
                                f"-DDTF_STAGGER={d}", f"-DDTF_STAGGER_MODE={mode}", "-DDTF_DIAG=1", "-I", ROOT + "/csrc/kernels", ROOT + "/csrc/kernels/conv2.hip",
                                "-o", f"{OUT}/conv2_st{d}.so"])
     print("built stagger")
+elif sys.argv[1] == "buildpc":
+    os.makedirs(OUT, exist_ok=True)
+    for v in sorted(WG_PC):
+        subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",
+                               f"-DDTF_ABLATE={v}", "-DDTF_DIAG=1", "-I", ROOT + "/csrc/kernels", ROOT + "/csrc/kernels/conv2.hip",
+                               "-o", f"{OUT}/conv2_ab{v}.so"])
+    print("built", len(WG_PC))
 elif sys.argv[1] == "build":
     os.makedirs(OUT, exist_ok=True)
     for v in sorted(set(WG) | set(IG)):
@@ -62,7 +71,8 @@ else:
         which = which[3:]
         items = {i: c for i, c in enumerate(CFGS[which])}
     else:
-        items = WG if which == "wgrad" else IG
+        items = WG_PC if which == "wgrad_pc" else WG if which == "wgrad" else IG
+        which = "wgrad" if which == "wgrad_pc" else which
     for v, name in items.items():
         lib = ctypes.CDLL(f"{OUT}/conv2_st{v}.so" if stg else f"{OUT}/conv2_{which}{v}.so" if cfg else f"{OUT}/conv2_ab{v}.so")
         if which == "wgrad":

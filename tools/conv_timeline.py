@@ -151,12 +151,20 @@ else:
         call(); torch.cuda.synchronize()
         t = buf2.cpu().double().reshape(G * 4, 2, 8)
         t0 = t[:, 0, 0].min()
-        for wv, name in ((0, "wave 0 (stages x + dY)"), (1, "wave 7 (stages x only)")):
+        pc = os.environ.get("DTF_C2W_PC", "1") != "0"
+        for wv, name in ((0, "wave 0 (MFMA wave)"), (1, "wave 8 (producer)")) if pc else ((0, "wave 0 (stages x + dY)"), (1, "wave 7 (stages x only)")):
             a = t[:, wv, :]
             print(f"wgrad B={B} {name}: {G * 4} workgroups, {B // G} images each")
             for i, n in enumerate(["start", "loop entered", "loop left", "reduced"]):
                 c = (a[:, i] - t0) * 10.0
                 print(f"  {n:14s} min {c.min() / 1e3:6.2f}  median {c.median() / 1e3:6.2f}  max {c.max() / 1e3:6.2f} us")
+            if pc and wv == 0:     # slots 4 / 6 of the MFMA wave: shader-clock cycles at loop entry / exit
+                mhz = (a[:, 6] - a[:, 4]) / ((a[:, 2] - a[:, 1]) * 10.0) * 1e3
+                print(f"  shader clock over the loop: median {mhz.median():.0f} MHz (min {mhz.min():.0f}, max {mhz.max():.0f})")
+                for i, n in ((5, "sum k-loop"), (7, "sum barrier wait")):
+                    c = a[:, i] * 10.0
+                    print(f"  {n:26s} median {c.median() / 1e3:6.2f}  max {c.max() / 1e3:6.2f} us")
+                continue
             for i, n in ((5, "sum k-loop"), (4, "sum wait for prefetch"), (6, "sum stage+prefetch issue"), (7, "sum barrier wait")):
                 c = a[:, i] * 10.0
                 print(f"  {n:26s} median {c.median() / 1e3:6.2f}  max {c.max() / 1e3:6.2f} us")
