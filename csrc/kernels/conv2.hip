@@ -25,6 +25,7 @@
 //   memory.  Split-K over images across workgroups; partial slabs are summed by
 //   reduce_segments (optim.hip).
 #include "conv1_core.hpp"
+#include <type_traits>
 #include "conv2_diag.hpp"   // DTF_ABLATED / DTF_STAMP / DTF_LAP... : empty in the shipped library
 
 // Tile configuration of the 32->64 layer: KTOT, KC, NC, IMGS, NW, MODE, min waves/SIMD
@@ -860,25 +861,28 @@ __global__ __launch_bounds__(768) void conv5x5_wgrad_pc(const bf16* __restrict__
 
   // (timing build: 16 slots per workgroup, wave 0 -> 0..7, wave 8 -> 8..15: 0 start, 1 loop entered, 2 loop left,
   //  3 reduced, 4 sum(wait for prefetched loads), 5 sum(k-loop), 6 sum(stage), 7 sum(barrier wait))
-  DTF_TIMING_ONLY(long long* tb = (g_timing_buf && (lane == 0) && (wave == 0 || wave == 8))
-                      ? g_timing_buf + ((size_t)(blockIdx.y * gridDim.x + blockIdx.x) * 16 + (wave ? 8 : 0)) : nullptr;)
+  //  32 slots per workgroup here: 16 + w = when MFMA wave w left its loop, 24 + w = its summed wait)
+  DTF_TIMING_ONLY(long long* tb_wg = g_timing_buf ? g_timing_buf + (size_t)(blockIdx.y * gridDim.x + blockIdx.x) * 32 : nullptr;)
+  DTF_TIMING_ONLY(long long* tb = (tb_wg && (lane == 0) && (wave == 0 || wave == 8)) ? tb_wg + (wave ? 8 : 0) : nullptr;)
   DTF_LAPS(t_k = 0, t_s = 0, t_w = 0, t_v = 0);
   DTF_TIMING_ONLY(if (tb) tb[0] = dtf_lap_prev_;)
   // Zero what no round writes: the halo (and slack) positions of the six input tiles, the x = 14, 15 dummy k rows of the
-  // six gradient tiles, the progress words -- 36 KiB, not the whole 146 KiB.
+  // six gradient tiles, the `done` words -- 36 KiB, not the whole 146 KiB.  The MFMA waves do it (512 threads) while
+  // the producers already stage round 0: the two touch disjoint bytes, and `staged` needs no zero (it is stored, not
+  // added to, and first read after the barrier that follows the producers' first store).
   auto zero_fill = [&]() {
     const u32x4 z = {0u, 0u, 0u, 0u};
-    for (int c = tid; c < 2 * kPcPairs * 2 * kTilePos; c += 768) {
+    for (int c = tid; c < 2 * kPcPairs * 2 * kTilePos; c += 512) {
       const int buf = c / (2 * kTilePos), rem = c - buf * (2 * kTilePos), pos = rem >> 1;
       const int row = pos / kTileW, col = pos - row * kTileW;
       if (!(row >= 2 && row < 16 && col >= 2 && col < 16)) *reinterpret_cast<u32x4*>(xt + buf * kBufElems + pos * 16 + (rem & 1) * 8) = z;
     }
-    for (int c = tid; c < 2 * kPcPairs * 7 * 4 * CO_CH; c += 768) {
+    for (int c = tid; c < 2 * kPcPairs * 7 * 4 * CO_CH; c += 512) {
       const int buf = c / (28 * CO_CH), rem = c - buf * (28 * CO_CH), rr = rem / CO_CH, ch = rem - rr * CO_CH;
       const int kk = (rr >> 2) * 32 + 14 + (rr & 1) + 16 * ((rr >> 1) & 1);
       *reinterpret_cast<u32x4*>(dyt + buf * kBufElems + kk * CO_W + ch * 8) = z;
     }
-    if (tid < 4) reinterpret_cast<u32x4*>(staged)[tid] = z;
+    if (tid < 8) done[tid] = 0u;
   };
 
   if (is_prod) {
@@ -951,11 +955,15 @@ __global__ __launch_bounds__(768) void conv5x5_wgrad_pc(const bf16* __restrict__
             *reinterpret_cast<u32x4*>(dp + ddst[k] + ((q >> 1) * 16 + (q & 1)) * CO_W) = o[q];
         }
     };
-    if (rounds > 0) prefetch(0);   // in flight under the zero fill
-    zero_fill();
-    __syncthreads();   // zero fill done
+    if (rounds > 0) {
+      prefetch(0);
+      stage(0);
+      if (rounds > 1) prefetch(1);
+    }
+    pc_signal(staged + pw, 1u, lane);
+    __syncthreads();   // the MFMA waves' zero fill is done; they find round 0 staged
     DTF_TIMING_ONLY(if (tb) tb[1] = wall_clock64();)
-    for (int q = 0; q < rounds; ++q) {
+    for (int q = 1; q < rounds; ++q) {
       // pair q % 3 was last read in round q - 3
       DTF_LAP_START();
       if (q >= kPcPairs) pc_wait_all_ge(done, 7, (unsigned)(q - kPcPairs + 1), lane);
@@ -1002,43 +1010,56 @@ __global__ __launch_bounds__(768) void conv5x5_wgrad_pc(const bf16* __restrict__
   __syncthreads();   // zero fill done
   DTF_TIMING_ONLY(if (tb) tb[1] = wall_clock64();)
   DTF_TIMING_ONLY(t_v = clock64();)   // MFMA wave: slots 4 / 6 = shader-clock cycles at loop entry / exit
-  for (int p = 0; p < rounds; ++p) {
-    DTF_LAP(t_k);
-    pc_wait_all_ge(staged, 3, (unsigned)(p + 1), lane);
-    DTF_LAP(t_w);
-    if (b_begin + 2 * p + kh >= b_end || DTF_ABLATED(256)) {   // odd image count: the kh = 1 waves sit out the last round
-      pc_signal(done + wave, (unsigned)(p + 1), lane);
-      continue;
+  // The k-loop is ONE software pipeline over all rounds: the fragments of the next round's first k-step roll in behind
+  // the MFMAs of this round's last one (A) and last two (B), so a round boundary costs no fragment-latency bubble and
+  // no exposed poll -- the progress words of round p + 1 are read during k-step 3 of round p and looked at after
+  // k-step 4.  Seven k-steps per round flip the parity of the two B sets, hence the body instantiated for both.
+  // The last round prefetches from its own buffers (never used): every round issues the same instruction stream and
+  // the compiler's wait counts stay exact.
+  bf16x8 af[7], bq[2][NT];
+  auto load_b = [&](const bf16* b_img, int r, bf16x8 (&bf)[NT]) {
+#pragma unroll
+    for (int j = 0; j < NT; ++j) {
+      const bf16* p0 = b_img + r * 32 * CO_W + ((j ^ bsw) << 4);
+      s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)p0);
+      s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(p0 + 8 * CO_W));
+      s16x8 v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+      bf[j] = __builtin_bit_cast(bf16x8, v);
     }
-    const int boff = ((p % kPcPairs) * 2 + kh) * kBufElems;
+  };
+  auto load_a = [&](const bf16* a_img, int r, int t) {
+    const bf16* p0 = a_img + 2 * r * kTileW * 16 + tap_off[t];
+    s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)p0);
+    s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(p0 + 8 * 16));
+    s16x8 av = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+    af[t] = __builtin_bit_cast(bf16x8, av);
+  };
+  int pair = 0;   // p % kPcPairs
+  auto round_body = [&](auto par_c, int p) {
+    constexpr int PAR = decltype(par_c)::value;
+    // the two MFMA waves of a SIMD take turns at being preferred by its issue arbiter (oldest first otherwise: the
+    // kh = 1 waves then fall 0.25 us behind per round and the whole workgroup waits for them at the end)
+    if ((PAR ^ kh) & 1) __builtin_amdgcn_s_setprio(1); else __builtin_amdgcn_s_setprio(0);
+    const bool has_next = p + 1 < rounds;
+    const int npair = pair + 1 == kPcPairs ? 0 : pair + 1;
+    const int boff = (pair * 2 + kh) * kBufElems;
+    const int noff = ((has_next ? npair : pair) * 2 + kh) * kBufElems;
     const bf16* a_img = a_lane + boff;
     const bf16* b_img = b_lane + boff;
-    bf16x8 af[7], bq[2][NT];
-    auto load_b = [&](int r, bf16x8 (&bf)[NT]) {
-#pragma unroll
-      for (int j = 0; j < NT; ++j) {
-        const bf16* p0 = b_img + r * 32 * CO_W + ((j ^ bsw) << 4);
-        s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)p0);
-        s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(p0 + 8 * CO_W));
-        s16x8 v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
-        bf[j] = __builtin_bit_cast(bf16x8, v);
-      }
-    };
-    auto load_a = [&](int r, int t) {
-      const bf16* p0 = a_img + 2 * r * kTileW * 16 + tap_off[t];
-      s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)p0);
-      s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(p0 + 8 * 16));
-      s16x8 av = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
-      af[t] = __builtin_bit_cast(bf16x8, av);
-    };
-    load_b(0, bq[0]);
-#pragma unroll
-    for (int t = 0; t < 7; ++t) load_a(0, t);
-    load_b(1, bq[1]);
-    __builtin_amdgcn_sched_barrier(0);
+    const bf16* a_nxt = a_lane + noff;
+    const bf16* b_nxt = b_lane + noff;
+    const unsigned need = (unsigned)(has_next ? p + 2 : p + 1);
+    unsigned seen = 0;
 #pragma unroll
     for (int r = 0; r < 7; ++r) {
-      bf16x8(&bf)[NT] = bq[r & 1];
+      bf16x8(&bf)[NT] = bq[(r + PAR) & 1];
+      if (r == 5) {   // before the first read of the next round's buffers
+        if (__builtin_amdgcn_ballot_w64(seen < need) != 0ull) {
+          DTF_LAP(t_k);
+          pc_wait_all_ge(staged, 3, need, lane);
+          DTF_LAP(t_w);
+        }
+      }
 #pragma unroll
       for (int t = 0; t < 7; ++t) {
         if DTF_ABLATED(64) {
@@ -1054,21 +1075,48 @@ __global__ __launch_bounds__(768) void conv5x5_wgrad_pc(const bf16* __restrict__
 #pragma unroll
           for (int j = 0; j < NT; ++j) acc[t][j] = mfma16(a, bf[j], acc[t][j]);
         }
-        if (r + 1 < 7 && !DTF_ABLATED(1024)) load_a(r + 1, t);
+        if (!DTF_ABLATED(1024)) {
+          if (r + 1 < 7) load_a(a_img, r + 1, t);
+          else load_a(a_nxt, 0, t);
+        }
         __builtin_amdgcn_sched_barrier(0);
       }
-      if (r + 2 < 7 && !DTF_ABLATED(1024)) {
-        load_b(r + 2, bq[r & 1]);
+      if (!DTF_ABLATED(1024)) {
+        if (r + 2 < 7) load_b(b_img, r + 2, bf);
+        else load_b(b_nxt, r + 2 - 7, bf);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      if (r == 3) {
+        seen = __hip_atomic_load(staged + (lane & 3), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         __builtin_amdgcn_sched_barrier(0);
       }
     }
-    pc_signal(done + wave, (unsigned)(p + 1), lane);   // every fragment read of the round has been waited for by the MFMA that used it
+    pc_signal(done + wave, (unsigned)(p + 1), lane);   // every read of this round's buffers has been waited for by its MFMA
+    pair = npair;
+  };
+  if (rounds > 0 && !DTF_ABLATED(256)) {
+    pc_wait_all_ge(staged, 3, 1u, lane);
+    DTF_LAP(t_w);
+    const int boff = kh * kBufElems;
+    load_b(b_lane + boff, 0, bq[0]);
+#pragma unroll
+    for (int t = 0; t < 7; ++t) load_a(a_lane + boff, 0, t);
+    load_b(b_lane + boff, 1, bq[1]);
+    __builtin_amdgcn_sched_barrier(0);
+    // an odd image count leaves the kh = 1 waves without an image in the last round: they stop before it (the
+    // producers never wait for a round's `done` words after the last three rounds)
+    const int my_rounds = (b_end - b_begin - kh + 1) >> 1;
+    for (int p = 0; p < my_rounds; p += 2) {
+      round_body(std::integral_constant<int, 0>{}, p);
+      if (p + 1 < my_rounds) round_body(std::integral_constant<int, 1>{}, p + 1);
+    }
   }
 
   // ---- sum the two kh halves through LDS; kh = 0 waves write their taps: rows ci, cols co ----
   DTF_LAP_AFTER("s_nop 0", t_k);
   DTF_TIMING_ONLY(t_s = clock64();)
   DTF_TIMING_ONLY(if (tb) { tb[2] = wall_clock64(); tb[5] = t_k; tb[6] = t_s; tb[7] = t_w; tb[4] = t_v; })
+  DTF_TIMING_ONLY(if (tb_wg && lane == 0) { tb_wg[16 + wave] = wall_clock64(); tb_wg[24 + wave] = t_w; })
   __syncthreads();
   float* red = reinterpret_cast<float*>(smem);  // [tw][RED_ROWS][64 lanes]
   if (kh == 1) {

@@ -290,6 +290,29 @@ def test_conv2_backward(gpu_lib, B, C1, C2):
     assert torch.equal(results[1], results[2])
 
 
+@pytest.mark.parametrize("B,G", [(7, 1), (37, 2), (64, 5), (33, 33), (96, 3)])
+def test_conv2_wgrad_producer_consumer_kernel_matches_the_self_staging_one(gpu_lib, B, G):
+    """conv5x5_wgrad_pc (the default launch of the 32/64 model: producer waves, two-image rounds handed over through
+    LDS progress words, three buffer pairs) against conv5x5_wgrad<2>: odd image counts per workgroup (the kh = 1 waves
+    sit out the last round), more rounds than buffer pairs (reuse behind the `done` words), one image per workgroup.
+    The two kernels sum the same bf16 products in a different order, fp32 accumulators."""
+    g, x, w, b = _conv2_inputs(B, 32, 64, 11)
+    gp = bf(torch.randn(B, 7, 7, 64, generator=g)).to(DEV)
+    arg = torch.randint(0, 5, (B, 7, 7, 64), generator=g, dtype=torch.uint8).to(DEV)
+    stride = 25 * 32 * 64 + 64
+    out = []
+    for nt in (0, 2):
+        part = torch.full((G, stride), float("nan"), device=DEV)
+        for _ in range(3):     # repeated launches: a stale progress word or buffer would show
+            check(gpu_lib.dtf_conv2_wgrad_nt(ptr(x), ptr(gp), ptr(arg), ptr(part), B, 32, 64, G, nt, stream()), f"wgrad nt={nt}")
+        got = part[:min(G, B)].sum(0)
+        assert bool(torch.isfinite(got).all())
+        out.append(got)
+    assert rel_err(out[0][:-64], out[1][:-64]) < 2e-6
+    assert rel_err(out[0][-64:], out[1][-64:]) < 2e-6      # bias: ones x dY on the matrix core vs the VALU sum
+    assert float(out[1].abs().sum()) > 0
+
+
 # ----------------------------------------------------------------------- GEMMs
 @pytest.mark.parametrize("M,N,K,tile", [(100, 1024, 3136, 64), (128, 1024, 3136, 128), (257, 192, 64, 64),
                                         (1000, 3136, 1024, 128), (64, 64, 128, 0)])

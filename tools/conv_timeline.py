@@ -141,7 +141,8 @@ else:
         gp = torch.randn(B, 7, 7, 64, device="cuda").bfloat16()
         arg = torch.randint(0, 5, (B, 7, 7, 64), device="cuda", dtype=torch.uint8)
         part = torch.empty(G, 25 * 32 * 64 + 64, device="cuda")
-        buf2 = torch.zeros(G * 4, 16, dtype=torch.int64, device="cuda")
+        pc = os.environ.get("DTF_C2W_PC", "1") != "0"
+        buf2 = torch.zeros(G * 4, 32 if pc else 16, dtype=torch.int64, device="cuda")   # the pc kernel stamps 32 slots
         fw = lib.dtf_conv2_wgrad; fw.argtypes = [P] * 4 + [ctypes.c_int] * 4 + [P]
         call = lambda: fw(x.data_ptr(), gp.data_ptr(), arg.data_ptr(), part.data_ptr(), B, 32, 64, G, s)
         lib.dtf_conv2_set_timing_buf(None)
@@ -149,9 +150,14 @@ else:
         torch.cuda.synchronize()
         assert lib.dtf_conv2_set_timing_buf(buf2.data_ptr()) == 0
         call(); torch.cuda.synchronize()
-        t = buf2.cpu().double().reshape(G * 4, 2, 8)
+        full = buf2.cpu().double()
+        t = full[:, :16].reshape(G * 4, 2, 8)
         t0 = t[:, 0, 0].min()
-        pc = os.environ.get("DTF_C2W_PC", "1") != "0"
+        if pc:
+            left, wait = (full[:, 16:24] - t0) * 10.0 / 1e3, full[:, 24:32] * 10.0 / 1e3
+            print("MFMA waves 0..7, loop left (median us): " + " ".join(f"{left[:, w].median():6.2f}" for w in range(8)))
+            print("                 summed wait (median) : " + " ".join(f"{wait[:, w].median():6.2f}" for w in range(8)))
+            print(f"                 last wave of a workgroup leaves at median {left.max(dim=1).values.median():.2f} us, first at {left.min(dim=1).values.median():.2f}")
         for wv, name in ((0, "wave 0 (MFMA wave)"), (1, "wave 8 (producer)")) if pc else ((0, "wave 0 (stages x + dY)"), (1, "wave 7 (stages x only)")):
             a = t[:, wv, :]
             print(f"wgrad B={B} {name}: {G * 4} workgroups, {B // G} images each")
