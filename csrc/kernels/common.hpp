@@ -218,4 +218,22 @@ __device__ __forceinline__ void xcd_tile(int gx, int gy, int& tx, int& ty) {
   xcd_tile_linear(blockIdx.x + gx * blockIdx.y, gx, gy, tx, ty);
 }
 
+// ---------------------------------------------------------------------------
+// Producer / consumer hand-over inside a workgroup WITHOUT s_barrier (conv5x5_wgrad_pc, the ring GEMMs): one progress
+// word PER WAVE in LDS (a shared counter cannot tell two steps of a fast wave from one step of two waves).  LDS
+// operations of one wave execute in order, so the word's update (release) follows the wave's own LDS writes / reads;
+// a waiting wave polls all words of the other side with one read (lane l reads word l & n_mask) + s_sleep.
+// The spin is bounded: a wave that gives up computes garbage, but the grid always drains.
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ void pc_signal(unsigned* word, unsigned steps_done, int lane) {
+  if (lane == 0) __hip_atomic_store(word, steps_done, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+__device__ __forceinline__ void pc_wait_all_ge(unsigned* words, int n_mask, unsigned target, int lane) {
+  for (int spin = 0; spin < (1 << 22); ++spin) {
+    const unsigned v = __hip_atomic_load(words + (lane & n_mask), __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP);
+    if (__builtin_amdgcn_ballot_w64(v < target) == 0ull) return;
+    __builtin_amdgcn_s_sleep(1);
+  }
+}
+
 }  // namespace dtf

@@ -819,21 +819,7 @@ constexpr int kPcFlagOff = 2 * kPcPairs * kPcBufBytes;             // two progre
 constexpr int kPcLdsBytes = kPcFlagOff + 64;                       // 149056 of the CU's 163840
 static_assert(kPcFlagOff >= wg_red_bytes(2), "the end-of-kernel reduction aliases the image buffers");
 
-// Round hand-over without s_barrier: one progress word PER WAVE (a shared counter cannot tell two rounds of a fast
-// wave from one round of two waves) -- staged[pw] = rounds producer wave pw has written, done[w] = rounds MFMA wave w
-// has finished.  LDS operations of one wave execute in order, so the word's update (release) follows the wave's
-// writes / reads; a waiting wave polls all words of the other side with one read (lane l reads word l mod n) + s_sleep.
-// The spin is bounded: a wave that gives up computes garbage but the grid always drains.
-__device__ __forceinline__ void pc_signal(unsigned* word, unsigned rounds_done, int lane) {
-  if (lane == 0) __hip_atomic_store(word, rounds_done, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
-}
-__device__ __forceinline__ void pc_wait_all_ge(unsigned* words, int n_mask, unsigned target, int lane) {
-  for (int spin = 0; spin < (1 << 22); ++spin) {
-    const unsigned v = __hip_atomic_load(words + (lane & n_mask), __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP);
-    if (__builtin_amdgcn_ballot_w64(v < target) == 0ull) return;
-    __builtin_amdgcn_s_sleep(1);
-  }
-}
+// (round hand-over through per-wave LDS progress words: pc_signal / pc_wait_all_ge, common.hpp)
 
 template <int C_IN, int C_OUT>
 __global__ __launch_bounds__(768) void conv5x5_wgrad_pc(const bf16* __restrict__ x, const bf16* __restrict__ gpool,
