@@ -1301,6 +1301,7 @@ int dtf_conv2_wgrad_nt(const void* x, const void* gpool, const void* arg, void* 
     }
     if (forced == 2 || forced == 4) nt = forced;
     else if (cin == 32 && cout == 64 && pc) return launch_wgrad_pc<32, 64>(x, gpool, arg, part, B, G, s);
+    else if (cin == 128 && cout == 256 && pc) return launch_wgrad_pc<128, 256>(x, gpool, arg, part, B, G, s);
     else nt = cin >= 128 ? 4 : 2;
   }
   if (nt != 2 && nt != 4) return -3;
