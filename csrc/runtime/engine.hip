@@ -242,7 +242,7 @@ static int fc1_dgrad(const DtfEngineDesc* e, int head_w, hipStream_t s) {
 
 // head_w < 0: fc1 dgrad (and with it the head wgrad) has already been issued by the caller
 static int backward_conv_impl(const DtfEngineDesc* e, const void* images, const void* idx, int record_dgrad,
-                              int reduce, int head_w, hipStream_t s) {
+                              int reduce, int head_w, hipStream_t s, bool dgrad_first = false) {
   if (head_w >= 0) DTF_TRY(fc1_dgrad(e, head_w, s));
   if (record_dgrad) HIP_TRY(hipEventRecord(e->ev_dgrad, s));
   hipStream_t s2 = s;
@@ -251,10 +251,30 @@ static int backward_conv_impl(const DtfEngineDesc* e, const void* images, const 
     HIP_TRY(hipStreamWaitEvent(e->side2, e->ev_fork, 0));
     s2 = e->side2;
   }
-  DTF_TRY(conv2_wgrad(e, s2));
-  if (e->multi_stream) HIP_TRY(hipEventRecord(e->ev_join2, s2));
-  DTF_TRY(dgrad_conv1_wgrad(e, images, idx, s));
-  if (e->multi_stream) HIP_TRY(hipStreamWaitEvent(s, e->ev_join2, 0));
+  // dgrad_first (one stream): in the data-parallel step the dense exchange (comm stream) starts together with this
+  // backward; conv5x5_wgrad_pc fills a CU (twelve waves x 168 registers, 146 KiB of LDS), so exchange workgroups that
+  // are not placed before it wait for its 25 us -- next to the dgrad kernel (two 4-wave workgroups per CU) they fit
+  // (bench.py --force_dp --no_collapse with the shard of a 2 / 4 / 8-rank job: -3.7 / -1.9 / -0.8 % step time).
+  // Without a concurrent exchange the other order is the faster one (the slab sums right behind conv2 wgrad cost
+  // +5 us, measured with --force_dp), so it stays the default.  And ONLY when every rank has a GPU to itself: with
+  // two ranks time-sliced on one device (the test harness, --rehearse_one_gpu) the exchange workgroups of one rank,
+  // placed early and spinning, kept the other rank's kernels off the device for seconds at a time -- 24 steps took
+  // 3 s, 36 s, 57 s, > 60 s in four consecutive runs (tools/scratch/sync_p2p_repro.py), 3 s in all eight the other way.
+  static int dgrad_first_env = -1;   // DTF_DGRAD_FIRST=0|1 overrides (A/B switch)
+  if (dgrad_first_env < 0) {
+    const char* v = getenv("DTF_DGRAD_FIRST");
+    dgrad_first_env = (v && *v) ? (atoi(v) ? 1 : 0) : 2;
+  }
+  if (dgrad_first_env != 2) dgrad_first = dgrad_first_env == 1;
+  if (!e->multi_stream && dgrad_first) {
+    DTF_TRY(dgrad_conv1_wgrad(e, images, idx, s));
+    DTF_TRY(conv2_wgrad(e, s));
+  } else {
+    DTF_TRY(conv2_wgrad(e, s2));
+    if (e->multi_stream) HIP_TRY(hipEventRecord(e->ev_join2, s2));
+    DTF_TRY(dgrad_conv1_wgrad(e, images, idx, s));
+    if (e->multi_stream) HIP_TRY(hipStreamWaitEvent(s, e->ev_join2, 0));
+  }
   if (!reduce) return 0;
   // reduce == 2: the head slabs (written by backward_dense with reduce == 0) are summed here too, in
   // the same launch -- the data-parallel step needs head + conv reduced only for its tail collective
@@ -509,6 +529,9 @@ int dtf_engine_dp_step(const DtfEngineDesc* e, const DtfDpFabric* f, int collaps
   // a one-rank job with collapse_world1: SGD applies the dense update in the wgrad epilogue; any other optimizer lets
   // the commit workgroups of the tail kernel do it straight from the gradient arena (with_dense == 2).  Either way
   // there is no dense exchange kernel, no branch and no event in the step.
+  // (bit 1 of collapse_world1: every rank has a GPU to itself -- see backward_conv_impl's dgrad_first)
+  const bool own_gpu = (collapse_world1 & 2) != 0;
+  collapse_world1 &= 1;
   const bool collapsed = f->world == 1 && collapse_world1 && !adam;
   const bool local_dense = f->world == 1 && collapse_world1 && adam;
   if (collapsed) {
@@ -537,7 +560,7 @@ int dtf_engine_dp_step(const DtfEngineDesc* e, const DtfDpFabric* f, int collaps
                                   adam ? (const void*)((const int64_t*)e->state + 3) : nullptr, comm));
     if (comm != s) HIP_TRY(hipEventRecord(e->ev_dense_updated, comm));
   }
-  DTF_TRY(backward_conv_impl(e, e->ds_images, e->idx, 0, 2, -1, s));
+  DTF_TRY(backward_conv_impl(e, e->ds_images, e->idx, 0, 2, -1, s, own_gpu && !collapsed && !local_dense && comm != s));
   if (!collapsed && !local_dense && comm != s) HIP_TRY(hipStreamWaitEvent(s, e->ev_dense_updated, 0));
   return dtf_dp_tail_commit(f, adam, collapsed ? 0 : (local_dense ? 2 : 1), e->params, e->grads, e->adam_m, e->adam_v, shadow_of(e), e->hyper,
                             e->wc2T, e->off_wc2, e->c1, e->c2, e->out_wT, e->off_out_w, e->hidden, e->state, 3, 4, e->B,

@@ -110,6 +110,11 @@ class DpFabric:
                 err = repr(e)
             handles: List[Optional[bytes]] = [None] * self.world
             dist.all_gather_object(handles, None if err else handle.raw, group=group)
+            # does every rank have a GPU to itself?  (ranks that share a device are time-sliced: the step then keeps
+            # the kernel order that does not let one rank's spinning exchange starve the other's kernels, engine.hip)
+            ids: List[Optional[str]] = [None] * self.world
+            dist.all_gather_object(ids, self._device_identity(), group=group)
+            self.exclusive_devices = len(set(ids)) == self.world
             if err is None and any(h is None for h in handles):
                 err = "a peer could not allocate/export its buffer"
             if err is None:
@@ -131,6 +136,12 @@ class DpFabric:
             raise RuntimeError("exchange fabric bring-up failed: " + "; ".join(f"rank {r}: {o}" for r, o in enumerate(oks) if o))
         torch.cuda.synchronize(self.device)
         dist.barrier(group=group)     # nobody stores into a peer before everybody has mapped (and zeroed) everything
+
+    def _device_identity(self) -> str:
+        import socket
+        p = torch.cuda.get_device_properties(self.device)
+        uuid = getattr(p, "uuid", None)
+        return f"{socket.gethostname()}/{uuid if uuid is not None else torch.cuda.current_device()}/{getattr(p, 'pci_bus_id', '')}"
 
     def byref(self):
         return ctypes.byref(self.desc)

@@ -319,7 +319,9 @@ class SyncDataParallel:
 
     def _fabric_step(self):
         eng = self.eng
-        check(eng.lib.dtf_engine_dp_step(eng._d(), self.fabric.byref(), int(self.collapse_world1), eng.step_inc,
+        # bit 0: collapse a one-rank job; bit 1: every rank has a GPU to itself (kernel order of the backward, engine.hip)
+        flags = int(self.collapse_world1) | (2 if getattr(self.fabric, "exclusive_devices", False) else 0)
+        check(eng.lib.dtf_engine_dp_step(eng._d(), self.fabric.byref(), flags, eng.step_inc,
                                          torch.cuda.current_stream(eng.device).cuda_stream,
                                          torch.cuda.current_stream(eng.device).cuda_stream if self.fabric_single_stream
                                          else self.comm_stream.cuda_stream),
