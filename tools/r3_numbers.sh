@@ -4,7 +4,7 @@ set -o pipefail
 export TMPDIR=/tmp
 OUT=gpurun_out/r3_final_numbers.txt
 : > $OUT
-run() { echo "## $*" >> $OUT; timeout -k 10 200 "$@" 2>/dev/null | tail -1 >> $OUT || { echo "FAILED: $*" >> $OUT; exit 1; }; }
+run() { echo "## $*" >> $OUT; timeout -k 10 200 "$@" 2>gpurun_out/r3_numbers_last_stderr.log | tail -1 >> $OUT || { echo "FAILED: $*" >> $OUT; tail -20 gpurun_out/r3_numbers_last_stderr.log; exit 1; }; }
 run python bench.py --steps 1000 --warmup 50
 run python bench.py --steps 20 --warmup 5
 run python bench.py --force_dp --steps 1000 --warmup 50
