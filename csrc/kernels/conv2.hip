@@ -821,6 +821,31 @@ static_assert(kPcFlagOff >= wg_red_bytes(2), "the end-of-kernel reduction aliase
 
 // (round hand-over through per-wave LDS progress words: pc_signal / pc_wait_all_ge, common.hpp)
 
+// Tap chains.  The A fragment F(y, kx) = input rows (y, y + 1) shifted by kx serves tap (ky, kx) at row pair r whenever
+// 2 r + ky = y: taps (0, kx), (2, kx), (4, kx) of consecutive row pairs read the SAME fragments, and so do (1, kx),
+// (3, kx).  An MFMA wave therefore owns whole chains -- E_kx = {(0,kx), (2,kx), (4,kx)} and O_kx = {(1,kx), (3,kx)} --
+// keeps a chain's 3 (2) fragments in registers and fetches ONE new fragment per chain and k-step (the one the chain's
+// last tap needs next), into the slot of the fragment that just died: 2-3 A fragments per k-step instead of 7, and no
+// tap slot that is computed and discarded (25 taps = 6 + 6 + 7 + 6).  Roles of the four waves of an image:
+//   0: E0 E1 (+ the bias row: ones x dY in slot 6)   1: E2 E3   2: E4 O0 O1   3: O2 O3 O4
+// (14, 12, 14, 12 tiles per k-step.)  The kh = 1 wave of SIMD tw takes role tw + 1, so every SIMD multiplies 26 tiles
+// per k-step pair (28 before).
+struct WgChain {
+  int len, ky0, kx;
+};
+constexpr int wg_role_chains(int role) { return role < 2 ? 2 : 3; }
+constexpr WgChain wg_role_chain(int role, int c) {
+  return role == 0 ? WgChain{3, 0, c}
+         : role == 1 ? WgChain{3, 0, 2 + c}
+         : role == 2 ? (c == 0 ? WgChain{3, 0, 4} : WgChain{2, 1, c - 1})
+                     : WgChain{2, 1, 2 + c};
+}
+constexpr int wg_role_base(int role, int c) {
+  int b = 0;
+  for (int i = 0; i < c; ++i) b += wg_role_chain(role, i).len;
+  return b;
+}
+
 template <int C_IN, int C_OUT>
 __global__ __launch_bounds__(768) void conv5x5_wgrad_pc(const bf16* __restrict__ x, const bf16* __restrict__ gpool,
                                                         const uint8_t* __restrict__ arg, float* __restrict__ part, int B,
@@ -970,171 +995,194 @@ __global__ __launch_bounds__(768) void conv5x5_wgrad_pc(const bf16* __restrict__
   // ---- MFMA waves ----
   const int g = lane >> 4, i16 = lane & 15;
   const int qr = i16 >> 2, pc = i16 & 3;
-  // Bias gradient = column sums of the gradient tile = ones x dY: tap group 1's seventh tap slot does not exist (it is
-  // clamped, computed and discarded in groups 1..3), so in the ci_t == 0 workgroups that slot multiplies an all-ones
-  // A fragment instead -- every row of acc[6][j] is then the bias sum, for free (the VALU sum of the B fragments
-  // it replaces cost the tap-0 waves 32 instructions per k-step and made them the last to finish).
-  const bool do_bias = (ci_t == 0) && (tw == 1);
-  f32x4 acc[7][NT];
-#pragma unroll
-  for (int t = 0; t < 7; ++t)
-#pragma unroll
-    for (int j = 0; j < NT; ++j) acc[t][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
   zero_fill();
   const int tr_pos = (g >> 1) * kTileW + 4 * (g & 1) + qr;   // A: row pair 0, tap (0,0), first read
   const int kkrow = (g >> 1) * 16 + 4 * (g & 1) + qr;        // B: k row of the first read
   const int bsw = dy_swz(kkrow);
-  int tap_off[7];   // taps tw + 4t; the 7th of groups 1..3 is clamped to tap 24, computed and discarded
-#pragma unroll
-  for (int t = 0; t < 7; ++t) {
-    const int tap = min(tw + 4 * t, 24);
-    tap_off[t] = ((tap / 5) * kTileW + tap % 5) * 16;
-  }
   const bf16* a_lane = xt + tr_pos * 16 + pc * 4;
   const bf16* b_lane = dyt + kkrow * CO_W + pc * 4;
+  const int role = (tw + kh) & 3;   // SIMD tw hosts roles tw and tw + 1: 14 + 12 tiles per k-step pair on every SIMD
 
   __syncthreads();   // zero fill done
   DTF_TIMING_ONLY(if (tb) tb[1] = wall_clock64();)
   DTF_TIMING_ONLY(t_v = clock64();)   // MFMA wave: slots 4 / 6 = shader-clock cycles at loop entry / exit
+  // Everything from here to the slab write is instantiated per role (the chain shapes fix which register a tap reads
+  // at which k-step; a run-time role would put the accumulators behind a join).
   // The k-loop is ONE software pipeline over all rounds: the fragments of the next round's first k-step roll in behind
-  // the MFMAs of this round's last one (A) and last two (B), so a round boundary costs no fragment-latency bubble and
-  // no exposed poll -- the progress words of round p + 1 are read during k-step 3 of round p and looked at after
-  // k-step 4.  Seven k-steps per round flip the parity of the two B sets, hence the body instantiated for both.
-  // The last round prefetches from its own buffers (never used): every round issues the same instruction stream and
-  // the compiler's wait counts stay exact.
-  bf16x8 af[7], bq[2][NT];
-  auto load_b = [&](const bf16* b_img, int r, bf16x8 (&bf)[NT]) {
-#pragma unroll
-    for (int j = 0; j < NT; ++j) {
-      const bf16* p0 = b_img + r * 32 * CO_W + ((j ^ bsw) << 4);
-      s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)p0);
-      s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(p0 + 8 * CO_W));
-      s16x8 v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
-      bf[j] = __builtin_bit_cast(bf16x8, v);
-    }
-  };
-  auto load_a = [&](const bf16* a_img, int r, int t) {
-    const bf16* p0 = a_img + 2 * r * kTileW * 16 + tap_off[t];
-    s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)p0);
-    s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(p0 + 8 * 16));
-    s16x8 av = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
-    af[t] = __builtin_bit_cast(bf16x8, av);
-  };
-  int pair = 0;   // p % kPcPairs
-  auto round_body = [&](auto par_c, int p) {
-    constexpr int PAR = decltype(par_c)::value;
-    // the two MFMA waves of a SIMD take turns at being preferred by its issue arbiter (oldest first otherwise: the
-    // kh = 1 waves then fall 0.25 us behind per round and the whole workgroup waits for them at the end)
-    if ((PAR ^ kh) & 1) __builtin_amdgcn_s_setprio(1); else __builtin_amdgcn_s_setprio(0);
-    const bool has_next = p + 1 < rounds;
-    const int npair = pair + 1 == kPcPairs ? 0 : pair + 1;
-    const int boff = (pair * 2 + kh) * kBufElems;
-    const int noff = ((has_next ? npair : pair) * 2 + kh) * kBufElems;
-    const bf16* a_img = a_lane + boff;
-    const bf16* b_img = b_lane + boff;
-    const bf16* a_nxt = a_lane + noff;
-    const bf16* b_nxt = b_lane + noff;
-    const unsigned need = (unsigned)(has_next ? p + 2 : p + 1);
-    unsigned seen = 0;
-#pragma unroll
-    for (int r = 0; r < 7; ++r) {
-      bf16x8(&bf)[NT] = bq[(r + PAR) & 1];
-      if (r == 5) {   // before the first read of the next round's buffers
-        if (__builtin_amdgcn_ballot_w64(seen < need) != 0ull) {
-          DTF_LAP(t_k);
-          pc_wait_all_ge(staged, 3, need, lane);
-          DTF_LAP(t_w);
-        }
-      }
-#pragma unroll
-      for (int t = 0; t < 7; ++t) {
-        if DTF_ABLATED(64) {
-          asm volatile("" ::"v"(af[t]), "v"(bf[0]), "v"(bf[1]));
-        } else {
-          bf16x8 a = af[t];
-          if (t == 6) {   // wave-uniform select, four v_cndmask
-            const u32x4 ld = __builtin_bit_cast(u32x4, a);
-            const unsigned one2 = 0x3F803F80u;   // bf16 (1.0, 1.0)
-            const u32x4 sel = {do_bias ? one2 : ld[0], do_bias ? one2 : ld[1], do_bias ? one2 : ld[2], do_bias ? one2 : ld[3]};
-            a = __builtin_bit_cast(bf16x8, sel);
-          }
-#pragma unroll
-          for (int j = 0; j < NT; ++j) acc[t][j] = mfma16(a, bf[j], acc[t][j]);
-        }
-        if (!DTF_ABLATED(1024)) {
-          if (r + 1 < 7) load_a(a_img, r + 1, t);
-          else load_a(a_nxt, 0, t);
-        }
-        __builtin_amdgcn_sched_barrier(0);
-      }
-      if (!DTF_ABLATED(1024)) {
-        if (r + 2 < 7) load_b(b_img, r + 2, bf);
-        else load_b(b_nxt, r + 2 - 7, bf);
-        __builtin_amdgcn_sched_barrier(0);
-      }
-      if (r == 3) {
-        seen = __hip_atomic_load(staged + (lane & 3), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-        __builtin_amdgcn_sched_barrier(0);
-      }
-    }
-    pc_signal(done + wave, (unsigned)(p + 1), lane);   // every read of this round's buffers has been waited for by its MFMA
-    pair = npair;
-  };
-  if (rounds > 0 && !DTF_ABLATED(256)) {
-    pc_wait_all_ge(staged, 3, 1u, lane);
-    DTF_LAP(t_w);
-    const int boff = kh * kBufElems;
-    load_b(b_lane + boff, 0, bq[0]);
-#pragma unroll
-    for (int t = 0; t < 7; ++t) load_a(a_lane + boff, 0, t);
-    load_b(b_lane + boff, 1, bq[1]);
-    __builtin_amdgcn_sched_barrier(0);
-    // an odd image count leaves the kh = 1 waves without an image in the last round: they stop before it (the
-    // producers never wait for a round's `done` words after the last three rounds)
-    const int my_rounds = (b_end - b_begin - kh + 1) >> 1;
-    for (int p = 0; p < my_rounds; p += 2) {
-      round_body(std::integral_constant<int, 0>{}, p);
-      if (p + 1 < my_rounds) round_body(std::integral_constant<int, 1>{}, p + 1);
-    }
-  }
-
-  // ---- sum the two kh halves through LDS; kh = 0 waves write their taps: rows ci, cols co ----
-  DTF_LAP_AFTER("s_nop 0", t_k);
-  DTF_TIMING_ONLY(t_s = clock64();)
-  DTF_TIMING_ONLY(if (tb) { tb[2] = wall_clock64(); tb[5] = t_k; tb[6] = t_s; tb[7] = t_w; tb[4] = t_v; })
-  DTF_TIMING_ONLY(if (tb_wg && lane == 0) { tb_wg[16 + wave] = wall_clock64(); tb_wg[24 + wave] = t_w; })
-  __syncthreads();
-  float* red = reinterpret_cast<float*>(smem);  // [tw][RED_ROWS][64 lanes]
-  if (kh == 1) {
+  // the MFMAs of this round's last one, so a round boundary costs no fragment-latency bubble and no exposed poll -- the
+  // progress words of round p + 1 are read during k-step 3 of round p and looked at after k-step 4.  Seven k-steps per
+  // round flip the parity of the two B sets (hence the body instantiated for both) and leave the chains' slot rotation
+  // where it started (6 = 0 mod 3 and mod 2).  The last round prefetches from its own buffers (never used): every round
+  // issues the same instruction stream and the compiler's wait counts stay exact.
+  auto run = [&](auto role_c) {
+    constexpr int ROLE = decltype(role_c)::value;
+    constexpr int NCH = wg_role_chains(ROLE);
+    constexpr bool BIAS = ROLE == 0;   // slot 6: ones x dY = the column sums of the gradient tile = the bias gradient
+    f32x4 acc[7][NT];
 #pragma unroll
     for (int t = 0; t < 7; ++t)
 #pragma unroll
-      for (int j = 0; j < NT; ++j)
+      for (int j = 0; j < NT; ++j) acc[t][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    bf16x8 af[7], bq[2][NT];
+    const unsigned one2 = 0x3F803F80u;   // bf16 (1.0, 1.0)
+    const bf16x8 ones = __builtin_bit_cast(bf16x8, (u32x4){one2, one2, one2, one2});
+    auto load_b = [&](const bf16* b_img, int r, bf16x8 (&bf)[NT]) {
 #pragma unroll
-        for (int r = 0; r < 4; ++r) red[(tw * RED_ROWS + (t * NT + j) * 4 + r) * 64 + lane] = acc[t][j][r];
-  }
-  __syncthreads();
-  DTF_TIMING_ONLY(if (tb) tb[3] = wall_clock64();)
-  if (kh == 1) return;
-  float* slab = part + (size_t)blockIdx.x * (25 * C_IN * C_OUT + C_OUT);
+      for (int j = 0; j < NT; ++j) {
+        const bf16* p0 = b_img + r * 32 * CO_W + ((j ^ bsw) << 4);
+        s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)p0);
+        s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(p0 + 8 * CO_W));
+        s16x8 v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+        bf[j] = __builtin_bit_cast(bf16x8, v);
+      }
+    };
+    auto load_a = [&](const bf16* a_img, int y, int kx, int slot) {   // F(y, kx) -> af[slot]
+      const bf16* p0 = a_img + (y * kTileW + kx) * 16;
+      s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)p0);
+      s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(p0 + 8 * 16));
+      s16x8 av = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+      af[slot] = __builtin_bit_cast(bf16x8, av);
+    };
+    int pair = 0;   // p % kPcPairs
+    auto round_body = [&](auto par_c, int p) {
+      constexpr int PAR = decltype(par_c)::value;
+      // the two MFMA waves of a SIMD take turns at being preferred by its issue arbiter (oldest first otherwise: the
+      // kh = 1 waves then fall 0.25 us behind per round and the whole workgroup waits for them at the end)
+      if ((PAR ^ kh) & 1) __builtin_amdgcn_s_setprio(1); else __builtin_amdgcn_s_setprio(0);
+      const bool has_next = p + 1 < rounds;
+      const int npair = pair + 1 == kPcPairs ? 0 : pair + 1;
+      const int boff = (pair * 2 + kh) * kBufElems;
+      const int noff = ((has_next ? npair : pair) * 2 + kh) * kBufElems;
+      const bf16* a_img = a_lane + boff;
+      const bf16* b_img = b_lane + boff;
+      const bf16* a_nxt = a_lane + noff;
+      const bf16* b_nxt = b_lane + noff;
+      const unsigned need = (unsigned)(has_next ? p + 2 : p + 1);
+      unsigned seen = 0;
 #pragma unroll
-  for (int t = 0; t < 7; ++t) {
-    const int tap = tw + 4 * t;
-    if (tap < 25) {
+      for (int r = 0; r < 7; ++r) {
+        bf16x8(&bf)[NT] = bq[(r + PAR) & 1];
+        if (r == 5) {   // before the first read of the next round's buffers
+          if (__builtin_amdgcn_ballot_w64(seen < need) != 0ull) {
+            DTF_LAP(t_k);
+            pc_wait_all_ge(staged, 3, need, lane);
+            DTF_LAP(t_w);
+          }
+        }
 #pragma unroll
-      for (int j = 0; j < NT; ++j)
+        for (int c = 0; c < NCH; ++c) {
+          const WgChain ch = wg_role_chain(ROLE, c);
+          const int base = wg_role_base(ROLE, c);
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          int ci = ci_t * 16 + 4 * g + r;
-          int co = co_t * CO_W + j * 16 + i16;
-          slab[((size_t)tap * C_IN + ci) * C_OUT + co] = acc[t][j][r] + red[(tw * RED_ROWS + (t * NT + j) * 4 + r) * 64 + lane];
+          for (int j = 0; j < 3; ++j) {
+            if (j < ch.len) {
+              const int slot = base + (r + j) % ch.len;   // holds F(2 r + ky0 + 2 j, kx)
+              if DTF_ABLATED(64) {
+                asm volatile("" ::"v"(af[slot]), "v"(bf[0]), "v"(bf[1]));
+              } else {
+#pragma unroll
+                for (int n = 0; n < NT; ++n) acc[base + j][n] = mfma16(af[slot], bf[n], acc[base + j][n]);
+              }
+              if (!DTF_ABLATED(1024)) {
+                if (r < 6) {
+                  // the chain's oldest fragment died with tap j = 0: its slot takes what the last tap reads next step
+                  if (j == 0) load_a(a_img, 2 * r + ch.ky0 + 2 * ch.len, ch.kx, slot);
+                } else {
+                  load_a(a_nxt, ch.ky0 + 2 * j, ch.kx, slot);   // next round, k-step 0: slot (0 + j) % len = this one
+                }
+              }
+              __builtin_amdgcn_sched_barrier(0);
+            }
+          }
+        }
+        if (BIAS && !DTF_ABLATED(64)) {
+#pragma unroll
+          for (int n = 0; n < NT; ++n) acc[6][n] = mfma16(ones, bf[n], acc[6][n]);
+          __builtin_amdgcn_sched_barrier(0);
+        }
+        if (!DTF_ABLATED(1024)) {
+          if (r + 2 < 7) load_b(b_img, r + 2, bf);
+          else load_b(b_nxt, r + 2 - 7, bf);
+          __builtin_amdgcn_sched_barrier(0);
+        }
+        if (r == 3) {
+          seen = __hip_atomic_load(staged + (lane & 3), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+          __builtin_amdgcn_sched_barrier(0);
+        }
+      }
+      pc_signal(done + wave, (unsigned)(p + 1), lane);   // every read of this round's buffers has been waited for by its MFMA
+      pair = npair;
+    };
+    if (rounds > 0 && !DTF_ABLATED(256)) {
+      pc_wait_all_ge(staged, 3, 1u, lane);
+      DTF_LAP(t_w);
+      const int boff = kh * kBufElems;
+      load_b(b_lane + boff, 0, bq[0]);
+#pragma unroll
+      for (int c = 0; c < NCH; ++c) {
+        const WgChain ch = wg_role_chain(ROLE, c);
+#pragma unroll
+        for (int j = 0; j < 3; ++j)
+          if (j < ch.len) load_a(a_lane + boff, ch.ky0 + 2 * j, ch.kx, wg_role_base(ROLE, c) + j);
+      }
+      load_b(b_lane + boff, 1, bq[1]);
+      __builtin_amdgcn_sched_barrier(0);
+      // an odd image count leaves the kh = 1 waves without an image in the last round: they stop before it (the
+      // producers never wait for a round's `done` words after the last three rounds)
+      const int my_rounds = (b_end - b_begin - kh + 1) >> 1;
+      for (int p = 0; p < my_rounds; p += 2) {
+        round_body(std::integral_constant<int, 0>{}, p);
+        if (p + 1 < my_rounds) round_body(std::integral_constant<int, 1>{}, p + 1);
+      }
+    }
+
+    // ---- sum the two images' waves of a role through LDS; the kh = 0 wave writes the role's taps: rows ci, cols co ----
+    DTF_LAP_AFTER("s_nop 0", t_k);
+    DTF_TIMING_ONLY(t_s = clock64();)
+    DTF_TIMING_ONLY(if (tb) { tb[2] = wall_clock64(); tb[5] = t_k; tb[6] = t_s; tb[7] = t_w; tb[4] = t_v; })
+    DTF_TIMING_ONLY(if (tb_wg && lane == 0) { tb_wg[16 + wave] = wall_clock64(); tb_wg[24 + wave] = t_w; })
+    __syncthreads();
+    float* red = reinterpret_cast<float*>(smem);  // [role][RED_ROWS][64 lanes]
+    if (kh == 1) {
+#pragma unroll
+      for (int t = 0; t < 7; ++t)
+#pragma unroll
+        for (int j = 0; j < NT; ++j)
+#pragma unroll
+          for (int e = 0; e < 4; ++e) red[(ROLE * RED_ROWS + (t * NT + j) * 4 + e) * 64 + lane] = acc[t][j][e];
+    }
+    __syncthreads();
+    DTF_TIMING_ONLY(if (tb) tb[3] = wall_clock64();)
+    if (kh == 1) return;
+    float* slab = part + (size_t)blockIdx.x * (25 * C_IN * C_OUT + C_OUT);
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) {
+      const WgChain ch = wg_role_chain(ROLE, c);
+#pragma unroll
+      for (int j = 0; j < 3; ++j)
+        if (j < ch.len) {
+          const int t = wg_role_base(ROLE, c) + j, tap = 5 * (ch.ky0 + 2 * j) + ch.kx;
+#pragma unroll
+          for (int n = 0; n < NT; ++n)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+              const int ci = ci_t * 16 + 4 * g + e;
+              const int co = co_t * CO_W + n * 16 + i16;
+              slab[((size_t)tap * C_IN + ci) * C_OUT + co] = acc[t][n][e] + red[(ROLE * RED_ROWS + (t * NT + n) * 4 + e) * 64 + lane];
+            }
         }
     }
-  }
-  if (do_bias && g == 0) {   // row 0 of the ones product: lanes 0..15, element 0
+    if (BIAS && ci_t == 0 && g == 0) {   // row 0 of the ones product: lanes 0..15, element 0
 #pragma unroll
-    for (int j = 0; j < NT; ++j)
-      slab[25 * C_IN * C_OUT + co_t * CO_W + j * 16 + i16] = acc[6][j][0] + red[(tw * RED_ROWS + (6 * NT + j) * 4) * 64 + lane];
+      for (int n = 0; n < NT; ++n)
+        slab[25 * C_IN * C_OUT + co_t * CO_W + n * 16 + i16] = acc[6][n][0] + red[(ROLE * RED_ROWS + (6 * NT + n) * 4) * 64 + lane];
+    }
+  };
+  switch (role) {
+    case 0: run(std::integral_constant<int, 0>{}); break;
+    case 1: run(std::integral_constant<int, 1>{}); break;
+    case 2: run(std::integral_constant<int, 2>{}); break;
+    default: run(std::integral_constant<int, 3>{}); break;
   }
 }
 
