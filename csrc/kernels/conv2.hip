@@ -850,7 +850,7 @@ template <int C_IN, int C_OUT>
 __global__ __launch_bounds__(768) void conv5x5_wgrad_pc(const bf16* __restrict__ x, const bf16* __restrict__ gpool,
                                                         const uint8_t* __restrict__ arg, float* __restrict__ part, int B,
                                                         int imgs_per_block) {
-  constexpr int NT = 2, CI_T = C_IN / 16, CO_W = 16 * NT, CO_CH = CO_W / 8, RED_ROWS = wg_red_rows(NT);
+  constexpr int NT = 2, CI_T = C_IN / 16, CO_W = 16 * NT, CO_CH = CO_W / 8;
   constexpr int kBufElems = kPcBufBytes / 2;
   static_assert(C_OUT % CO_W == 0 && C_IN % 16 == 0, "tile shape");
   typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
@@ -933,7 +933,7 @@ __global__ __launch_bounds__(768) void conv5x5_wgrad_pc(const bf16* __restrict__
     }
     u32x4 xr[XR], gv_r[DR];
     u32x2 ar_r[DR];
-    auto prefetch = [&](int p) {
+    auto prefetch = [&](int p, bool with_x = true) {
       const int b0 = b_begin + 2 * p;
       const int second = (b0 + 1 < b_end) ? 1 : 0;   // odd image count: the last round re-reads its only image
       const bf16* xg = x + (size_t)b0 * kXImg;
@@ -941,7 +941,7 @@ __global__ __launch_bounds__(768) void conv5x5_wgrad_pc(const bf16* __restrict__
       const uint8_t* ag = arg + (size_t)b0 * kDyImg;
 #pragma unroll
       for (int k = 0; k < XR; ++k)
-        if (xsrc[k] >= 0 && !DTF_ABLATED(32)) xr[k] = *reinterpret_cast<const u32x4*>(xg + xsrc[k] + (xim[k] & second) * kXImg);
+        if (with_x && xsrc[k] >= 0 && !DTF_ABLATED(32)) xr[k] = *reinterpret_cast<const u32x4*>(xg + xsrc[k] + (xim[k] & second) * kXImg);
 #pragma unroll
       for (int k = 0; k < DR; ++k)
         if (dsrc[k] >= 0 && !DTF_ABLATED(128)) {
@@ -950,12 +950,12 @@ __global__ __launch_bounds__(768) void conv5x5_wgrad_pc(const bf16* __restrict__
           ar_r[k] = *reinterpret_cast<const u32x2*>(ag + off);
         }
     };
-    auto stage = [&](int p) {
+    auto stage = [&](int p, bool with_x = true) {
       bf16* xp = xt + (p % kPcPairs) * 2 * kBufElems;
       bf16* dp = dyt + (p % kPcPairs) * 2 * kBufElems;
 #pragma unroll
       for (int k = 0; k < XR; ++k)
-        if (xsrc[k] >= 0 && !DTF_ABLATED(32)) *reinterpret_cast<u32x4*>(xp + xdst[k]) = xr[k];
+        if (with_x && xsrc[k] >= 0 && !DTF_ABLATED(32)) *reinterpret_cast<u32x4*>(xp + xdst[k]) = xr[k];
 #pragma unroll
       for (int k = 0; k < DR; ++k)
         if (dsrc[k] >= 0 && !DTF_ABLATED(128)) {
@@ -966,9 +966,9 @@ __global__ __launch_bounds__(768) void conv5x5_wgrad_pc(const bf16* __restrict__
             *reinterpret_cast<u32x4*>(dp + ddst[k] + ((q >> 1) * 16 + (q & 1)) * CO_W) = o[q];
         }
     };
-    if (rounds > 0) {
-      prefetch(0);
-      stage(0);
+    if (rounds > 0) {   // round 0: the gradient tiles only, the (idle) MFMA waves copy the input tiles
+      prefetch(0, false);
+      stage(0, false);
       if (rounds > 1) prefetch(1);
     }
     pc_signal(staged + pw, 1u, lane);
@@ -995,7 +995,24 @@ __global__ __launch_bounds__(768) void conv5x5_wgrad_pc(const bf16* __restrict__
   // ---- MFMA waves ----
   const int g = lane >> 4, i16 = lane & 15;
   const int qr = i16 >> 2, pc = i16 & 3;
-  zero_fill();
+  {
+    // round 0's input tiles (2 x 392 chunks of 16 bytes): requested before the zero fill, stored after it
+    u32x4 x0[2];
+    int dst0[2];
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+      const int it = tid + k * 512, im = it >= 392, w = it - im * 392, x_pos = w >> 1;
+      dst0[k] = -1;
+      if (it < 784 && b_begin + im < b_end && !DTF_ABLATED(32)) {
+        dst0[k] = im * kBufElems + ((x_pos / 14 + 2) * kTileW + (x_pos % 14 + 2)) * 16 + (w & 1) * 8;
+        x0[k] = *reinterpret_cast<const u32x4*>(x + ((size_t)(b_begin + im) * 196 + x_pos) * C_IN + ci_t * 16 + (w & 1) * 8);
+      }
+    }
+    zero_fill();
+#pragma unroll
+    for (int k = 0; k < 2; ++k)
+      if (dst0[k] >= 0) *reinterpret_cast<u32x4*>(xt + dst0[k]) = x0[k];
+  }
   const int tr_pos = (g >> 1) * kTileW + 4 * (g & 1) + qr;   // A: row pair 0, tap (0,0), first read
   const int kkrow = (g >> 1) * 16 + 4 * (g & 1) + qr;        // B: k row of the first read
   const int bsw = dy_swz(kkrow);
@@ -1142,14 +1159,12 @@ __global__ __launch_bounds__(768) void conv5x5_wgrad_pc(const bf16* __restrict__
     DTF_TIMING_ONLY(if (tb) { tb[2] = wall_clock64(); tb[5] = t_k; tb[6] = t_s; tb[7] = t_w; tb[4] = t_v; })
     DTF_TIMING_ONLY(if (tb_wg && lane == 0) { tb_wg[16 + wave] = wall_clock64(); tb_wg[24 + wave] = t_w; })
     __syncthreads();
-    float* red = reinterpret_cast<float*>(smem);  // [role][RED_ROWS][64 lanes]
+    f32x4* red = reinterpret_cast<f32x4*>(smem);  // [role][7 * NT tiles][64 lanes]: one 16-byte store / load per tile
     if (kh == 1) {
 #pragma unroll
       for (int t = 0; t < 7; ++t)
 #pragma unroll
-        for (int j = 0; j < NT; ++j)
-#pragma unroll
-          for (int e = 0; e < 4; ++e) red[(ROLE * RED_ROWS + (t * NT + j) * 4 + e) * 64 + lane] = acc[t][j][e];
+        for (int j = 0; j < NT; ++j) red[(ROLE * 7 * NT + t * NT + j) * 64 + lane] = acc[t][j];
     }
     __syncthreads();
     DTF_TIMING_ONLY(if (tb) tb[3] = wall_clock64();)
@@ -1163,19 +1178,21 @@ __global__ __launch_bounds__(768) void conv5x5_wgrad_pc(const bf16* __restrict__
         if (j < ch.len) {
           const int t = wg_role_base(ROLE, c) + j, tap = 5 * (ch.ky0 + 2 * j) + ch.kx;
 #pragma unroll
-          for (int n = 0; n < NT; ++n)
+          for (int n = 0; n < NT; ++n) {
+            const f32x4 o = red[(ROLE * 7 * NT + t * NT + n) * 64 + lane];
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
               const int ci = ci_t * 16 + 4 * g + e;
               const int co = co_t * CO_W + n * 16 + i16;
-              slab[((size_t)tap * C_IN + ci) * C_OUT + co] = acc[t][n][e] + red[(ROLE * RED_ROWS + (t * NT + n) * 4 + e) * 64 + lane];
+              slab[((size_t)tap * C_IN + ci) * C_OUT + co] = acc[t][n][e] + o[e];
             }
+          }
         }
     }
     if (BIAS && ci_t == 0 && g == 0) {   // row 0 of the ones product: lanes 0..15, element 0
 #pragma unroll
       for (int n = 0; n < NT; ++n)
-        slab[25 * C_IN * C_OUT + co_t * CO_W + n * 16 + i16] = acc[6][n][0] + red[(ROLE * RED_ROWS + (6 * NT + n) * 4) * 64 + lane];
+        slab[25 * C_IN * C_OUT + co_t * CO_W + n * 16 + i16] = acc[6][n][0] + red[(ROLE * 7 * NT + 6 * NT + n) * 64 + lane][0];
     }
   };
   switch (role) {
