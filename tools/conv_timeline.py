@@ -116,7 +116,7 @@ elif len(sys.argv) > 3 and sys.argv[3] == "head":
 else:
     import torch
     B = int(sys.argv[2]) if len(sys.argv) > 2 else 1024
-    lib = ctypes.CDLL(f"{OUT}/conv2_timing.so")
+    lib = ctypes.CDLL(os.environ.get("DTF_TIMING_LIB", f"{OUT}/conv2_timing.so"))
     P = ctypes.c_void_p
     x = torch.rand(B, 14, 14, 32, device="cuda").bfloat16()
     w = (torch.randn(2, 25 * 64 * 32, device="cuda") * 0.05).bfloat16()
