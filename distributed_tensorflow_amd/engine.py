@@ -218,18 +218,15 @@ class HipEngine:
         self.head_part = torch.empty((self.head_ks, self.head_stride), **f32)
         # conv2 wgrad split-K over images: G slabs x (C1/16 * C2/32) output tiles workgroups.  64 slabs fill the
         # chip for the 32/64 model (4 tiles); the widened model has 64 tiles and 3.3 MB slabs -> 8 slabs
-        # Wave tile of the bf16 kernel: 16 ci x 64 co (4 co tiles per wave: -39 % LDS fragment bytes per MFMA, half as
-        # many output tiles) for the widened model and, with twice the image chunks, for the 32/64 model above 4096
-        # images per GPU.  0 = the library's default launch for 16 ci x 32 co tiles, the producer / consumer kernel
-        # (conv5x5_wgrad_pc): step -0.6 % at 100 images, -3.8 % at 512, -5.4 % at 1024, -2.1 % at 2048, -1.2 % at 4096,
-        # even at 8192 (tools/scratch/ab_pc_batches.sh, ab_pc_big.sh: same device, alternating)
-        # The widened model runs the same kernel (64 tiles x 4 slabs): 1.445 -> 1.396 ms/step at 1024 images against
-        # the 16 ci x 64 co self-staging tile with 8 slabs (tools/scratch/ab_pc_wide.sh).
-        self.c2_nt = 4 if (C1 < 128 and B > 4096) else 0
+        # 0 = the library's default launch for 16 ci x 32 co tiles, the producer / consumer kernel (conv5x5_wgrad_pc),
+        # at every batch size and for both models: step -0.6 % at 100 images, -3.8 % at 512, -7.2 % at 1024, -2.1 % at
+        # 2048, -1.2 % at 4096, -1.8 % at 8192, -0.8 % at 16384 against the self-staging kernel (16 ci x 32 co tile up to
+        # 4096 images, 16 ci x 64 co with twice the slabs above); the widened model 1.445 -> 1.396 ms at 1024 images
+        # (64 tiles x 4 slabs against the 16 ci x 64 co tile with 8).  tools/scratch/ab_pc_batches.sh, ab_pc_big.sh,
+        # ab_pc_wide.sh: same device, alternating.  DTF_C2W_NT=2|4 selects the self-staging kernel (tests, A/B).
+        self.c2_nt = 0
         if tun.c2w_nt:                                          # A/B switch for tools
             self.c2_nt = tun.c2w_nt
-        if os.environ.get("DTF_FORCE_C2W_PC") == "1" and C1 < 128:   # A/B switch: the default launch at any batch size
-            self.c2_nt = 0
         c2_tiles = (C1 // 16) * (C2 // (16 * (self.c2_nt or 2)))
         default_g = (4 if self.c2_nt == 0 else 8) if C1 >= 128 else (64 if c2_tiles >= 4 else 128)
         self.c2_g = max(1, min((B + 1) // 2, tun.c2_g or default_g))
