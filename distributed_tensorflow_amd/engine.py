@@ -221,14 +221,14 @@ class HipEngine:
         # 0 = the library's default launch for 16 ci x 32 co tiles, the producer / consumer kernel (conv5x5_wgrad_pc),
         # at every batch size and for both models: step -0.6 % at 100 images, -3.8 % at 512, -7.2 % at 1024, -2.1 % at
         # 2048, -1.2 % at 4096, -1.8 % at 8192, -0.8 % at 16384 against the self-staging kernel (16 ci x 32 co tile up to
-        # 4096 images, 16 ci x 64 co with twice the slabs above); the widened model 1.445 -> 1.396 ms at 1024 images
-        # (64 tiles x 4 slabs against the 16 ci x 64 co tile with 8).  tools/scratch/ab_pc_batches.sh, ab_pc_big.sh,
+        # 4096 images, 16 ci x 64 co with twice the slabs above); the widened model 1.442 -> 1.375 ms at 1024 images
+        # (64 tiles x 8 slabs against 32 tiles of 16 ci x 64 co x 8 slabs).  tools/scratch/ab_pc_batches.sh, ab_pc_big.sh,
         # ab_pc_wide.sh: same device, alternating.  DTF_C2W_NT=2|4 selects the self-staging kernel (tests, A/B).
         self.c2_nt = 0
         if tun.c2w_nt:                                          # A/B switch for tools
             self.c2_nt = tun.c2w_nt
         c2_tiles = (C1 // 16) * (C2 // (16 * (self.c2_nt or 2)))
-        default_g = (4 if self.c2_nt == 0 else 8) if C1 >= 128 else (64 if c2_tiles >= 4 else 128)
+        default_g = 8 if C1 >= 128 else (64 if c2_tiles >= 4 else 128)
         self.c2_g = max(1, min((B + 1) // 2, tun.c2_g or default_g))
         if dtype == "fp32":
             # conv5x5_wgrad_f32: one workgroup per (image range, 32 ci x 64 co tile), one workgroup per CU
