@@ -3,10 +3,10 @@
 //
 // With C_in = 1 the layer has K = 25: at fp32 the matrix cores run at exactly the vector rate (64 FLOP/clk/SIMD),
 // so padding K to MFMA shapes can only lose.  Both kernels are direct VALU stencils with lane = output channel:
-//   * forward: a half-wave (32 channels) owns one pooling window at a time; the window's 6x6 input patch is read
-//     from a zero-haloed LDS image as broadcast ds_read_b64 (all 32 lanes the same address), the 25 filter taps
-//     of the lane's channel live in registers, and conv + bias + ReLU + pool + argmax never leave registers;
-//     stores are 128 contiguous bytes per window.
+//   * forward: 16 lanes x 2 channels own one pooling window at a time; the window's 6x6 input patch is read
+//     from a zero-haloed LDS image as broadcast ds_read_b64 (all 16 lanes the same address), the 25 filter taps
+//     of the lane's channel pair live in registers (packed FMAs), and conv + bias + ReLU + pool + argmax never
+//     leave registers; stores are 128 contiguous bytes per window.
 //   * wgrad: the pooled gradient reaches exactly ONE of the four positions of a window (the saved argmax), so
 //     dW[tap][c] += g * x[argmax position + tap] is 25 FMAs per (window, channel) instead of 100 -- the
 //     max-pool/ReLU gradient is never expanded.  Lanes gather their 25 pixels from LDS at their own argmax
@@ -30,9 +30,17 @@ __device__ __forceinline__ void c1f_store_px(float* img, int i4, const f32x4& v)
   *reinterpret_cast<f32x2*>(d + 2) = (f32x2){v[2], v[3]};
 }
 
-// grid = (min(B, ..), C/32, NS), 256 threads = 8 half-waves.  w: fp32 HWIO [25][C].  gridDim.z = NS workgroups share
-// an image's 196 pooling windows (small batches: one workgroup per image is 100 workgroups on 256 CUs at batch 100,
-// each a chain of 25 window rounds).
+// grid = (min(B, ..), C/32, NS), 256 threads = 16 window slots of 16 lanes.  w: fp32 HWIO [25][C].  gridDim.z = NS
+// workgroups share an image's 196 pooling windows (small batches: one workgroup per image is 100 workgroups on 256 CUs
+// at batch 100).
+//
+// Lane = TWO adjacent output channels: every FMA of the stencil is then a v_pk_fma_f32 (pixel splat x the channel
+// pair's tap weights), which is the only way to the full fp32 vector rate -- a scalar-per-lane v_fma_f32 runs at half
+// of it, and this kernel is VALU-bound (100 FMAs per window and channel).  The FMA order per channel is unchanged
+// (taps in ky, kx order), so the results are bit-for-bit those of the one-channel-per-lane kernel.
+// Window w = 16 * round + 4 * wave' + slot: round 12 holds the last 4 windows only, given to a different wave from
+// workgroup to workgroup (wave' = (wave + blockIdx.x) & 3) so that the co-resident workgroups of a CU do not all
+// leave their 13th round on the same SIMD.
 __global__ __launch_bounds__(256) void conv1_pool_fwd_f32(const float* __restrict__ images, const int* __restrict__ idx,
                                                           SampleArgs smp, const float* __restrict__ w,
                                                           const float* __restrict__ bias, float* __restrict__ pooled,
@@ -40,14 +48,14 @@ __global__ __launch_bounds__(256) void conv1_pool_fwd_f32(const float* __restric
   typedef __attribute__((ext_vector_type(2))) float f32x2;
   __shared__ __attribute__((aligned(16))) float img[kC1fElems];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int c = blockIdx.y * 32 + (lane & 31);
-  const int hw = wave * 2 + (lane >> 5);
+  const int c = blockIdx.y * 32 + 2 * (lane & 15);
+  const int slot = 4 * ((wave + (int)blockIdx.x) & 3) + (lane >> 4);
 
   const SampleCursor cur = sample_cursor(smp);
-  float wr[25];
+  f32x2 wr[25];
 #pragma unroll
-  for (int t = 0; t < 25; ++t) wr[t] = w[t * C + c];
-  const float bv = bias[c];
+  for (int t = 0; t < 25; ++t) wr[t] = *reinterpret_cast<const f32x2*>(w + t * C + c);
+  const f32x2 bv = *reinterpret_cast<const f32x2*>(bias + c);
   for (int i = tid; i < kC1fElems / 4; i += 256) reinterpret_cast<f32x4*>(img)[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
   f32x4 px = {0.f, 0.f, 0.f, 0.f};
@@ -61,39 +69,42 @@ __global__ __launch_bounds__(256) void conv1_pool_fwd_f32(const float* __restric
     if (tid < 196) c1f_store_px(img, tid, px);
     __syncthreads();
     if (b + (int)gridDim.x < B) fetch(b + gridDim.x);   // next image's pixels fly during this one's stencil
-    for (int win = hw + 8 * (int)blockIdx.z; win < 196; win += 8 * (int)gridDim.z) {
+    for (int win = slot + 16 * (int)blockIdx.z; win < 196; win += 16 * (int)gridDim.z) {
       const int py = win / 14, pxw = win % 14;
-      float p[6][6];
+      f32x2 p[6][3];   // the window's 6x6 input patch: broadcast reads (one address per 16-lane slot)
 #pragma unroll
       for (int r = 0; r < 6; ++r) {
         const float* rp = img + (2 * py + r) * kC1fPitch + 2 * pxw;
 #pragma unroll
-        for (int k = 0; k < 3; ++k) {
-          const f32x2 v = *reinterpret_cast<const f32x2*>(rp + 2 * k);
-          p[r][2 * k] = v[0];
-          p[r][2 * k + 1] = v[1];
-        }
+        for (int k = 0; k < 3; ++k) p[r][k] = *reinterpret_cast<const f32x2*>(rp + 2 * k);
       }
-      float a[4] = {0.f, 0.f, 0.f, 0.f};
+      auto pix = [&](int r, int x) -> f32x2 { const float v = p[r][x >> 1][x & 1]; return (f32x2){v, v}; };
+      f32x2 a[4] = {{0.f, 0.f}, {0.f, 0.f}, {0.f, 0.f}, {0.f, 0.f}};
 #pragma unroll
       for (int ky = 0; ky < 5; ++ky)
 #pragma unroll
         for (int kx = 0; kx < 5; ++kx) {
-          const float wv = wr[ky * 5 + kx];
-          a[0] = fmaf(p[ky][kx], wv, a[0]);
-          a[1] = fmaf(p[ky][kx + 1], wv, a[1]);
-          a[2] = fmaf(p[ky + 1][kx], wv, a[2]);
-          a[3] = fmaf(p[ky + 1][kx + 1], wv, a[3]);
+          const f32x2 wv = wr[ky * 5 + kx];
+          a[0] = __builtin_elementwise_fma(pix(ky, kx), wv, a[0]);
+          a[1] = __builtin_elementwise_fma(pix(ky, kx + 1), wv, a[1]);
+          a[2] = __builtin_elementwise_fma(pix(ky + 1, kx), wv, a[2]);
+          a[3] = __builtin_elementwise_fma(pix(ky + 1, kx + 1), wv, a[3]);
         }
-      float best = a[0];
-      int bi = 0;
-      if (a[1] > best) { best = a[1]; bi = 1; }
-      if (a[2] > best) { best = a[2]; bi = 2; }
-      if (a[3] > best) { best = a[3]; bi = 3; }
-      const float o = fmaxf(best + bv, 0.f);
+      f32x2 o;
+      unsigned code = 0;
+#pragma unroll
+      for (int e = 0; e < 2; ++e) {
+        float best = a[0][e];
+        int bi = 0;
+        if (a[1][e] > best) { best = a[1][e]; bi = 1; }
+        if (a[2][e] > best) { best = a[2][e]; bi = 2; }
+        if (a[3][e] > best) { best = a[3][e]; bi = 3; }
+        o[e] = fmaxf(best + bv[e], 0.f);
+        code |= (unsigned)(o[e] > 0.f ? bi : (int)kPoolDead) << (8 * e);
+      }
       const size_t off = ((size_t)b * 196 + win) * C + c;
-      pooled[off] = o;
-      arg[off] = (uint8_t)(o > 0.f ? bi : (int)kPoolDead);
+      *reinterpret_cast<f32x2*>(pooled + off) = o;
+      *reinterpret_cast<uint16_t*>(arg + off) = (uint16_t)code;
     }
   }
 }

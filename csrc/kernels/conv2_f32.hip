@@ -59,6 +59,14 @@ __global__ __launch_bounds__(256, 2) void conv5x5_igemm_f32(const float* __restr
   constexpr int KSPLIT = 4 / NTN;                         // K halves (dgrad)
   constexpr int NS = 25 * (KC / 16) / KSPLIT;             // k-block steps per wave and K chunk
   static_assert(KTOT % KC == 0 && NCTOT % NCW == 0, "channel counts must be multiples of the tile");
+  // LASTW (whole-image workgroups): the 13th M tile holds ONE real window, 4 rows of 16.  Every lane of that tile's A
+  // fragment already points at window 48 (clamped), position q = l16 & 3, k = 4g + e -- which is exactly the A operand of
+  // a 4x4x1 MFMA whose sixteen blocks (block = lane >> 2 = 4g + n/4) are [4 channels n/4] x [k group g]; the B fragment
+  // (k = 4g + e, column n) fits the same way.  So tile 13 runs as v_mfma_f32_4x4x1 on the registers the 16x16x4 would
+  // have used: the accumulator of lane (g, n) is then the partial sum over ITS k group, rows = the four positions, and
+  // the four groups are added by two cross-lane steps per image.  13 tiles cost 12.25 instead of 13 (-5.8 % MFMA time).
+  constexpr bool LASTW = (MT == 13);
+  constexpr int MTF = LASTW ? MT - 1 : MT;   // M tiles on the 16x16x4 instruction
   extern __shared__ __attribute__((aligned(16))) float tile[];   // [324][36] (+ the dgrad reduction area)
 
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -154,9 +162,12 @@ __global__ __launch_bounds__(256, 2) void conv5x5_igemm_f32(const float* __restr
 #pragma unroll
         for (int t = 0; t < MT; ++t) a[t] = *reinterpret_cast<const f32x4*>(ap + aoff[t]);
 #pragma unroll
-        for (int e = 0; e < 4; ++e)
+        for (int e = 0; e < 4; ++e) {
 #pragma unroll
-          for (int t = 0; t < MT; ++t) acc[t] = mfma16f(a[t][e], bf[e], acc[t]);
+          for (int t = 0; t < MTF; ++t) acc[t] = mfma16f(a[t][e], bf[e], acc[t]);
+          // the image's 49th window (see LASTW): same operand registers, a quarter of the matrix-pipe time
+          if (LASTW) acc[MT - 1] = mfma4f(a[MT - 1][e], bf[e], acc[MT - 1]);
+        }
       };
       // B fragment of step s+1 requested before the MFMAs of step s; unconditional (the last step re-loads itself)
       f32x4 b0 = load_b(0), b1;
@@ -184,6 +195,16 @@ __global__ __launch_bounds__(256, 2) void conv5x5_igemm_f32(const float* __restr
       // them); only the ksp == 0 wave of a pair stores its result
 #pragma unroll
       for (int t = 0; t < MT; ++t) acc[t] += red[(ntile * MT + t) * 64 + lane];
+    }
+
+    if (LASTW) {   // window 48: sum of the four k groups (lanes n, n + 16, n + 32, n + 48); every lane gets the total
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        float v = acc[MT - 1][r];
+        v += __shfl_xor(v, 16);
+        v += __shfl_xor(v, 32);
+        acc[MT - 1][r] = v;
+      }
     }
 
     // ---- epilogue.  C/D map: lane holds rows 4g + r -> window 4t + g, q = r; column l16 ----

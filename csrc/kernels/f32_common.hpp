@@ -29,6 +29,13 @@ __device__ __forceinline__ f32x4 mfma16f(float a, float b, f32x4 c) {
   return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
 }
 
+// v_mfma_f32_4x4x1_16b_f32: sixteen independent 4x4 outer products, block = lane >> 2; A lane l -> A_block[i = l&3],
+// B lane l -> B_block[j = l&3], C/D 4 regs: col = l&3, rows r.  Two passes (8 cycles) for 512 FLOP: the same
+// 64 FLOP/clk/SIMD with a quarter of the rows of a 16x16x4.
+__device__ __forceinline__ f32x4 mfma4f(float a, float b, f32x4 c) {
+  return __builtin_amdgcn_mfma_f32_4x4x1f32(a, b, c, 0, 0, 0);
+}
+
 __device__ __forceinline__ f32x4 buf_load16f(__amdgpu_buffer_rsrc_t r, uint32_t voff, uint32_t soff) {
   return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, (int)voff, (int)soff, 0));
 }
