@@ -6,13 +6,13 @@
 //
 // conv5x5_igemm_f32 (forward and dgrad), v_mfma_f32_16x16x4_f32, ONE image per 4-wave workgroup:
 //   M = the image's 49 pooling windows x 4 positions, rows ordered m = 4*window + q, so the four accumulator
-//   registers of a lane ARE one pooling window (bias + ReLU + max-pool + argmax in registers) -- 13 M tiles of
-//   4 windows (the last holds one real window: 6 % padding instead of the 12.5 % of row-shaped tiles).
+//   registers of a lane ARE one pooling window (bias + ReLU + max-pool + argmax in registers) -- 12 M tiles of
+//   4 windows and the 49th window on the 4x4x1 instruction (below): no padding.
 //   The zero-haloed 18x18 input tile sits in LDS as [pos][32 ch + 4 pad] floats; the A fragment of tap (ky,kx),
 //   k block kb is one ds_read_b128 of four consecutive channels at a shifted position -- no im2col.
 //   Weights come from a fragment-ordered fp32 pack (pack_conv2_weights_f32): the B fragment of (tap, 16-k block,
 //   16-wide n tile) is one coalesced 1 KiB read, prefetched one step ahead.  A wave owns one 16-channel n tile
-//   and all 13 M tiles: 52 MFMAs (1664 cycles) per k block against 13 LDS reads and one 16-byte load.
+//   and all M tiles: 48 + 4 MFMAs (1568 cycles) per k block against 13 LDS reads and one 16-byte load.
 //   Forward: 64 output channels = 4 waves.  Dgrad (N = 32 input channels): 2 n tiles x 2 K halves (the waves of a
 //   pair take alternate k blocks and are summed through LDS once); the tile is staged through the max-pool /
 //   ReLU gradient (pooled gradient scattered to the saved argmax position) and taps are read flipped.
@@ -42,10 +42,18 @@ enum { F32_MODE_FWD = 0, F32_MODE_DGRAD = 1 };
 //   in   FWD  : x     [B,14,14,KTOT] fp32          DGRAD: gpool [B,7,7,KTOT] fp32 + in_arg [B,7,7,KTOT] u8
 //   wk   fragment-ordered pack for this direction (see pack_conv2_weights_f32)
 //   out  FWD  : pooled [B,7,7,NCTOT] fp32 + out_arg u8      DGRAD: dx [B,14,14,NCTOT] fp32
-// grid = (B, NCTOT / NCW, ceil(13 / MT)): MT = M tiles per workgroup.  13 is the whole image; a small batch (fewer
-// workgroups than CUs: the reference's batch 100) cuts the image into 2 or 3 M ranges (MT = 7 / 5), each workgroup
-// staging the same input tile and running its share of the MFMAs -- the kernel is bound by the per-SIMD matrix pipe,
-// so what matters is how many SIMDs work, not how much is staged twice.
+// grid = (B, NCTOT / NCW, 12 / MT): MT = full (4-window) M tiles per workgroup.  12 is the whole image; a small batch
+// (fewer workgroups than CUs: the reference's batch 100) cuts the image into 2 or 3 M ranges (MT = 6 / 4), each
+// workgroup staging the same input tile and running its share of the MFMAs -- the kernel is bound by the per-SIMD
+// matrix pipe, so what matters is how many SIMDs work, not how much is staged twice.
+//
+// The 49th window: a 13th 16-row tile would hold ONE real window, 4 rows of 16.  With every lane's row clamped to window
+// 48 -- position q = l16 & 3, k = 4g + e -- that tile's A fragment is exactly the A operand of a 4x4x1 MFMA whose
+// sixteen blocks (block = lane >> 2 = 4g + n/4) are [4 channels n/4] x [k group g], and the B fragment (k = 4g + e,
+// column n) fits the same way.  So the window runs as v_mfma_f32_4x4x1 on the registers a 16x16x4 would have used, in
+// a quarter of its matrix-pipe time: the accumulator of lane (g, n) is the partial sum over ITS k group, rows = the
+// four positions, and the four groups are added by two cross-lane steps per image.  An image costs 12.25 tiles, not 13
+// (-11 us per kernel at 1024 images).  Every M range runs it (branch-free k-loop); the last range stores it.
 // ----------------------------------------------------------------------------------------------------
 constexpr int kF32RedBytes = 2 * 13 * 64 * 16;   // dgrad: the K-half partner's 13 accumulator tiles per n tile
 
@@ -59,14 +67,8 @@ __global__ __launch_bounds__(256, 2) void conv5x5_igemm_f32(const float* __restr
   constexpr int KSPLIT = 4 / NTN;                         // K halves (dgrad)
   constexpr int NS = 25 * (KC / 16) / KSPLIT;             // k-block steps per wave and K chunk
   static_assert(KTOT % KC == 0 && NCTOT % NCW == 0, "channel counts must be multiples of the tile");
-  // LASTW (whole-image workgroups): the 13th M tile holds ONE real window, 4 rows of 16.  Every lane of that tile's A
-  // fragment already points at window 48 (clamped), position q = l16 & 3, k = 4g + e -- which is exactly the A operand of
-  // a 4x4x1 MFMA whose sixteen blocks (block = lane >> 2 = 4g + n/4) are [4 channels n/4] x [k group g]; the B fragment
-  // (k = 4g + e, column n) fits the same way.  So tile 13 runs as v_mfma_f32_4x4x1 on the registers the 16x16x4 would
-  // have used: the accumulator of lane (g, n) is then the partial sum over ITS k group, rows = the four positions, and
-  // the four groups are added by two cross-lane steps per image.  13 tiles cost 12.25 instead of 13 (-5.8 % MFMA time).
-  constexpr bool LASTW = (MT == 13);
-  constexpr int MTF = LASTW ? MT - 1 : MT;   // M tiles on the 16x16x4 instruction
+  static_assert(12 % MT == 0, "the 12 full M tiles are cut into equal ranges");
+  constexpr int MTW = MT;   // index of the window-48 fragment / accumulator behind the MT full tiles
   extern __shared__ __attribute__((aligned(16))) float tile[];   // [324][36] (+ the dgrad reduction area)
 
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -75,12 +77,11 @@ __global__ __launch_bounds__(256, 2) void conv5x5_igemm_f32(const float* __restr
   const int t0 = blockIdx.z * MT;   // first M tile of this workgroup
   const int l16 = lane & 15, g = lane >> 4;
 
-  // A row of this lane in M tile t: window 4t + (l16 >> 2), position q = l16 & 3 (windows past 48 are clamped
-  // and their results discarded)
-  int aoff[MT];
+  // A row of this lane in M tile t: window 4t + (l16 >> 2), position q = l16 & 3; entry MT: window 48
+  int aoff[MT + 1];
 #pragma unroll
-  for (int t = 0; t < MT; ++t) {
-    const int wI = min(4 * (t0 + t) + (l16 >> 2), 48), q = l16 & 3;
+  for (int t = 0; t <= MT; ++t) {
+    const int wI = t < MT ? 4 * (t0 + t) + (l16 >> 2) : 48, q = l16 & 3;
     const int pos = (2 * (wI / 7) + (q >> 1)) * kF32TileW + 2 * (wI % 7) + (q & 1);
     aoff[t] = pos * kF32Pitch + 4 * g;
   }
@@ -130,9 +131,9 @@ __global__ __launch_bounds__(256, 2) void conv5x5_igemm_f32(const float* __restr
   if (b < B) issue_loads(b, 0);
 #pragma unroll 1
   for (; b < B; b += gridDim.x) {
-    f32x4 acc[MT];
+    f32x4 acc[MT + 1];
 #pragma unroll
-    for (int t = 0; t < MT; ++t) acc[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    for (int t = 0; t <= MT; ++t) acc[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
 #pragma unroll 1
     for (int kc0 = 0; kc0 < KTOT; kc0 += KC) {
@@ -158,15 +159,14 @@ __global__ __launch_bounds__(256, 2) void conv5x5_igemm_f32(const float* __restr
       auto do_step = [&](int s, const f32x4& bf) {
         const int tap = step_tap(s), kb = step_kb(s);
         const float* ap = tile + ((tap / 5) * kF32TileW + tap % 5) * kF32Pitch + kb * 16;
-        f32x4 a[MT];
+        f32x4 a[MT + 1];
 #pragma unroll
-        for (int t = 0; t < MT; ++t) a[t] = *reinterpret_cast<const f32x4*>(ap + aoff[t]);
+        for (int t = 0; t <= MT; ++t) a[t] = *reinterpret_cast<const f32x4*>(ap + aoff[t]);
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
 #pragma unroll
-          for (int t = 0; t < MTF; ++t) acc[t] = mfma16f(a[t][e], bf[e], acc[t]);
-          // the image's 49th window (see LASTW): same operand registers, a quarter of the matrix-pipe time
-          if (LASTW) acc[MT - 1] = mfma4f(a[MT - 1][e], bf[e], acc[MT - 1]);
+          for (int t = 0; t < MT; ++t) acc[t] = mfma16f(a[t][e], bf[e], acc[t]);
+          acc[MTW] = mfma4f(a[MTW][e], bf[e], acc[MTW]);   // window 48
         }
       };
       // B fragment of step s+1 requested before the MFMAs of step s; unconditional (the last step re-loads itself)
@@ -185,27 +185,27 @@ __global__ __launch_bounds__(256, 2) void conv5x5_igemm_f32(const float* __restr
 
     // ---- K halves summed through LDS (dgrad); its own area behind the tile, so the tile's zero halo survives ----
     if (KSPLIT == 2) {
-      f32x4* red = reinterpret_cast<f32x4*>(reinterpret_cast<char*>(tile) + kF32TileBytes);   // [ntile][13][64 lanes]
+      f32x4* red = reinterpret_cast<f32x4*>(reinterpret_cast<char*>(tile) + kF32TileBytes);   // [ntile][MT + 1][64 lanes]
       if (ksp == 1) {
 #pragma unroll
-        for (int t = 0; t < MT; ++t) red[(ntile * MT + t) * 64 + lane] = acc[t];
+        for (int t = 0; t <= MT; ++t) red[(ntile * (MT + 1) + t) * 64 + lane] = acc[t];
       }
       __syncthreads();
       // every wave adds (branch-free: a conditional update of the accumulators costs a second register copy of
       // them); only the ksp == 0 wave of a pair stores its result
 #pragma unroll
-      for (int t = 0; t < MT; ++t) acc[t] += red[(ntile * MT + t) * 64 + lane];
+      for (int t = 0; t <= MT; ++t) acc[t] += red[(ntile * (MT + 1) + t) * 64 + lane];
     }
 
-    if (LASTW) {   // window 48: sum of the four k groups (lanes n, n + 16, n + 32, n + 48); every lane gets the total
+    // window 48: sum of the four k groups (lanes n, n + 16, n + 32, n + 48); every lane gets the total
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        float v = acc[MT - 1][r];
-        v += __shfl_xor(v, 16);
-        v += __shfl_xor(v, 32);
-        acc[MT - 1][r] = v;
-      }
+    for (int r = 0; r < 4; ++r) {
+      float v = acc[MTW][r];
+      v += __shfl_xor(v, 16);
+      v += __shfl_xor(v, 32);
+      acc[MTW][r] = v;
     }
+    const bool own_w48 = blockIdx.z == gridDim.z - 1;
 
     // ---- epilogue.  C/D map: lane holds rows 4g + r -> window 4t + g, q = r; column l16 ----
     // (the lane's row group is made opaque per image: the store addresses are then recomputed here instead of being
@@ -216,9 +216,9 @@ __global__ __launch_bounds__(256, 2) void conv5x5_igemm_f32(const float* __restr
     if (MODE == F32_MODE_FWD) {
       const float bv = bias[n];
 #pragma unroll
-      for (int t = 0; t < MT; ++t) {
-        const int wI = 4 * (t0 + t) + ge;
-        if (wI < 49) {
+      for (int t = 0; t <= MT; ++t) {
+        const int wI = t < MT ? 4 * (t0 + t) + ge : 48;
+        if (t < MT || (own_w48 && ge == 0)) {
           const f32x4 v = acc[t];
           float best = v[0];
           int bi = 0;
@@ -233,9 +233,9 @@ __global__ __launch_bounds__(256, 2) void conv5x5_igemm_f32(const float* __restr
       }
     } else if (ksp == 0) {
 #pragma unroll
-      for (int t = 0; t < MT; ++t) {
-        const int wI = 4 * (t0 + t) + ge;
-        if (wI < 49) {
+      for (int t = 0; t <= MT; ++t) {
+        const int wI = t < MT ? 4 * (t0 + t) + ge : 48;
+        if (t < MT || (own_w48 && ge == 0)) {
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
             const int y = 2 * (wI / 7) + (r >> 1), x = 2 * (wI % 7) + (r & 1);
@@ -478,7 +478,7 @@ static int launch_igemm_f32_mt(const void* in, const void* in_arg, const void* w
   constexpr int groups = NCTOT / NCW;
   int gx = (2 * f32_cu_count() + groups - 1) / groups;
   if (gx > B) gx = B;
-  hipLaunchKernelGGL(kern, dim3(gx, groups, (13 + MT - 1) / MT), dim3(256), lds, s, (const float*)in,
+  hipLaunchKernelGGL(kern, dim3(gx, groups, 12 / MT), dim3(256), lds, s, (const float*)in,
                      (const uint8_t*)in_arg, (const float*)wk, (const float*)bias, (float*)out, (uint8_t*)out_arg, B);
   return (int)hipGetLastError();
 }
@@ -501,9 +501,9 @@ static int launch_igemm_f32(const void* in, const void* in_arg, const void* wk, 
                             int B, hipStream_t s) {
   constexpr int groups = NCTOT / ((MODE == F32_MODE_FWD) ? 64 : 32);
   switch (f32_msplit(B * groups)) {
-    case 3: return launch_igemm_f32_mt<KTOT, NCTOT, MODE, 5>(in, in_arg, wk, bias, out, out_arg, B, s);
-    case 2: return launch_igemm_f32_mt<KTOT, NCTOT, MODE, 7>(in, in_arg, wk, bias, out, out_arg, B, s);
-    default: return launch_igemm_f32_mt<KTOT, NCTOT, MODE, 13>(in, in_arg, wk, bias, out, out_arg, B, s);
+    case 3: return launch_igemm_f32_mt<KTOT, NCTOT, MODE, 4>(in, in_arg, wk, bias, out, out_arg, B, s);
+    case 2: return launch_igemm_f32_mt<KTOT, NCTOT, MODE, 6>(in, in_arg, wk, bias, out, out_arg, B, s);
+    default: return launch_igemm_f32_mt<KTOT, NCTOT, MODE, 12>(in, in_arg, wk, bias, out, out_arg, B, s);
   }
 }
 
