@@ -15,6 +15,8 @@
 //                 per half-wave: conflict-free).
 // Register-prefetched double buffering, one barrier per K tile: a tile is 2048 cycles of MFMA per wave
 // against ~150 cycles of LDS traffic, so this simple pipeline already leaves the matrix pipe as the bound.
+#include <cstdlib>
+
 #include "f32_common.hpp"
 #include "head_wgrad_core.hpp"
 #include <hip/hip_ext.h>
@@ -31,13 +33,15 @@ enum { F32_EPI_STORE = 0, F32_EPI_SGD = 1 };
 // HEADW: the grid has hw_layers extra z layers whose workgroups compute the output-layer weight gradient
 // (head_wgrad_core.hpp) -- dispatched after the tiles, into the CUs the fc1 dgrad's 200 tiles leave idle, instead of
 // a launch of their own (the bf16 kernel set does the same, gemm.hip HEADW).
-template <int LA, int LB, int EPI, bool HEADW = false>
+template <int LA, int LB, int EPI, bool HEADW = false, int BK = 32>
 __global__ __launch_bounds__(512) void gemm_f32(const float* A, const float* Bm, float* __restrict__ C, int M, int N,
                                                 int K, int lda, int ldb, int ldc, int tiles_per_split,
                                                 const float* __restrict__ hyper,
                                                 HeadWgradArgsT<float> hw = HeadWgradArgsT<float>{}, int hw_guests = 0,
                                                 int hw_layers = 0) {
-  constexpr int BM = 128, BN = 128, BK = 32, NT = 512;
+  constexpr int BM = 128, BN = 128, NT = 512;
+  constexpr int RC = BM * BK / 4 / NT;   // 16-byte staging chunks per thread and operand
+  constexpr int SL = BK / 4;             // 16-byte slots per K-contiguous row
   constexpr int PK = BK + 4;
   constexpr int A_FLOATS = (LA == F32_KCONTIG) ? BM * PK : BK * BM;
   constexpr int B_FLOATS = (LB == F32_KCONTIG) ? BN * PK : BK * BN;
@@ -73,13 +77,13 @@ __global__ __launch_bounds__(512) void gemm_f32(const float* A, const float* Bm,
   // unconditional raw buffer loads: rows past the end of the matrix read as zero
   const __amdgpu_buffer_rsrc_t rA = make_rsrc(A, (LA == F32_KCONTIG ? (size_t)M : (size_t)K) * lda * 4);
   const __amdgpu_buffer_rsrc_t rB = make_rsrc(Bm, (LB == F32_KCONTIG ? (size_t)N : (size_t)K) * ldb * 4);
-  uint32_t va[2], vb[2];
-  int la[2], lb[2];   // LDS float offsets of this thread's two chunks per operand
+  uint32_t va[RC], vb[RC];
+  int la[RC], lb[RC];   // LDS float offsets of this thread's chunks per operand
 #pragma unroll
-  for (int j = 0; j < 2; ++j) {
+  for (int j = 0; j < RC; ++j) {
     const int c = tid + j * NT;
     if (LA == F32_KCONTIG) {
-      const int row = c >> 3, slot = c & 7;
+      const int row = c / SL, slot = c % SL;
       va[j] = (uint32_t)(m0 + row) * (uint32_t)(lda * 4) + slot * 16 + (uint32_t)t_begin * (BK * 4);
       la[j] = row * PK + slot * 4;
     } else {
@@ -88,7 +92,7 @@ __global__ __launch_bounds__(512) void gemm_f32(const float* A, const float* Bm,
       la[j] = row * BM + slot * 4;
     }
     if (LB == F32_KCONTIG) {
-      const int row = c >> 3, slot = c & 7;
+      const int row = c / SL, slot = c % SL;
       vb[j] = (uint32_t)(n0 + row) * (uint32_t)(ldb * 4) + slot * 16 + (uint32_t)t_begin * (BK * 4);
       lb[j] = row * PK + slot * 4;
     } else {
@@ -100,18 +104,18 @@ __global__ __launch_bounds__(512) void gemm_f32(const float* A, const float* Bm,
   const uint32_t stepA = (LA == F32_KCONTIG) ? BK * 4 : (uint32_t)lda * (BK * 4);
   const uint32_t stepB = (LB == F32_KCONTIG) ? BK * 4 : (uint32_t)ldb * (BK * 4);
 
-  f32x4 ra[2], rb[2];
+  f32x4 ra[RC], rb[RC];
   auto gload = [&](int t) {
 #pragma unroll
-    for (int j = 0; j < 2; ++j) ra[j] = buf_load16f(rA, va[j], (uint32_t)t * stepA);
+    for (int j = 0; j < RC; ++j) ra[j] = buf_load16f(rA, va[j], (uint32_t)t * stepA);
 #pragma unroll
-    for (int j = 0; j < 2; ++j) rb[j] = buf_load16f(rB, vb[j], (uint32_t)t * stepB);
+    for (int j = 0; j < RC; ++j) rb[j] = buf_load16f(rB, vb[j], (uint32_t)t * stepB);
   };
   auto swrite = [&](int buf) {
 #pragma unroll
-    for (int j = 0; j < 2; ++j) *reinterpret_cast<f32x4*>(sA + buf * A_FLOATS + la[j]) = ra[j];
+    for (int j = 0; j < RC; ++j) *reinterpret_cast<f32x4*>(sA + buf * A_FLOATS + la[j]) = ra[j];
 #pragma unroll
-    for (int j = 0; j < 2; ++j) *reinterpret_cast<f32x4*>(sB + buf * B_FLOATS + lb[j]) = rb[j];
+    for (int j = 0; j < RC; ++j) *reinterpret_cast<f32x4*>(sB + buf * B_FLOATS + lb[j]) = rb[j];
   };
   auto compute = [&](int buf) {
     const float* a = sA + buf * A_FLOATS;
@@ -195,12 +199,276 @@ __global__ __launch_bounds__(512) void gemm_f32(const float* A, const float* Bm,
   }
 }
 
-template <int LA, int LB, int EPI>
+// ----------------------------------------------------------------------------------------------------
+// gemm_f32_t112: the same products on 128 x 112 (WM: the eight waves split M) or 112 x 128 (the waves split N) tiles of
+// v_mfma_f32_16x16x4_f32 fragments, wave tile 16 x 112 = seven accumulators.  What it is for: fc1's 3136 = 28 * 112
+// features.  128-wide tiles cut them into 24.5 columns -- 200 workgroups for 256 CUs, one round in which 56 CUs have
+// nothing to do -- 112-wide tiles into 28: 224 workgroups of 7/8 the work, the round 12.5 % shorter.
+// (Finer tiles do not help: the round is as long as its longest CU, and 400 half-size workgroups still put two on one.)
+//   K-contiguous operands: [row][32 + 4] floats as above (one ds_read_b128 = four k of a fragment row);
+//   K-slow operands:       [k][112] or [k][128 + 16] floats: consecutive k rows land 48 / 16 floats apart modulo the
+//                          64 banks, so the 4 x 16 lanes of a fragment read are conflict-free (see kslow_row).
+// Per 16 k a wave issues 1 + 7 fragment reads for 28 MFMAs (896 cycles).
+// ----------------------------------------------------------------------------------------------------
+template <int LA, int LB, int EPI, bool WM, bool HEADW = false, int BK = 32>
+__global__ __launch_bounds__(512) void gemm_f32_t112(const float* A, const float* Bm, float* __restrict__ C, int M, int N,
+                                                     int K, int lda, int ldb, int ldc, int tiles_per_split,
+                                                     const float* __restrict__ hyper,
+                                                     HeadWgradArgsT<float> hw = HeadWgradArgsT<float>{}, int hw_guests = 0,
+                                                     int hw_layers = 0) {
+  constexpr int BM = WM ? 128 : 112, BN = WM ? 112 : 128, NT = 512;
+  constexpr int FA = WM ? 1 : 7, FB = WM ? 7 : 1;   // fragments per wave
+  constexpr int PK = BK + 4;
+  constexpr int PA = (BM == 128) ? 144 : 112, PB = (BN == 128) ? 144 : 112;   // K-slow row pitches
+  constexpr int A_FLOATS = (LA == F32_KCONTIG) ? BM * PK : BK * PA;
+  constexpr int B_FLOATS = (LB == F32_KCONTIG) ? BN * PK : BK * PB;
+  constexpr int A_CHUNKS = BM * BK / 4, B_CHUNKS = BN * BK / 4;   // 16-byte staging chunks per tile: 1024 / 896 at BK 32
+  constexpr int RA = (A_CHUNKS + NT - 1) / NT, RB = (B_CHUNKS + NT - 1) / NT;   // staging rounds per thread
+  constexpr int SL = BK / 4;                                                      // 16-byte slots per K-contiguous row
+  extern __shared__ __attribute__((aligned(16))) float smem_f32[];
+  float* sA = smem_f32;                  // [2][A_FLOATS]
+  float* sB = smem_f32 + 2 * A_FLOATS;   // [2][B_FLOATS]
+  if constexpr (HEADW) {
+    static_assert(2 * (A_FLOATS + B_FLOATS) >= head_wgrad_lds_floats<8>(), "head wgrad scratch must fit in the tile buffers");
+    const int first_guest_layer = (int)gridDim.z - hw_layers;
+    if ((int)blockIdx.z >= first_guest_layer) {
+      const int id = (((int)blockIdx.z - first_guest_layer) * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;
+      if (id < hw_guests) head_wgrad_block<8, float>(hw, id % hw.nbx, id / hw.nbx, smem_f32);
+      return;
+    }
+  }
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int i16 = lane & 15, g = lane >> 4;
+  int tile_x, tile_y;
+  xcd_tile(gridDim.x, gridDim.y, tile_x, tile_y);
+  const int m0 = tile_y * BM, n0 = tile_x * BN;
+  const int T_all = (K + BK - 1) / BK;
+  const int t_begin = blockIdx.z * tiles_per_split;
+  const int T = min(T_all, t_begin + tiles_per_split) - t_begin;
+
+  f32x4 acc[FA][FB];
+#pragma unroll
+  for (int fa = 0; fa < FA; ++fa)
+#pragma unroll
+    for (int fb = 0; fb < FB; ++fb) acc[fa][fb] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  // unconditional raw buffer loads: rows past the end of the matrix read as zero
+  const __amdgpu_buffer_rsrc_t rA = make_rsrc(A, (LA == F32_KCONTIG ? (size_t)M : (size_t)K) * lda * 4);
+  const __amdgpu_buffer_rsrc_t rB = make_rsrc(Bm, (LB == F32_KCONTIG ? (size_t)N : (size_t)K) * ldb * 4);
+  uint32_t va[RA], vb[RB];
+  int la[RA], lb[RB];   // LDS float offsets of this thread's chunks per operand
+#pragma unroll
+  for (int j = 0; j < RA; ++j) {
+    {
+      const int c = min(tid + j * NT, A_CHUNKS - 1);
+      if (LA == F32_KCONTIG) {
+        const int row = c / SL, slot = c % SL;
+        va[j] = (uint32_t)(m0 + row) * (uint32_t)(lda * 4) + slot * 16 + (uint32_t)t_begin * (BK * 4);
+        la[j] = row * PK + slot * 4;
+      } else {
+        const int row = c / (BM / 4), slot = c % (BM / 4);
+        va[j] = (uint32_t)(t_begin * BK + row) * (uint32_t)(lda * 4) + (uint32_t)(m0 + slot * 4) * 4;
+        la[j] = row * PA + slot * 4;
+      }
+    }
+  }
+#pragma unroll
+  for (int j = 0; j < RB; ++j) {
+    {
+      const int c = min(tid + j * NT, B_CHUNKS - 1);
+      if (LB == F32_KCONTIG) {
+        const int row = c / SL, slot = c % SL;
+        vb[j] = (uint32_t)(n0 + row) * (uint32_t)(ldb * 4) + slot * 16 + (uint32_t)t_begin * (BK * 4);
+        lb[j] = row * PK + slot * 4;
+      } else {
+        const int row = c / (BN / 4), slot = c % (BN / 4);
+        vb[j] = (uint32_t)(t_begin * BK + row) * (uint32_t)(ldb * 4) + (uint32_t)(n0 + slot * 4) * 4;
+        lb[j] = row * PB + slot * 4;
+      }
+    }
+  }
+  // the 112-row operand's last round is partial: threads past its end load a clamped chunk and drop it
+  const uint32_t stepA = (LA == F32_KCONTIG) ? BK * 4 : (uint32_t)lda * (BK * 4);
+  const uint32_t stepB = (LB == F32_KCONTIG) ? BK * 4 : (uint32_t)ldb * (BK * 4);
+
+  f32x4 ra[RA], rb[RB];
+  auto gload = [&](int t) {
+#pragma unroll
+    for (int j = 0; j < RA; ++j) ra[j] = buf_load16f(rA, va[j], (uint32_t)t * stepA);
+#pragma unroll
+    for (int j = 0; j < RB; ++j) rb[j] = buf_load16f(rB, vb[j], (uint32_t)t * stepB);
+  };
+  auto swrite = [&](int buf) {
+#pragma unroll
+    for (int j = 0; j < RA; ++j)
+      if ((j + 1) * NT <= A_CHUNKS || tid + j * NT < A_CHUNKS) *reinterpret_cast<f32x4*>(sA + buf * A_FLOATS + la[j]) = ra[j];
+#pragma unroll
+    for (int j = 0; j < RB; ++j)
+      if ((j + 1) * NT <= B_CHUNKS || tid + j * NT < B_CHUNKS) *reinterpret_cast<f32x4*>(sB + buf * B_FLOATS + lb[j]) = rb[j];
+  };
+  // fragment element e of lane (i16, g) <-> k = 16 * kb + 4 * g + e, for A and B alike; with both operands K-slow
+  // k = 16 * kb + 4 * e + g instead: the four lane groups of a ds_read_b32 then read CONSECUTIVE k rows (48 / 16 floats
+  // apart modulo the banks) -- rows four apart are a multiple of 64 floats apart with either pitch, a 4-way conflict.
+  constexpr bool KSS = (LA == F32_KSLOW && LB == F32_KSLOW);
+  auto kslow_row = [&](int kb, int e) { return KSS ? kb * 16 + 4 * e + g : kb * 16 + 4 * g + e; };
+  auto compute = [&](int buf) {
+    const float* a = sA + buf * A_FLOATS;
+    const float* b = sB + buf * B_FLOATS;
+#pragma unroll
+    for (int kb = 0; kb < BK / 16; ++kb) {
+      f32x4 av[FA], bv[FB];
+#pragma unroll
+      for (int fa = 0; fa < FA; ++fa) {
+        const int row = (WM ? wave : fa) * 16 + i16;
+        if (LA == F32_KCONTIG) {
+          av[fa] = *reinterpret_cast<const f32x4*>(a + row * PK + kb * 16 + 4 * g);
+        } else {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) av[fa][e] = a[kslow_row(kb, e) * PA + row];
+        }
+      }
+#pragma unroll
+      for (int fb = 0; fb < FB; ++fb) {
+        const int col = (WM ? fb : wave) * 16 + i16;
+        if (LB == F32_KCONTIG) {
+          bv[fb] = *reinterpret_cast<const f32x4*>(b + col * PK + kb * 16 + 4 * g);
+        } else {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) bv[fb][e] = b[kslow_row(kb, e) * PB + col];
+        }
+      }
+#pragma unroll
+      for (int e = 0; e < 4; ++e)
+#pragma unroll
+        for (int fa = 0; fa < FA; ++fa)
+#pragma unroll
+          for (int fb = 0; fb < FB; ++fb) acc[fa][fb] = mfma16f(av[fa][e], bv[fb][e], acc[fa][fb]);
+    }
+  };
+
+  if (T > 0) {
+    gload(0);
+    swrite(0);
+    __syncthreads();
+    for (int t = 0; t < T; ++t) {
+      gload(t + 1);   // in flight during this tile's MFMAs; unconditional (see gemm_f32)
+      __builtin_amdgcn_sched_barrier(0);
+      compute(t & 1);
+      swrite((t + 1) & 1);
+      __syncthreads();
+    }
+  }
+
+  // C/D map of a 16x16 fragment: col = lane & 15, row = 4 * (lane >> 4) + r
+  float* Cz = C + (EPI == F32_EPI_STORE ? (size_t)blockIdx.z * M * ldc : 0);
+  if (EPI == F32_EPI_SGD) {
+    // fused update of the fp32 weight (see gemm_f32): all 28 weights of the lane are requested before the first store
+    const float lr = hyper[0] * hyper[4];
+    f32x4 w[FA][FB];
+#pragma unroll
+    for (int fa = 0; fa < FA; ++fa)
+#pragma unroll
+      for (int fb = 0; fb < FB; ++fb) {
+        const int col = min(n0 + (WM ? fb : wave) * 16 + i16, N - 1);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int row = min(m0 + (WM ? wave : fa) * 16 + 4 * g + r, M - 1);
+          w[fa][fb][r] = __builtin_nontemporal_load(Cz + (size_t)row * ldc + col);
+        }
+      }
+#pragma unroll
+    for (int fa = 0; fa < FA; ++fa)
+#pragma unroll
+      for (int fb = 0; fb < FB; ++fb) {
+        const int col = n0 + (WM ? fb : wave) * 16 + i16;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int row = m0 + (WM ? wave : fa) * 16 + 4 * g + r;
+          if (row < M && col < N) Cz[(size_t)row * ldc + col] = fmaf(-lr, acc[fa][fb][r], w[fa][fb][r]);
+        }
+      }
+  } else {
+#pragma unroll
+    for (int fa = 0; fa < FA; ++fa)
+#pragma unroll
+      for (int fb = 0; fb < FB; ++fb) {
+        const int col = n0 + (WM ? fb : wave) * 16 + i16;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int row = m0 + (WM ? wave : fa) * 16 + 4 * g + r;
+          if (row < M && col < N) Cz[(size_t)row * ldc + col] = acc[fa][fb][r];
+        }
+      }
+  }
+}
+
+// Which tiling a product gets: the rounds of workgroups it takes on this device times the work of one workgroup.
+static int f32_gemm_cus() {
+  static int cus = 0;
+  if (!cus) {
+    int dev = 0;
+    hipDeviceProp_t prop;
+    if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) cus = prop.multiProcessorCount;
+    if (cus <= 0) cus = 256;
+  }
+  return cus;
+}
+static int g_f32_t112_forced = -2;   // -1: by shape; 0 | 1: forced by DTF_F32_T112 (A/B runs) or dtf_gemm_f32_force_t112 (tests)
+static bool f32_use_t112(int M, int N, bool wm) {
+  if (g_f32_t112_forced == -2) {
+    const char* v = getenv("DTF_F32_T112");
+    g_f32_t112_forced = (v && *v) ? atoi(v) : -1;
+  }
+  if (g_f32_t112_forced >= 0) return g_f32_t112_forced != 0;
+  // K-slow operands (TN, fc1 wgrad) pay four ds_read_b32 per fragment where a K-contiguous one pays one ds_read_b128:
+  // with seven fragments per wave that eats the shorter round (72.6 / 71.5 us against the 128 x 128 kernel's 71.0)
+  if (!wm) return false;
+  const long cus = f32_gemm_cus();
+  const long t128 = (long)((M + 127) / 128) * ((N + 127) / 128);
+  const long t112 = wm ? (long)((M + 127) / 128) * ((N + 111) / 112) : (long)((M + 111) / 112) * ((N + 127) / 128);
+  return ((t112 + cus - 1) / cus) * 112 < ((t128 + cus - 1) / cus) * 128;
+}
+
+static bool f32_bk64() {   // DTF_F32_BK64=0: 32-deep K tiles everywhere (A/B runs)
+  static int v = -1;
+  if (v < 0) {
+    const char* e = getenv("DTF_F32_BK64");
+    v = (e && *e) ? (atoi(e) != 0) : 1;
+  }
+  return v != 0;
+}
+
+template <int LA, int LB, int EPI, bool WM, int BK = 32>
+constexpr size_t f32_t112_lds() {
+  constexpr int BM = WM ? 128 : 112, BN = WM ? 112 : 128;
+  return (size_t)(2 * ((LA == F32_KCONTIG) ? BM * (BK + 4) : BK * (BM == 128 ? 144 : 112)) +
+                  2 * ((LB == F32_KCONTIG) ? BN * (BK + 4) : BK * (BN == 128 ? 144 : 112))) * 4;
+}
+
+template <int LA, int LB, int EPI, bool WM, int BK = 32>
+static int launch_gemm_f32_t112(const void* A, const void* B, void* C, int M, int N, int K, int lda, int ldb, int ldc,
+                                const void* hyper, hipStream_t s, hipEvent_t done = nullptr) {
+  constexpr size_t lds = f32_t112_lds<LA, LB, EPI, WM, BK>();
+  constexpr int BM = WM ? 128 : 112, BN = WM ? 112 : 128;
+  auto kern = gemm_f32_t112<LA, LB, EPI, WM, false, BK>;
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    attr_set = true;
+  }
+  hipExtLaunchKernelGGL(kern, dim3((N + BN - 1) / BN, (M + BM - 1) / BM, 1), dim3(512), lds, s, nullptr, done, 0,
+                        (const float*)A, (const float*)B, (float*)C, M, N, K, lda, ldb, ldc, (K + 31) / 32,
+                        (const float*)hyper, HeadWgradArgsT<float>{}, 0, 0);
+  return (int)hipGetLastError();
+}
+
+template <int LA, int LB, int EPI, int BK = 32>
 static int launch_gemm_f32(const void* A, const void* B, void* C, int M, int N, int K, int lda, int ldb, int ldc, int S,
                            int tps, const void* hyper, hipStream_t s, hipEvent_t done = nullptr) {
-  constexpr int PK = 36;
-  constexpr size_t lds = (2 * ((LA == F32_KCONTIG) ? 128 * PK : 32 * 128) + 2 * ((LB == F32_KCONTIG) ? 128 * PK : 32 * 128)) * 4;
-  auto kern = gemm_f32<LA, LB, EPI>;
+  constexpr int PK = BK + 4;
+  constexpr size_t lds = (2 * ((LA == F32_KCONTIG) ? 128 * PK : BK * 128) + 2 * ((LB == F32_KCONTIG) ? 128 * PK : BK * 128)) * 4;
+  auto kern = gemm_f32<LA, LB, EPI, false, BK>;
   static bool attr_set = false;
   if (!attr_set) {
     (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -237,9 +505,20 @@ int dtf_gemm_f32_nn_partial(const void* A, const void* B, void* part, int M, int
   return rc == 0 ? S : -1;
 }
 
+// tiling of the NT / TN products: 1 = 112-wide tiles, 0 = 128 x 128, -1 = chosen by shape (the default)
+int dtf_gemm_f32_force_t112(int mode) {
+  g_f32_t112_forced = mode < 0 ? -1 : (mode != 0);
+  return 0;
+}
+
 // C[M,N] = A[M,K] . B[N,K]^T  (fc1 dgrad: A = dh1, B = wd1)
 int dtf_gemm_f32_nt(const void* A, const void* B, void* C, int M, int N, int K, int lda, int ldb, int ldc, hipStream_t s) {
   if ((K & 31) || (lda & 3) || (ldb & 3)) return -3;
+  if (f32_use_t112(M, N, true)) {
+    if (K % 64 == 0 && f32_bk64())
+      return launch_gemm_f32_t112<F32_KCONTIG, F32_KCONTIG, F32_EPI_STORE, true, 64>(A, B, C, M, N, K, lda, ldb, ldc, nullptr, s);
+    return launch_gemm_f32_t112<F32_KCONTIG, F32_KCONTIG, F32_EPI_STORE, true>(A, B, C, M, N, K, lda, ldb, ldc, nullptr, s);
+  }
   return launch_gemm_f32<F32_KCONTIG, F32_KCONTIG, F32_EPI_STORE>(A, B, C, M, N, K, lda, ldb, ldc, 1, K / 32, nullptr, s);
 }
 
@@ -259,7 +538,8 @@ int dtf_gemm_f32_nt_head_wgrad(const void* A, const void* B, void* splitk_part, 
   if (S > T) S = T;
   const int tps = (T + S - 1) / S;
   S = (T + tps - 1) / tps;
-  const int gx = (N + 127) / 128, gy = (M + 127) / 128;
+  const bool t112 = S == 1 && f32_use_t112(M, N, true);
+  const int gx = t112 ? (N + 111) / 112 : (N + 127) / 128, gy = (M + 127) / 128;
   const long tiles = (long)gx * gy, wgs = tiles * S;
   const int nbx = (H + kHeadCols - 1) / kHeadCols;
   const long guests = (long)nbx * KS;
@@ -271,6 +551,21 @@ int dtf_gemm_f32_nt_head_wgrad(const void* A, const void* B, void* splitk_part, 
   }
   HeadWgradArgsT<float> hw{(const float*)h1, (const float*)dlogits, (const float*)da, (float*)part, Bsz, H,
                            (Bsz + KS - 1) / KS, nbx};
+  if (t112) {
+    const bool bk64 = K % 64 == 0 && f32_bk64();
+    const size_t lds112 = bk64 ? f32_t112_lds<F32_KCONTIG, F32_KCONTIG, F32_EPI_STORE, true, 64>()
+                               : f32_t112_lds<F32_KCONTIG, F32_KCONTIG, F32_EPI_STORE, true, 32>();
+    auto kern112 = bk64 ? gemm_f32_t112<F32_KCONTIG, F32_KCONTIG, F32_EPI_STORE, true, true, 64>
+                        : gemm_f32_t112<F32_KCONTIG, F32_KCONTIG, F32_EPI_STORE, true, true, 32>;
+    static bool attr112_set[2] = {false, false};
+    if (!attr112_set[bk64]) {
+      (void)hipFuncSetAttribute((const void*)kern112, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds112);
+      attr112_set[bk64] = true;
+    }
+    hipLaunchKernelGGL(kern112, dim3(gx, gy, 1 + layers), dim3(512), lds112, s, (const float*)A, (const float*)B, (float*)C, M,
+                       N, K, lda, ldb, ldc, tps, (const float*)nullptr, hw, (int)guests, layers);
+    return hipGetLastError() == hipSuccess ? 0 : -1;
+  }
   constexpr size_t lds = (size_t)(4 * 128 * 36) * 4;
   auto kern = gemm_f32<F32_KCONTIG, F32_KCONTIG, F32_EPI_STORE, true>;
   static bool attr_set = false;
@@ -316,6 +611,11 @@ int dtf_gemm_f32_tn_ev(const void* A, const void* B, void* C, int M, int N, int 
                        const void* hyper, hipEvent_t done, hipStream_t s) {
   if ((lda & 3) || (ldb & 3) || (M & 3) || (N & 3)) return -3;
   const int T = (K + 31) / 32;
+  if (f32_use_t112(M, N, false)) {
+    if (hyper) return launch_gemm_f32_t112<F32_KSLOW, F32_KSLOW, F32_EPI_SGD, false>(A, B, C, M, N, K, lda, ldb, ldc, hyper, s, done);
+    return launch_gemm_f32_t112<F32_KSLOW, F32_KSLOW, F32_EPI_STORE, false>(A, B, C, M, N, K, lda, ldb, ldc, nullptr, s, done);
+  }
+  // (64-deep K tiles, launch_gemm_f32<.., 64>: 73.1 us against 71.2 for this product -- not the barriers, then)
   if (hyper) return launch_gemm_f32<F32_KSLOW, F32_KSLOW, F32_EPI_SGD>(A, B, C, M, N, K, lda, ldb, ldc, 1, T, hyper, s, done);
   return launch_gemm_f32<F32_KSLOW, F32_KSLOW, F32_EPI_STORE>(A, B, C, M, N, K, lda, ldb, ldc, 1, T, nullptr, s, done);
 }

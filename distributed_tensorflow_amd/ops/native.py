@@ -121,6 +121,7 @@ _SIGS = {
     "dtf_conv2_f32_dgrad": [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p],
     "dtf_conv2_f32_wgrad": [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p],
     "dtf_gemm_f32_nn_partial": [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p],
+    "dtf_gemm_f32_force_t112": [c_int],
     "dtf_gemm_f32_nt": [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p],
     "dtf_gemm_f32_nt_head_wgrad": [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_int,
                                    c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p],

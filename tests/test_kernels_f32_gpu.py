@@ -54,8 +54,19 @@ def test_gemm_f32_nn_partial(gpu_lib, M, N, K, S):
     assert rel_err(got, A.double() @ Bm.double()) < TOL
 
 
-@pytest.mark.parametrize("M,N,K", [(1024, 3136, 1024), (100, 3136, 1024), (257, 192, 64), (64, 64, 128), (5, 130, 32)])
-def test_gemm_f32_nt(gpu_lib, M, N, K):
+@pytest.fixture
+def tiling(gpu_lib, request):
+    """Both tilings of the NT / TN products on every shape: 128 x 128 (0) and the 112-wide tiles (1); the library picks
+    by shape otherwise (-1, restored afterwards)."""
+    gpu_lib.dtf_gemm_f32_force_t112(request.param)
+    yield request.param
+    gpu_lib.dtf_gemm_f32_force_t112(-1)
+
+
+@pytest.mark.parametrize("tiling", [0, 1, -1], indirect=True)
+@pytest.mark.parametrize("M,N,K", [(1024, 3136, 1024), (100, 3136, 1024), (257, 192, 64), (64, 64, 128), (5, 130, 32),
+                                   (300, 230, 96)])
+def test_gemm_f32_nt(gpu_lib, M, N, K, tiling):
     g = torch.Generator(device="cpu").manual_seed(5)
     A = torch.randn(M, K, generator=g).to(DEV)
     Bm = (torch.randn(N, K, generator=g) * 0.05 + torch.arange(N).float()[:, None] * 1e-3).to(DEV)
@@ -83,8 +94,10 @@ def test_gemm_f32_nt_splitk(gpu_lib, M, N, K, S):
         assert gpu_lib.dtf_gemm_f32_nt_splitk(ptr(A), ptr(Bm), ptr(part), ptr(C), M, N, K, K, K, N + 4, S, stream()) == -3
 
 
-@pytest.mark.parametrize("M,N,K", [(3136, 1024, 100), (3136, 1024, 256), (200, 136, 1000), (128, 128, 64), (36, 260, 7)])
-def test_gemm_f32_tn_and_fused_sgd(gpu_lib, M, N, K):
+@pytest.mark.parametrize("tiling", [0, 1, -1], indirect=True)
+@pytest.mark.parametrize("M,N,K", [(3136, 1024, 100), (3136, 1024, 256), (200, 136, 1000), (128, 128, 64), (36, 260, 7),
+                                   (236, 300, 33)])
+def test_gemm_f32_tn_and_fused_sgd(gpu_lib, M, N, K, tiling):
     g = torch.Generator(device="cpu").manual_seed(7)
     A = (torch.randn(K, M, generator=g) + torch.arange(M).float()[None, :] * 1e-3).to(DEV)
     Bm = torch.randn(K, N, generator=g).to(DEV)
