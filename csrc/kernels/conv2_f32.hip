@@ -38,6 +38,20 @@ constexpr int kF32TileBytes = kF32TilePos * kF32Pitch * 4;   // 46656
 
 enum { F32_MODE_FWD = 0, F32_MODE_DGRAD = 1 };
 
+// -DDTF_F32_TIMING=1 (tools/conv_f32_timeline.py): wave 0 of every workgroup stamps the 100 MHz wall clock into
+// g_f32_timing[workgroup][16]: 0 start; per image n: 1+4n at the staging barrier, 2+4n tile staged, 3+4n left the k-loop,
+// 4+4n stores issued.  The release build has no trace of it.
+#if DTF_F32_TIMING
+__device__ long long* g_f32_timing;
+#define F32_STAMP(slot)                                                                                            \
+  do {                                                                                                             \
+    if (g_f32_timing && threadIdx.x == 0 && (slot) < 16)                                                           \
+      g_f32_timing[((size_t)blockIdx.y * gridDim.x + blockIdx.x) * 16 + (slot)] = __builtin_amdgcn_s_memrealtime(); \
+  } while (0)
+#else
+#define F32_STAMP(slot) do { } while (0)
+#endif
+
 // ----------------------------------------------------------------------------------------------------
 //   in   FWD  : x     [B,14,14,KTOT] fp32          DGRAD: gpool [B,7,7,KTOT] fp32 + in_arg [B,7,7,KTOT] u8
 //   wk   fragment-ordered pack for this direction (see pack_conv2_weights_f32)
@@ -128,7 +142,9 @@ __global__ __launch_bounds__(256, 2) void conv5x5_igemm_f32(const float* __restr
   };
 
   int b = blockIdx.x;
+  F32_STAMP(0);
   if (b < B) issue_loads(b, 0);
+  [[maybe_unused]] int img_n = 0;
 #pragma unroll 1
   for (; b < B; b += gridDim.x) {
     f32x4 acc[MT + 1];
@@ -137,9 +153,11 @@ __global__ __launch_bounds__(256, 2) void conv5x5_igemm_f32(const float* __restr
 
 #pragma unroll 1
     for (int kc0 = 0; kc0 < KTOT; kc0 += KC) {
+      F32_STAMP(1 + 4 * img_n);
       __syncthreads();   // zero fill done / previous unit's k-loop (and reduction reads) finished
       write_tile();
       __syncthreads();
+      F32_STAMP(2 + 4 * img_n);
       {   // next unit's loads fly during this unit's k-loop
         const bool more_k = kc0 + KC < KTOT;
         const int nb = more_k ? b : b + (int)gridDim.x;
@@ -183,6 +201,7 @@ __global__ __launch_bounds__(256, 2) void conv5x5_igemm_f32(const float* __restr
       }
     }
 
+    F32_STAMP(3 + 4 * img_n);
     // ---- K halves summed through LDS (dgrad); its own area behind the tile, so the tile's zero halo survives ----
     if (KSPLIT == 2) {
       f32x4* red = reinterpret_cast<f32x4*>(reinterpret_cast<char*>(tile) + kF32TileBytes);   // [ntile][MT + 1][64 lanes]
@@ -244,6 +263,8 @@ __global__ __launch_bounds__(256, 2) void conv5x5_igemm_f32(const float* __restr
         }
       }
     }
+    F32_STAMP(4 + 4 * img_n);
+    ++img_n;
   }
 }
 
@@ -477,6 +498,9 @@ static int launch_igemm_f32_mt(const void* in, const void* in_arg, const void* w
   constexpr int NCW = (MODE == F32_MODE_FWD) ? 64 : 32;
   constexpr int groups = NCTOT / NCW;
   int gx = (2 * f32_cu_count() + groups - 1) / groups;
+#if DTF_F32_TIMING
+  if (const char* v = getenv("DTF_F32_WG_PER_CU")) gx = (atoi(v) * f32_cu_count() + groups - 1) / groups;   // timeline experiments
+#endif
   if (gx > B) gx = B;
   hipLaunchKernelGGL(kern, dim3(gx, groups, 12 / MT), dim3(256), lds, s, (const float*)in,
                      (const uint8_t*)in_arg, (const float*)wk, (const float*)bias, (float*)out, (uint8_t*)out_arg, B);
@@ -529,6 +553,13 @@ static int launch_wgrad_f32(const void* x, const void* gpool, const void* arg, v
 }
 
 extern "C" {
+
+#if DTF_F32_TIMING
+int dtf_conv2_f32_set_timing_buf(void* p) {
+  long long* q = (long long*)p;
+  return (int)hipMemcpyToSymbol(HIP_SYMBOL(dtf::g_f32_timing), &q, sizeof(q));
+}
+#endif
 
 // packed (2 * 25*cin*cout fp32) = [fwd pack | dgrad pack] of the fp32 HWIO weights w
 int dtf_conv2_f32_pack_weights(const void* w, void* packed, int cin, int cout, hipStream_t s) {
