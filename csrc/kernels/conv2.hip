@@ -37,6 +37,18 @@
 #define DTF_DGRAD_CFG 64, 32, 32, 2, 1, MODE_DGRAD, 3
 #endif
 
+// ... and of the widened 128->256 layer (NC is the layer's whole N: the launch has no channel groups).  dgrad walks its
+// 256 reduction channels in 64-channel chunks: a 47 KiB tile lets three 4-wave workgroups share a CU where the
+// 128-channel tile (89 KiB) allowed one -- dgrad 286 -> ~215 us, step 1.378 -> 1.296 ms on one device
+// (tools/scratch/ab_wide_cfg.sh; 32-channel chunks 1.300, 8 waves per image 1.348 / 1.294 with 128 / 64 channels, two
+// images per workgroup 1.31-1.33; forward: 64- or 32-channel chunks and 4 waves per image are neutral or worse).
+#ifndef DTF_WIDE_FWD_CFG
+#define DTF_WIDE_FWD_CFG 128, 128, 256, 1, 4, MODE_FWD
+#endif
+#ifndef DTF_WIDE_DGRAD_CFG
+#define DTF_WIDE_DGRAD_CFG 256, 64, 128, 1, 2, MODE_DGRAD
+#endif
+
 namespace dtf {
 
 constexpr int kTileW = 18;          // 14 + 2*2 halo
@@ -1230,7 +1242,12 @@ static int launch_igemm(const void* in, const void* in_arg, const void* wk,
   constexpr size_t fwd_extra = (size_t)IMGS * kC1ImgElems * 2 + (size_t)IMGS * 2 * NW * (1024 + 512);
   // fused conv1 wgrad: dx + shifted image copies + half a gradient tile, aliased over the (dead) conv2 tile
   constexpr size_t c1w_lds = (size_t)IMGS * 196 * NC * 2 + kCpBytes + (size_t)kFusedC1wDyRows * kDy1RowBytes;
-  constexpr size_t lds = !FUSE1 ? tile_lds : (MODE == MODE_FWD ? tile_lds + fwd_extra : (tile_lds > c1w_lds ? tile_lds : c1w_lds));
+  // the epilogue stages the results in the (dead) tile: [IMGS][49][NC] bf16 + argmax bytes forward, [IMGS][196][NC] bf16
+  // dgrad -- with a K chunk narrower than the layer's N that can be MORE than the tile (wide dgrad, 64-channel chunks:
+  // 47 KiB of tile, 49 KiB of dx)
+  constexpr size_t epi_lds = MODE == MODE_FWD ? (size_t)IMGS * 49 * NC * 3 : (size_t)IMGS * 196 * NC * 2;
+  constexpr size_t plain_lds = tile_lds > epi_lds ? tile_lds : epi_lds;
+  constexpr size_t lds = !FUSE1 ? plain_lds : (MODE == MODE_FWD ? tile_lds + fwd_extra : (tile_lds > c1w_lds ? tile_lds : c1w_lds));
   auto kern = conv5x5_igemm<KTOT, KC, NC, IMGS, NW, MODE, MINW, FUSE1>;
   static bool attr_set = false;
   if (!attr_set) {
@@ -1298,7 +1315,7 @@ int dtf_conv2_fwd(const void* x, const void* wT, const void* bias, void* pooled,
   if (cin == 32 && cout == 64)
     return launch_igemm<DTF_FWD_CFG>(x, nullptr, wT, bias, pooled, arg, B, s);
   if (cin == 128 && cout == 256)
-    return launch_igemm<128, 128, 256, 1, 4, MODE_FWD>(x, nullptr, wT, bias, pooled, arg, B, s);
+    return launch_igemm<DTF_WIDE_FWD_CFG>(x, nullptr, wT, bias, pooled, arg, B, s);
   return -1;
 }
 
@@ -1326,7 +1343,7 @@ int dtf_conv2_dgrad(const void* gpool, const void* arg, const void* w, void* dx,
   if (cin == 32 && cout == 64)
     return launch_igemm<DTF_DGRAD_CFG>(gpool, arg, w, nullptr, dx, nullptr, B, s);
   if (cin == 128 && cout == 256)
-    return launch_igemm<256, 128, 128, 1, 2, MODE_DGRAD>(gpool, arg, w, nullptr, dx, nullptr, B, s);
+    return launch_igemm<DTF_WIDE_DGRAD_CFG>(gpool, arg, w, nullptr, dx, nullptr, B, s);
   return -1;
 }
 
