@@ -1,12 +1,9 @@
 // First conv block in exact fp32 (--dtype fp32): 5x5 SAME conv with ONE input channel + bias + ReLU +
 // 2x2 max-pool + argmax code (reference .idea/MNISTDist.py:71-73), and its filter/bias gradient.
 //
-// With C_in = 1 the layer has K = 25: at fp32 the matrix cores run at exactly the vector rate (64 FLOP/clk/SIMD),
-// so padding K to MFMA shapes can only lose.  Both kernels are direct VALU stencils with lane = output channel:
-//   * forward: 16 lanes x 2 channels own one pooling window at a time; the window's 6x6 input patch is read
-//     from a zero-haloed LDS image as broadcast ds_read_b64 (all 16 lanes the same address), the 25 filter taps
-//     of the lane's channel pair live in registers (packed FMAs), and conv + bias + ReLU + pool + argmax never
-//     leave registers; stores are 128 contiguous bytes per window.
+// With C_in = 1 the layer has K = 25: at fp32 the matrix cores run at exactly the (packed) vector rate, 64 FLOP/clk/SIMD.
+//   * forward: implicit GEMM on v_mfma_f32_16x16x4_f32 with K padded to 28 (see the kernel): what the matrix core
+//     saves is instruction issue, not FLOPs; conv + bias + ReLU + pool + argmax never leave registers.
 //   * wgrad: the pooled gradient reaches exactly ONE of the four positions of a window (the saved argmax), so
 //     dW[tap][c] += g * x[argmax position + tap] is 25 FMAs per (window, channel) instead of 100 -- the
 //     max-pool/ReLU gradient is never expanded.  Lanes gather their 25 pixels from LDS at their own argmax
@@ -30,32 +27,46 @@ __device__ __forceinline__ void c1f_store_px(float* img, int i4, const f32x4& v)
   *reinterpret_cast<f32x2*>(d + 2) = (f32x2){v[2], v[3]};
 }
 
-// grid = (min(B, ..), C/32, NS), 256 threads = 16 window slots of 16 lanes.  w: fp32 HWIO [25][C].  gridDim.z = NS
-// workgroups share an image's 196 pooling windows (small batches: one workgroup per image is 100 workgroups on 256 CUs
-// at batch 100).
+// grid = (min(B, ..), C/32, NS), 256 threads = 4 waves.  w: fp32 HWIO [25][C].  gridDim.z = NS workgroups share an
+// image's 49 M tiles (small batches: one workgroup per image is 100 workgroups on 256 CUs at batch 100).
 //
-// Lane = TWO adjacent output channels: every FMA of the stencil is then a v_pk_fma_f32 (pixel splat x the channel
-// pair's tap weights), which is the only way to the full fp32 vector rate -- a scalar-per-lane v_fma_f32 runs at half
-// of it, and this kernel is VALU-bound (100 FMAs per window and channel).  The FMA order per channel is unchanged
-// (taps in ky, kx order), so the results are bit-for-bit those of the one-channel-per-lane kernel.
-// Window w = 16 * round + 4 * wave' + slot: round 12 holds the last 4 windows only, given to a different wave from
-// workgroup to workgroup (wave' = (wave + blockIdx.x) & 3) so that the co-resident workgroups of a CU do not all
-// leave their 13th round on the same SIMD.
+// On the matrix cores (v_mfma_f32_16x16x4_f32), K = 25 taps padded to 28: at fp32 they are no faster than packed VALU
+// FMAs (64 FLOP/clk/SIMD either way), but an MFMA needs ONE instruction per 2048 FLOP where the stencil needs one per
+// 256 and a patch of 36 registers.  Measured against the packed-FMA stencil it replaced (lane = two channels, 100
+// v_pk_fma_f32 per window; itself 29.0 -> 24.2 us against the one-channel-per-lane stencil): kernel 24.2 -> 21.7 us,
+// step unchanged at 1024 images and -1.2 % at 100 -- 10.7 us of matrix pipe per SIMD instead of 14 us of VALU issue,
+// and a workgroup's life (sampler, image fetch, 13 tiles per wave, stores) that neither version overlaps any better
+// with fewer, fatter workgroups (grids of 768 / 512 / 256: +0 / +1 / +6 us).  M = the image's 196 pooling windows x 4 positions, rows m = 4 * window + q
+// as in the conv2 kernels, so the four accumulator registers of a lane are one window: 49 M tiles, no padding.
+//   A fragment (step s): lane (row i, k group g) reads pixel [position of row i + tap 4s + g] from the zero-haloed LDS
+//     image -- one ds_read_b32 per step and tile, its tap offset a per-lane constant; taps 25..27 read any pixel
+//     (their weights are zero).
+//   B fragments: w[tap 4s + g][channel], 7 steps x 2 n tiles = 14 registers, loaded once per workgroup.
+// A tile is 7 reads + 14 MFMAs (448 cycles) + ~25 VALU instructions of epilogue; tile t of an image goes to wave
+// (t + blockIdx.x) & 3, so the co-resident workgroups of a CU do not all leave their 13th tile on the same SIMD.
 __global__ __launch_bounds__(256) void conv1_pool_fwd_f32(const float* __restrict__ images, const int* __restrict__ idx,
                                                           SampleArgs smp, const float* __restrict__ w,
                                                           const float* __restrict__ bias, float* __restrict__ pooled,
                                                           uint8_t* __restrict__ arg, int B, int C) {
-  typedef __attribute__((ext_vector_type(2))) float f32x2;
   __shared__ __attribute__((aligned(16))) float img[kC1fElems];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int c = blockIdx.y * 32 + 2 * (lane & 15);
-  const int slot = 4 * ((wave + (int)blockIdx.x) & 3) + (lane >> 4);
+  const int j = lane & 15, g = lane >> 4;
+  const int c0 = blockIdx.y * 32 + j;
+  const int wslot = (wave + (int)blockIdx.x) & 3;
 
   const SampleCursor cur = sample_cursor(smp);
-  f32x2 wr[25];
+  float bw[7][2];
+  int tapoff[7];
 #pragma unroll
-  for (int t = 0; t < 25; ++t) wr[t] = *reinterpret_cast<const f32x2*>(w + t * C + c);
-  const f32x2 bv = *reinterpret_cast<const f32x2*>(bias + c);
+  for (int s = 0; s < 7; ++s) {
+    const int k = 4 * s + g;
+    tapoff[s] = k < 25 ? (k / 5) * kC1fPitch + k % 5 : 0;
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt) bw[s][nt] = k < 25 ? w[k * C + c0 + 16 * nt] : 0.f;
+  }
+  const float bv[2] = {bias[c0], bias[c0 + 16]};
+  // row i = lane & 15 of a tile: window 4t + (i >> 2), position q = i & 3
+  const int wi = j >> 2, q = j & 3;
   for (int i = tid; i < kC1fElems / 4; i += 256) reinterpret_cast<f32x4*>(img)[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
   f32x4 px = {0.f, 0.f, 0.f, 0.f};
@@ -68,43 +79,32 @@ __global__ __launch_bounds__(256) void conv1_pool_fwd_f32(const float* __restric
     __syncthreads();   // previous image consumed / zero fill done
     if (tid < 196) c1f_store_px(img, tid, px);
     __syncthreads();
-    if (b + (int)gridDim.x < B) fetch(b + gridDim.x);   // next image's pixels fly during this one's stencil
-    for (int win = slot + 16 * (int)blockIdx.z; win < 196; win += 16 * (int)gridDim.z) {
-      const int py = win / 14, pxw = win % 14;
-      f32x2 p[6][3];   // the window's 6x6 input patch: broadcast reads (one address per 16-lane slot)
+    if (b + (int)gridDim.x < B) fetch(b + gridDim.x);   // next image's pixels fly during this one's tiles
+    for (int t = wslot + 4 * (int)blockIdx.z; t < 49; t += 4 * (int)gridDim.z) {
+      const int W = 4 * t + wi, py = W / 14, pxw = W % 14;
+      const float* ap = img + (2 * py + (q >> 1)) * kC1fPitch + 2 * pxw + (q & 1);
+      float a[7];
 #pragma unroll
-      for (int r = 0; r < 6; ++r) {
-        const float* rp = img + (2 * py + r) * kC1fPitch + 2 * pxw;
+      for (int s = 0; s < 7; ++s) a[s] = ap[tapoff[s]];
+      f32x4 acc[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
 #pragma unroll
-        for (int k = 0; k < 3; ++k) p[r][k] = *reinterpret_cast<const f32x2*>(rp + 2 * k);
-      }
-      auto pix = [&](int r, int x) -> f32x2 { const float v = p[r][x >> 1][x & 1]; return (f32x2){v, v}; };
-      f32x2 a[4] = {{0.f, 0.f}, {0.f, 0.f}, {0.f, 0.f}, {0.f, 0.f}};
+      for (int s = 0; s < 7; ++s)
 #pragma unroll
-      for (int ky = 0; ky < 5; ++ky)
+        for (int nt = 0; nt < 2; ++nt) acc[nt] = mfma16f(a[s], bw[s][nt], acc[nt]);
+      // C/D: lane (column j, group g) holds rows 4g + r = window 4t + g, position q = r
+      const size_t off = ((size_t)b * 196 + 4 * t + g) * C + c0;
 #pragma unroll
-        for (int kx = 0; kx < 5; ++kx) {
-          const f32x2 wv = wr[ky * 5 + kx];
-          a[0] = __builtin_elementwise_fma(pix(ky, kx), wv, a[0]);
-          a[1] = __builtin_elementwise_fma(pix(ky, kx + 1), wv, a[1]);
-          a[2] = __builtin_elementwise_fma(pix(ky + 1, kx), wv, a[2]);
-          a[3] = __builtin_elementwise_fma(pix(ky + 1, kx + 1), wv, a[3]);
-        }
-      f32x2 o;
-      unsigned code = 0;
-#pragma unroll
-      for (int e = 0; e < 2; ++e) {
-        float best = a[0][e];
+      for (int nt = 0; nt < 2; ++nt) {
+        const f32x4 v = acc[nt];
+        float best = v[0];
         int bi = 0;
-        if (a[1][e] > best) { best = a[1][e]; bi = 1; }
-        if (a[2][e] > best) { best = a[2][e]; bi = 2; }
-        if (a[3][e] > best) { best = a[3][e]; bi = 3; }
-        o[e] = fmaxf(best + bv[e], 0.f);
-        code |= (unsigned)(o[e] > 0.f ? bi : (int)kPoolDead) << (8 * e);
+        if (v[1] > best) { best = v[1]; bi = 1; }
+        if (v[2] > best) { best = v[2]; bi = 2; }
+        if (v[3] > best) { best = v[3]; bi = 3; }
+        const float o = fmaxf(best + bv[nt], 0.f);
+        pooled[off + 16 * nt] = o;
+        arg[off + 16 * nt] = (uint8_t)(o > 0.f ? bi : (int)kPoolDead);
       }
-      const size_t off = ((size_t)b * 196 + win) * C + c;
-      *reinterpret_cast<f32x2*>(pooled + off) = o;
-      *reinterpret_cast<uint16_t*>(arg + off) = (uint16_t)code;
     }
   }
 }
