@@ -15,6 +15,9 @@ run python bench.py --force_dp --optimizer adam --steps 500 --warmup 50 --no_fp3
 run python bench.py --per_gpu_batch 100 --steps 1000 --warmup 50
 run python bench.py --per_gpu_batch 4096 --steps 200 --warmup 20
 run python bench.py --model wide --steps 100 --warmup 10 --no_fp32
+run python bench.py --dtype fp32 --per_gpu_batch 100 --steps 1000 --warmup 50
+run python bench.py --dtype fp32 --per_gpu_batch 4096 --steps 100 --warmup 10
+run python bench.py --dtype fp32 --model wide --steps 30 --warmup 5
 echo "## tools/scratch/dp_host.py" >> $OUT
 timeout -k 10 200 python tools/scratch/dp_host.py 2>/dev/null | grep "host" >> $OUT
 cat $OUT | cut -c1-330

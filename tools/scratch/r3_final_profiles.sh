@@ -13,6 +13,8 @@ run() {  # tag, env assignment or "-", bench args...
 }
 run bf16_1024 - --no_fp32 --no_graph --single_stream &&
 run fp32_1024 - --dtype fp32 --no_graph --single_stream &&
+run fp32_100 - --dtype fp32 --no_graph --single_stream --per_gpu_batch 100 &&
+run wide_bf16_1024 - --model wide --no_fp32 --no_graph --single_stream &&
 run dp1_collapsed - --force_dp --no_fp32 &&
 run dp1_full_kernels - --force_dp --no_collapse --no_fp32 &&
 run dp1_shard_of_8 DTF_DP_FAKE_WORLD=8 --force_dp --no_collapse --no_fp32
