@@ -150,6 +150,12 @@ int dtf_gemm_f32_tn_ev(const void* A, const void* B, void* C, int M, int N, int 
                        const void* hyper, hipEvent_t done, hipStream_t s);
 int dtf_gemm_f32_tn(const void* A, const void* B, void* C, int M, int N, int K, int lda, int ldb, int ldc,
                     const void* hyper, hipStream_t s);
+// stream-K variant (gemm_f32.hip gemm_f32_sk) and its per-engine uncached workspace; ws == NULL: the plain launch
+int dtf_gemm_f32_tn_sk(const void* A, const void* B, void* C, int M, int N, int K, int lda, int ldb, int ldc,
+                       const void* hyper, void* ws, hipEvent_t done, hipStream_t s);
+long dtf_gemm_f32_sk_workspace_bytes();
+void* dtf_gemm_f32_sk_workspace_alloc();
+void dtf_gemm_f32_sk_workspace_free(void* p);
 int dtf_head_f32_fwd_bwd(const void* h1, const void* wT, const void* bias, const void* labels, const void* idx,
                          void* logits_out, void* loss_rows, void* correct_rows, void* dlogits, void* da, int B, int H,
                          float grad_scale, float inv_keep, int backward, hipStream_t s);

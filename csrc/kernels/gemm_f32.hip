@@ -19,6 +19,7 @@
 
 #include "f32_common.hpp"
 #include "head_wgrad_core.hpp"
+#include "peer_store.hpp"
 #include <hip/hip_ext.h>
 
 // csrc/kernels/optim.hip: sums part[G][stride] slabs into out (the split-K dgrad below reuses it)
@@ -403,6 +404,255 @@ __global__ __launch_bounds__(512) void gemm_f32_t112(const float* A, const float
   }
 }
 
+// ----------------------------------------------------------------------------------------------------
+// gemm_f32_sk: stream-K over the 128 x 128 x 32 kernel's tiles, for products whose tiles do not fill the chip --
+// fc1 wgrad is 25 x 8 = 200 tiles for 256 CUs.  The (tile, k-tile) iterations are laid end to end -- 200 x T, T = K / 32
+// -- and cut into one equal range per CU (25 T / 32 iterations: 25 at 1024 images).  A range spans at most two tiles:
+// it finishes the tile it starts in (as that tile's OWNER, unless it started it), then begins the next one and hands
+// that beginning over as a partial sum.  XCD-aligned: workgroup w = (blockIdx % 8) * 32 + blockIdx / 8, so the 32 ranges
+// of an XCD are consecutive and cover exactly 25 whole tiles -- owner and contributors of a tile always sit on one XCD,
+// and an owner only ever waits for LOWER-numbered workgroups of its own XCD (all of them resident: one workgroup per CU).
+// Hand-over: the contributor writes its 64 KiB accumulator tile into its slot of an UNCACHED workspace with
+// write-through stores, waits for them (vmcnt 0: no fence, see peer_store.hpp) and sets its flag; the owner -- which ran
+// and published the part IT hands over before the part it finishes -- polls the flag(s), adds the partial
+// sums in ascending-k order (a fixed order: results are deterministic), clears the flags for the next launch (graph
+// replay needs no per-launch argument) and runs the normal epilogue.  Bounded polls: a broken launch computes
+// garbage, it does not hang.
+// ----------------------------------------------------------------------------------------------------
+struct F32SkArgs {
+  float* ws;         // [workgroups][128 * 128] partial tiles
+  unsigned* flags;   // [workgroups], zero between launches
+  int T, tiles_x, ipw;
+};
+
+template <int LA, int LB, int EPI>
+__global__ __launch_bounds__(512) void gemm_f32_sk(const float* A, const float* Bm, float* __restrict__ C, int M, int N,
+                                                   int K, int lda, int ldb, int ldc, const float* __restrict__ hyper,
+                                                   F32SkArgs sk) {
+  constexpr int BM = 128, BN = 128, BK = 32, NT = 512;
+  constexpr int PK = BK + 4;
+  constexpr int A_FLOATS = (LA == F32_KCONTIG) ? BM * PK : BK * BM;
+  constexpr int B_FLOATS = (LB == F32_KCONTIG) ? BN * PK : BK * BN;
+  extern __shared__ __attribute__((aligned(16))) float smem_f32[];
+  float* sA = smem_f32;                  // [2][A_FLOATS]
+  float* sB = smem_f32 + 2 * A_FLOATS;   // [2][B_FLOATS]
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave >> 2, wn = wave & 3;
+  const int i32 = lane & 31, h = lane >> 5;
+  const int nwg = gridDim.x;
+  const int w = ((int)blockIdx.x % 8) * (nwg / 8) + (int)blockIdx.x / 8;
+  const long g0 = (long)w * sk.ipw;
+  const int t0 = (int)(g0 / sk.T), ka = (int)(g0 % sk.T);
+  const int n1 = min(sk.T - ka, sk.ipw);   // iterations in the tile the range starts in
+  const int n2 = sk.ipw - n1;              // ... and at the head of the next one
+
+  const __amdgpu_buffer_rsrc_t rA = make_rsrc(A, (LA == F32_KCONTIG ? (size_t)M : (size_t)K) * lda * 4);
+  const __amdgpu_buffer_rsrc_t rB = make_rsrc(Bm, (LB == F32_KCONTIG ? (size_t)N : (size_t)K) * ldb * 4);
+  const uint32_t stepA = (LA == F32_KCONTIG) ? BK * 4 : (uint32_t)lda * (BK * 4);
+  const uint32_t stepB = (LB == F32_KCONTIG) ? BK * 4 : (uint32_t)ldb * (BK * 4);
+
+  // staging addresses of a segment (tile, first k-tile); the LDS offsets of a thread's two chunks are the same for all
+  int la[2], lb[2];
+  auto seg_addr = [&](int tile, int kbeg, uint32_t (&va)[2], uint32_t (&vb)[2]) {
+    const int m0 = (tile / sk.tiles_x) * BM, n0 = (tile % sk.tiles_x) * BN;
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int c = tid + j * NT;
+      if (LA == F32_KCONTIG) {
+        const int row = c >> 3, slot = c & 7;
+        va[j] = (uint32_t)(m0 + row) * (uint32_t)(lda * 4) + slot * 16 + (uint32_t)kbeg * (BK * 4);
+        la[j] = row * PK + slot * 4;
+      } else {
+        const int row = c >> 5, slot = c & 31;
+        va[j] = (uint32_t)(kbeg * BK + row) * (uint32_t)(lda * 4) + (uint32_t)(m0 + slot * 4) * 4;
+        la[j] = row * BM + slot * 4;
+      }
+      if (LB == F32_KCONTIG) {
+        const int row = c >> 3, slot = c & 7;
+        vb[j] = (uint32_t)(n0 + row) * (uint32_t)(ldb * 4) + slot * 16 + (uint32_t)kbeg * (BK * 4);
+        lb[j] = row * PK + slot * 4;
+      } else {
+        const int row = c >> 5, slot = c & 31;
+        vb[j] = (uint32_t)(kbeg * BK + row) * (uint32_t)(ldb * 4) + (uint32_t)(n0 + slot * 4) * 4;
+        lb[j] = row * BN + slot * 4;
+      }
+    }
+  };
+  f32x4 ra[2], rb[2];
+  auto gload = [&](const uint32_t (&va)[2], const uint32_t (&vb)[2], int t) {
+#pragma unroll
+    for (int j = 0; j < 2; ++j) ra[j] = buf_load16f(rA, va[j], (uint32_t)t * stepA);
+#pragma unroll
+    for (int j = 0; j < 2; ++j) rb[j] = buf_load16f(rB, vb[j], (uint32_t)t * stepB);
+  };
+  auto swrite = [&](int buf) {
+#pragma unroll
+    for (int j = 0; j < 2; ++j) *reinterpret_cast<f32x4*>(sA + buf * A_FLOATS + la[j]) = ra[j];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) *reinterpret_cast<f32x4*>(sB + buf * B_FLOATS + lb[j]) = rb[j];
+  };
+  f32x16 acc[2];
+  auto zero_acc = [&]() {
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[mt][r] = 0.f;
+  };
+  auto compute = [&](int buf) {
+    const float* a = sA + buf * A_FLOATS;
+    const float* b = sB + buf * B_FLOATS;
+#pragma unroll
+    for (int kb = 0; kb < BK / 8; ++kb) {
+      f32x4 av[2], bv;
+#pragma unroll
+      for (int mt = 0; mt < 2; ++mt) {
+        const int row = wm * 64 + mt * 32 + i32;
+        if (LA == F32_KCONTIG) {
+          av[mt] = *reinterpret_cast<const f32x4*>(a + row * PK + kb * 8 + 4 * h);
+        } else {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) av[mt][e] = a[(kb * 8 + 4 * h + e) * BM + row];
+        }
+      }
+      {
+        const int col = wn * 32 + i32;
+        if (LB == F32_KCONTIG) {
+          bv = *reinterpret_cast<const f32x4*>(b + col * PK + kb * 8 + 4 * h);
+        } else {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) bv[e] = b[(kb * 8 + 4 * h + e) * BN + col];
+        }
+      }
+#pragma unroll
+      for (int e = 0; e < 4; ++e)
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt) acc[mt] = mfma32f(av[mt][e], bv[e], acc[mt]);
+    }
+  };
+
+  // this thread's 32 accumulator values as eight 16-byte pieces of the slot: piece p of thread tid at (p * 512 + tid)
+  auto put_partial = [&]() {
+    f32x4* dst = reinterpret_cast<f32x4*>(sk.ws + (size_t)w * (BM * BN));
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+      for (int q = 0; q < 4; ++q)
+        dp_put16(dst + (mt * 4 + q) * NT + tid, (f32x4){acc[mt][4 * q], acc[mt][4 * q + 1], acc[mt][4 * q + 2], acc[mt][4 * q + 3]});
+    dp_puts_done();
+    __syncthreads();
+    if (tid == 0) uc_store(sk.flags + w, 1u);
+  };
+  auto epilogue = [&](int tile) {
+    // C/D map of the 32x32 tile: col = lane & 31, row = (r & 3) + 8 * (r >> 2) + 4 * h
+    const int m0 = (tile / sk.tiles_x) * BM, n0 = (tile % sk.tiles_x) * BN;
+    const int col = n0 + wn * 32 + i32;
+    if (col >= N) return;
+    if (EPI == F32_EPI_SGD) {
+      const float lr = hyper[0] * hyper[4];
+      float wv[2][16];
+#pragma unroll
+      for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int row = min(m0 + wm * 64 + mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * h, M - 1);
+          wv[mt][r] = __builtin_nontemporal_load(C + (size_t)row * ldc + col);
+        }
+#pragma unroll
+      for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int row = m0 + wm * 64 + mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+          if (row < M) C[(size_t)row * ldc + col] = fmaf(-lr, acc[mt][r], wv[mt][r]);
+        }
+    } else {
+#pragma unroll
+      for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int row = m0 + wm * 64 + mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+          if (row < M) C[(size_t)row * ldc + col] = acc[mt][r];
+        }
+    }
+  };
+
+  // ONE software pipeline over the range's iterations, the handed-over part FIRST (its owner then finds the partial sum
+  // written, acknowledged and flagged long before it needs it, instead of every owner starting to wait when every
+  // contributor starts to write): iterations [0, nS0) are the head of tile t0 + 1, the rest k-tiles ka.. of tile t0; the
+  // first k-tile of the second part is requested under the last MFMAs of the first, so the switch costs no prologue.
+  const bool finishes = ka + n1 == sk.T;
+  const int nS0 = finishes ? n2 : 0, nI = nS0 + n1;
+  uint32_t va0[2], vb0[2], va1[2], vb1[2];
+  seg_addr(t0 + 1, 0, va0, vb0);
+  seg_addr(t0, ka, va1, vb1);
+  auto gload_it = [&](int it) {
+    if (it < nS0) gload(va0, vb0, it);
+    else gload(va1, vb1, it - nS0);   // (past the range: the tile's next k-tile or zeros, never multiplied)
+  };
+  zero_acc();
+  gload_it(0);
+  swrite(0);
+  __syncthreads();
+  for (int it = 0; it < nI; ++it) {
+    gload_it(it + 1);
+    __builtin_amdgcn_sched_barrier(0);
+    compute(it & 1);
+    if (it + 1 == nS0) {   // the head of tile t0 + 1 is complete: hand it over
+      put_partial();
+      zero_acc();
+    }
+    swrite((it + 1) & 1);
+    __syncthreads();
+  }
+  if (!finishes) {   // the range lies inside one tile: a contributor only
+    put_partial();
+    return;
+  }
+  if (ka > 0) {
+    // owner of tile t0: the k-tiles [0, ka) come from the ranges before this one, earliest first
+    const int nc = (ka + sk.ipw - 1) / sk.ipw;
+    if (tid == 0) {
+      for (int j = nc; j >= 1; --j)
+        for (int spin = 0; spin < (1 << 22) && uc_load(sk.flags + (w - j)) != 1u; ++spin) __builtin_amdgcn_s_sleep(2);
+    }
+    __syncthreads();
+    f32x4 sum[8];
+#pragma unroll
+    for (int p8 = 0; p8 < 8; ++p8) sum[p8] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    for (int j = nc; j >= 1; --j) {
+      const unsigned* src = reinterpret_cast<const unsigned*>(sk.ws + (size_t)(w - j) * (BM * BN));
+      // all eight 16-byte pieces in flight, ONE wait (uc_load4 waits per load: eight dependent round trips to memory)
+      f32x4 v[8];
+      const unsigned* q0 = src + (size_t)tid * 4;
+      asm volatile(
+          "global_load_dwordx4 %0, %8, off sc0 sc1\n\t"
+          "global_load_dwordx4 %1, %9, off sc0 sc1\n\t"
+          "global_load_dwordx4 %2, %10, off sc0 sc1\n\t"
+          "global_load_dwordx4 %3, %11, off sc0 sc1\n\t"
+          "global_load_dwordx4 %4, %12, off sc0 sc1\n\t"
+          "global_load_dwordx4 %5, %13, off sc0 sc1\n\t"
+          "global_load_dwordx4 %6, %14, off sc0 sc1\n\t"
+          "global_load_dwordx4 %7, %15, off sc0 sc1\n\t"
+          "s_waitcnt vmcnt(0)"
+          : "=&v"(v[0]), "=&v"(v[1]), "=&v"(v[2]), "=&v"(v[3]), "=&v"(v[4]), "=&v"(v[5]), "=&v"(v[6]), "=&v"(v[7])
+          : "v"(q0), "v"(q0 + 1 * NT * 4), "v"(q0 + 2 * NT * 4), "v"(q0 + 3 * NT * 4), "v"(q0 + 4 * NT * 4),
+            "v"(q0 + 5 * NT * 4), "v"(q0 + 6 * NT * 4), "v"(q0 + 7 * NT * 4)
+          : "memory");
+#pragma unroll
+      for (int p8 = 0; p8 < 8; ++p8) sum[p8] = (j == nc) ? v[p8] : sum[p8] + v[p8];
+    }
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+      for (int q = 0; q < 4; ++q)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) acc[mt][4 * q + e] = sum[mt * 4 + q][e] + acc[mt][4 * q + e];
+    __syncthreads();   // every thread has read its pieces
+    if (tid == 0)
+      for (int j = nc; j >= 1; --j) uc_store(sk.flags + (w - j), 0u);
+  }
+  epilogue(t0);
+}
+
 // Which tiling a product gets: the rounds of workgroups it takes on this device times the work of one workgroup.
 static int f32_gemm_cus() {
   static int cus = 0;
@@ -622,6 +872,62 @@ int dtf_gemm_f32_tn_ev(const void* A, const void* B, void* C, int M, int N, int 
 int dtf_gemm_f32_tn(const void* A, const void* B, void* C, int M, int N, int K, int lda, int ldb, int ldc,
                     const void* hyper, hipStream_t s) {
   return dtf_gemm_f32_tn_ev(A, B, C, M, N, K, lda, ldb, ldc, hyper, nullptr, s);
+}
+
+// Stream-K workspace (gemm_f32_sk): uncached device memory, [256 partial tiles of 64 KiB | 256 flag words], zeroed.
+// One per engine (two engines may run this product on two streams at once).
+long dtf_gemm_f32_sk_workspace_bytes() { return 256L * 128 * 128 * 4 + 4096; }
+void* dtf_gemm_f32_sk_workspace_alloc() {
+  void* p = nullptr;
+  const size_t bytes = (size_t)dtf_gemm_f32_sk_workspace_bytes();
+  if (hipExtMallocWithFlags(&p, bytes, hipDeviceMallocUncached) != hipSuccess) {
+    (void)hipGetLastError();
+    return nullptr;
+  }
+  if (hipMemset(p, 0, bytes) != hipSuccess) {
+    (void)hipGetLastError();
+    (void)hipFree(p);
+    return nullptr;
+  }
+  return p;
+}
+void dtf_gemm_f32_sk_workspace_free(void* p) {
+  if (p) (void)hipFree(p);
+}
+
+// The same product as dtf_gemm_f32_tn_ev; ws != NULL (a workspace from dtf_gemm_f32_sk_workspace_alloc): stream-K over
+// the tiles when they leave CUs idle and the iterations divide evenly (fc1 wgrad: 3136 x 1024, K = a multiple of 1024
+// images), otherwise -- and with DTF_F32_TN_SK=0 -- the plain launch.
+int dtf_gemm_f32_tn_sk(const void* A, const void* B, void* C, int M, int N, int K, int lda, int ldb, int ldc,
+                       const void* hyper, void* ws, hipEvent_t done, hipStream_t s) {
+  static int enabled = -1;
+  if (enabled < 0) {
+    const char* v = getenv("DTF_F32_TN_SK");
+    enabled = (v && *v) ? (atoi(v) != 0) : 1;
+  }
+  const int cus = f32_gemm_cus();
+  const int tx = (N + 127) / 128, ty = (M + 127) / 128, T = (K + 31) / 32;
+  const long tiles = (long)tx * ty, total = tiles * T;
+  const bool fits = ws && enabled && !(lda & 3) && !(ldb & 3) && !(M & 3) && !(N & 3) && cus == 256 && tiles < cus &&
+                    tiles % 8 == 0 && total % cus == 0 && total / cus <= T && 4 * tiles >= 3 * cus;
+  if (!fits) return dtf_gemm_f32_tn_ev(A, B, C, M, N, K, lda, ldb, ldc, hyper, done, s);
+  F32SkArgs sk{(float*)ws, (unsigned*)((char*)ws + 256L * 128 * 128 * 4), T, tx, (int)(total / cus)};
+  constexpr size_t lds = (size_t)(4 * 32 * 128) * 4;
+#define SK_LAUNCH(EPI_)                                                                                             \
+  do {                                                                                                              \
+    auto kern = gemm_f32_sk<F32_KSLOW, F32_KSLOW, EPI_>;                                                            \
+    static bool attr_set = false;                                                                                   \
+    if (!attr_set) {                                                                                                \
+      (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);           \
+      attr_set = true;                                                                                              \
+    }                                                                                                               \
+    hipExtLaunchKernelGGL(kern, dim3(cus), dim3(512), lds, s, nullptr, done, 0, (const float*)A, (const float*)B,   \
+                          (float*)C, M, N, K, lda, ldb, ldc, (const float*)hyper, sk);                              \
+  } while (0)
+  if (hyper) SK_LAUNCH(F32_EPI_SGD);
+  else SK_LAUNCH(F32_EPI_STORE);
+#undef SK_LAUNCH
+  return (int)hipGetLastError();
 }
 
 }  // extern "C"

@@ -37,6 +37,7 @@ struct DtfEngineDesc {
   hipStream_t side1, side2;
   hipEvent_t ev_head, ev_fork, ev_join1, ev_join2, ev_dgrad;
   hipEvent_t ev_dense_ready, ev_dense_updated, ev_tail_ready, ev_tail_reduced;  // data-parallel step
+  void* sk_ws;   // fp32: uncached stream-K workspace of the fc1 wgrad GEMM (gemm_f32.hip gemm_f32_sk), or NULL
 };
 
 #define DTF_TRY(x)            \
@@ -73,6 +74,7 @@ int dtf_engine_init(DtfEngineDesc* e) {
   // hole in the compute stream behind each record that follows a 12.8 MB producer (the fc1 GEMMs).
   const unsigned flags = hipEventDisableTiming | ((DTF_EXP_DP & 8) ? 0u : (unsigned)hipEventReleaseToDevice);
   for (auto ev : evs) HIP_TRY(hipEventCreateWithFlags(ev, flags));
+  e->sk_ws = is_f32(e) ? dtf_gemm_f32_sk_workspace_alloc() : nullptr;   // NULL (no uncached memory): the plain launch
   return 0;
 }
 
@@ -83,6 +85,8 @@ int dtf_engine_destroy(DtfEngineDesc* e) {
     if (ev) (void)hipEventDestroy(ev);
   if (e->side1) (void)hipStreamDestroy(e->side1);
   if (e->side2) (void)hipStreamDestroy(e->side2);
+  dtf_gemm_f32_sk_workspace_free(e->sk_ws);
+  e->sk_ws = nullptr;
   return 0;
 }
 
@@ -212,8 +216,8 @@ static int backward_dense_impl(const DtfEngineDesc* e, int reduce, hipStream_t s
     DTF_TRY(dtf_reduce_segments(1, part, out, G, n, st, s));
   }
   if (is_f32(e))
-    return dtf_gemm_f32_tn_ev(e->p2, e->da, f32at(e->grads, e->off_wd1), e->flat, e->hidden, e->B, e->flat, e->hidden,
-                              e->hidden, nullptr, done, s);
+    return dtf_gemm_f32_tn_sk(e->p2, e->da, f32at(e->grads, e->off_wd1), e->flat, e->hidden, e->B, e->flat, e->hidden,
+                              e->hidden, nullptr, e->sk_ws, done, s);
   if (g16)
     return dtf_gemm_tn_g16_ev(e->p2, e->da, e->dense_g16, e->flat, e->hidden, e->B, e->flat, e->hidden, e->hidden, done, s);
   return dtf_gemm_tn_ev(e->p2, e->da, f32at(e->grads, e->off_wd1), e->flat, e->hidden, e->B, e->flat, e->hidden,
@@ -367,8 +371,8 @@ static int train_tail_fused_dense(const DtfEngineDesc* e, long step_inc, hipStre
     s2 = e->side2;
   }
   if (is_f32(e))
-    DTF_TRY(dtf_gemm_f32_tn(e->p2, e->da, f32at(e->params, e->off_wd1), e->flat, e->hidden, e->B, e->flat, e->hidden,
-                            e->hidden, e->hyper, s1));
+    DTF_TRY(dtf_gemm_f32_tn_sk(e->p2, e->da, f32at(e->params, e->off_wd1), e->flat, e->hidden, e->B, e->flat, e->hidden,
+                               e->hidden, e->hyper, e->sk_ws, nullptr, s1));
   else
     DTF_TRY(dtf_gemm_tn_sgd(e->p2, e->da, f32at(e->params, e->off_wd1), bf16at(e->shadow, e->off_wd1), e->hyper, e->flat,
                             e->hidden, e->B, e->flat, e->hidden, e->hidden, s1));
@@ -536,8 +540,8 @@ int dtf_engine_dp_step(const DtfEngineDesc* e, const DtfDpFabric* f, int collaps
   const bool local_dense = f->world == 1 && collapse_world1 && adam;
   if (collapsed) {
     if (is_f32(e))
-      DTF_TRY(dtf_gemm_f32_tn(e->p2, e->da, f32at(e->params, e->off_wd1), e->flat, e->hidden, e->B, e->flat, e->hidden,
-                              e->hidden, e->hyper, s));
+      DTF_TRY(dtf_gemm_f32_tn_sk(e->p2, e->da, f32at(e->params, e->off_wd1), e->flat, e->hidden, e->B, e->flat, e->hidden,
+                                 e->hidden, e->hyper, e->sk_ws, nullptr, s));
     else
       DTF_TRY(dtf_gemm_tn_sgd(e->p2, e->da, f32at(e->params, e->off_wd1), bf16at(e->shadow, e->off_wd1), e->hyper, e->flat,
                               e->hidden, e->B, e->flat, e->hidden, e->hidden, s));

@@ -128,6 +128,11 @@ _SIGS = {
     "dtf_gemm_f32_nt_splitk": [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_int,
                                c_void_p],
     "dtf_gemm_f32_tn": [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p],
+    "dtf_gemm_f32_tn_sk": [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p,
+                           c_void_p, c_void_p],
+    "dtf_gemm_f32_sk_workspace_bytes": [],
+    "dtf_gemm_f32_sk_workspace_alloc": [],
+    "dtf_gemm_f32_sk_workspace_free": [c_void_p],
     "dtf_head_f32_fwd_bwd": [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                              c_void_p, c_void_p, c_int, c_int, c_float, c_float, c_int, c_void_p],
     "dtf_head_f32_fused_fwd_bwd": [c_void_p, c_int, c_void_p, c_float, c_uint64, c_void_p, c_void_p, c_void_p, c_void_p,
@@ -153,7 +158,7 @@ class EngineDesc(ctypes.Structure):
                                    "ds_images",
                                    "ds_labels")]
         + [(n, c_void_p) for n in ("side1", "side2", "ev_head", "ev_fork", "ev_join1", "ev_join2", "ev_dgrad",
-                                   "ev_dense_ready", "ev_dense_updated", "ev_tail_ready", "ev_tail_reduced")]
+                                   "ev_dense_ready", "ev_dense_updated", "ev_tail_ready", "ev_tail_reduced", "sk_ws")]
     )
 
 
@@ -207,7 +212,10 @@ def load() -> ctypes.CDLL:
     for name, argtypes in list(_SIGS.items()) + list(_ENGINE_SIGS.items()):
         fn = getattr(lib, name)
         fn.argtypes = argtypes
-        fn.restype = c_long if name in ("dtf_p2p_bytes", "dtf_p2p2_bytes", "dtf_dp_fabric_layout", "dtf_ps_ctl_bytes") else c_int
+        fn.restype = (c_long if name in ("dtf_p2p_bytes", "dtf_p2p2_bytes", "dtf_dp_fabric_layout", "dtf_ps_ctl_bytes",
+                                         "dtf_gemm_f32_sk_workspace_bytes")
+                      else c_void_p if name == "dtf_gemm_f32_sk_workspace_alloc"
+                      else None if name == "dtf_gemm_f32_sk_workspace_free" else c_int)
     lib.dtf_build_flavour.restype = c_char_p
     lib.dtf_build_flavour.argtypes = []
     flavour = lib.dtf_build_flavour().decode()

@@ -115,6 +115,52 @@ def test_gemm_f32_tn_and_fused_sgd(gpu_lib, M, N, K, tiling):
     assert float((W - want).abs().max()) <= 2e-7 * float(W0.abs().max() + lr * C.abs().max())
 
 
+@pytest.mark.parametrize("K", [1024, 2048, 100])
+def test_gemm_f32_tn_stream_k(gpu_lib, K):
+    """fc1 wgrad as stream-K (gemm_f32_sk): 200 tiles x K/32 iterations cut into 256 equal ranges, partial tiles handed
+    over through the uncached workspace.  Against fp64; two runs bitwise equal (fixed summation order); the flags are
+    back to zero (graph replay needs no per-launch argument); the fused SGD epilogue; K = 100 falls back to the plain
+    launch (the iterations do not divide)."""
+    M, N = 3136, 1024
+    g = torch.Generator(device="cpu").manual_seed(17)
+    A = (torch.randn(K, M, generator=g) + torch.arange(M).float()[None, :] * 1e-3).to(DEV)
+    Bm = torch.randn(K, N, generator=g).to(DEV)
+    ws = gpu_lib.dtf_gemm_f32_sk_workspace_alloc()
+    assert ws
+    try:
+        ref = A.double().t() @ Bm.double()
+        outs = []
+        for _ in range(2):
+            C = torch.full((M, N), float("nan"), device=DEV)
+            check(gpu_lib.dtf_gemm_f32_tn_sk(ptr(A), ptr(Bm), ptr(C), M, N, K, M, N, N, None, ws, None, stream()), "tn_sk")
+            torch.cuda.synchronize()
+            assert bool(torch.isfinite(C).all())
+            assert rel_err(C, ref) < TOL
+            outs.append(C)
+        assert torch.equal(outs[0], outs[1])
+        plain = torch.empty(M, N, device=DEV)
+        check(gpu_lib.dtf_gemm_f32_tn(ptr(A), ptr(Bm), ptr(plain), M, N, K, M, N, N, None, stream()), "tn")
+        if K % 1024:
+            assert torch.equal(plain, outs[0])          # the fallback IS the plain kernel
+        hyper = torch.tensor([0.05, 0.9, 0.999, 1e-8, 0.5, 0.0, 0.0, 0.0], device=DEV)
+        W0 = torch.randn(M, N, generator=g).to(DEV)
+        W = W0.clone()
+        check(gpu_lib.dtf_gemm_f32_tn_sk(ptr(A), ptr(Bm), ptr(W), M, N, K, M, N, N, ptr(hyper), ws, None, stream()), "tn_sk sgd")
+        lr = float(hyper[0] * hyper[4])
+        want = torch.addcmul(W0.double(), outs[0].double(), torch.tensor(-lr, dtype=torch.float64, device=DEV)).float()
+        assert float((W - want).abs().max()) <= 2e-7 * float(W0.abs().max() + lr * outs[0].abs().max())
+        import ctypes
+        flags = (ctypes.c_uint * 256)()
+        torch.cuda.synchronize()
+        from distributed_tensorflow_amd.ops import native as _n
+        rt = ctypes.CDLL("libamdhip64.so")
+        rt.hipMemcpy.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int]
+        assert rt.hipMemcpy(flags, ctypes.c_void_p(ws + 256 * 128 * 128 * 4), 1024, 2) == 0
+        assert not any(flags)
+    finally:
+        gpu_lib.dtf_gemm_f32_sk_workspace_free(ws)
+
+
 # ----------------------------------------------------------------------- conv1
 @pytest.mark.parametrize("B,C", [(1, 32), (37, 32), (8, 128)])
 def test_conv1_f32_fwd(gpu_lib, B, C):
